@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libdeepsee_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libdeepsee_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+OBJS=()
+for f in *.hip *.cpp; do
+  [ -e "$f" ] || continue
+  o="build/${f%.*}.o"
+  mkdir -p build
+  if [ ! -e "$o" ] || [ "$f" -nt "$o" ] || [ dsee_common.h -nt "$o" ] || [ ../../include/deepsee_hip.h -nt "$o" ]; then
+    echo "hipcc $f"
+    if [[ "$f" == *.hip ]]; then hipcc $FLAGS -c "$f" -o "$o"; else hipcc $FLAGS -x hip -c "$f" -o "$o"; fi
+  fi
+  OBJS+=("$o")
+done
+hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "$OUT"
+echo "built $(realpath $OUT)"

@@ -1,0 +1,52 @@
+// Internal helpers shared by every translation unit of libdeepsee_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/deepsee_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void dsee_set_error(const char* fmt, ...);
+
+#define DSEE_CHECK_ARG(cond)                                                        \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      dsee_set_error("%s:%d: argument check failed: %s", __FILE__, __LINE__, #cond); \
+      return DSEE_EINVAL;                                                           \
+    }                                                                               \
+  } while (0)
+
+#define DSEE_LAUNCH_CHECK()                                                            \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) {                                                           \
+      dsee_set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return DSEE_ELAUNCH;                                                             \
+    }                                                                                  \
+  } while (0)
+
+static inline int dsee_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float dsee_act(float v, int act, float slope) {
+  if (act == DSEE_ACT_LRELU) return v > 0.f ? v : v * slope;
+  if (act == DSEE_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == DSEE_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// d(act)/d(pre) expressed through the saved OUTPUT y (valid for lrelu/relu/tanh).
+__device__ __forceinline__ float dsee_act_grad_from_out(float y, int act, float slope) {
+  if (act == DSEE_ACT_LRELU) return y > 0.f ? 1.f : slope;
+  if (act == DSEE_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == DSEE_ACT_TANH) return 1.f - y * y;
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
