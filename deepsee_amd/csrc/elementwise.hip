@@ -1,0 +1,510 @@
+// Streaming (HBM-bound) element-wise kernels of the hot path, NHWC fp32, 16 B per lane.
+//
+//  * noise injection + nearest x2 upsample  (normalization.py:289-304, sr.py:57,69,87, architecture.py:76-77,111-112,133-134)
+//  * activation backward, residual helpers
+//  * avg_pool2d(3,2,1,count_include_pad=False) (discriminator.py:46-49), max_pool2d(2,2) (VGG19)
+//  * input preparation: label float->uint8, NCHW<->NHWC(pad 4), bicubic downsample + clamp
+//    (data/preprocessor.py:17-41, base_manager.py:28-66), discriminator input cat([seg, image]) (sr_model.py:655-668)
+//  * counter-based N(0,1)/U(0,1) generators (replaces tensor.normal_() / torch.rand_like on the device)
+#include "dsee_common.h"
+
+namespace {
+
+inline int egrid(long n) { return (int)min(8192L, (n + 255) / 256); }
+
+// y[n,h,w,c] = x[n,h>>ups,w>>ups,c] + nw[c]*eps[n,h,w,c]
+__global__ __launch_bounds__(256) void up_noise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                           const float* __restrict__ nw, float* __restrict__ y, int N,
+                                                           int H, int W, int C, int ups) {
+  const long total4 = (long)N * H * W * C / 4;
+  const int C4 = C / 4, h0 = H >> ups, w0 = W >> ups;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * h0 + (h >> ups)) * w0 + (w >> ups)) * C + q * 4);
+    if (eps) v += *reinterpret_cast<const f32x4*>(nw + q * 4) * *reinterpret_cast<const f32x4*>(eps + i * 4);
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// dx[n,h0,w0,c] = sum over the 2^ups x 2^ups block of dy  (+ add)
+__global__ __launch_bounds__(256) void sumpool_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H,
+                                                      int W, int C, int ups) {
+  const int h0 = H >> ups, w0 = W >> ups, C4 = C / 4, f = 1 << ups;
+  const long total4 = (long)N * h0 * w0 * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % w0);
+    t /= w0;
+    const int h = (int)(t % h0), n = (int)(t / h0);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < f; ++a)
+      for (int b = 0; b < f; ++b)
+        v += *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + h * f + a) * W + w * f + b) * C + q * 4);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = v;
+  }
+}
+
+// part[blk][C] = sum_pixels a*b  (b optional -> column sums), fixed order
+__global__ __launch_bounds__(256) void chdot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ part, long M, int C, int chunk_px) {
+  __shared__ f32x4 red[256];
+  const int tpp = C / 4, ppb = 256 / tpp > 0 ? 256 / tpp : 1;
+  const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
+  const bool active = threadIdx.x < ppb * tpp;
+  const long p0 = (long)blockIdx.x * chunk_px, p1 = min(M, p0 + chunk_px);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (active)
+    for (long p = p0 + s; p < p1; p += ppb) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(a + p * C + q * 4);
+      if (b) v *= *reinterpret_cast<const f32x4*>(b + p * C + q * 4);
+      acc += v;
+    }
+  if (active) red[s * tpp + q] = acc;
+  __syncthreads();
+  if (active && s == 0) {
+    f32x4 v = red[q];
+    for (int j = 1; j < ppb; ++j) v += red[j * tpp + q];
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + q * 4) = v;
+  }
+}
+
+__global__ void chdot_finalize_kernel(const float* __restrict__ part, int parts, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float v = 0.f;
+  for (int p = 0; p < parts; ++p) v += part[(size_t)p * C + c];
+  out[c] = v;
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dx, long total4, int act, float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = d[k] * dsee_act_grad_from_out(v[k], act, slope);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total4,
+                                                      int act, float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = dsee_act(v[k], act, slope);
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// y = a*alpha + b*beta  (b optional)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b,
+                                                    float beta, float* __restrict__ y, long total4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(a + i * 4) * alpha;
+    if (b) v += *reinterpret_cast<const f32x4*>(b + i * 4) * beta;
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// avg_pool2d(k=3, s=2, p=1, count_include_pad=False)
+__global__ __launch_bounds__(256) void avgpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                             int H, int W, int Ho, int Wo, int C) {
+  const int C4 = C / 4;
+  const long total4 = (long)N * Ho * Wo * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho), n = (int)(t / Ho);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    for (int a = -1; a <= 1; ++a)
+      for (int b = -1; b <= 1; ++b) {
+        const int h = oh * 2 + a, w = ow * 2 + b;
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+          v += *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + h) * W + w) * C + q * 4);
+          ++cnt;
+        }
+      }
+    *reinterpret_cast<f32x4*>(y + i * 4) = v / (float)cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool3s2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                                             int H, int W, int Ho, int Wo, int C) {
+  const int C4 = C / 4;
+  const long total4 = (long)N * H * W * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // outputs (oh,ow) whose window [2oh-1, 2oh+1] contains h
+    for (int oh = (h) / 2; oh <= (h + 1) / 2; ++oh)
+      for (int ow = (w) / 2; ow <= (w + 1) / 2; ++ow) {
+        if (oh < 0 || oh >= Ho || ow < 0 || ow >= Wo) continue;
+        if (abs(oh * 2 - h) > 1 || abs(ow * 2 - w) > 1) continue;
+        const int ch = min(H - 1, oh * 2 + 1) - max(0, oh * 2 - 1) + 1;
+        const int cw = min(W - 1, ow * 2 + 1) - max(0, ow * 2 - 1) + 1;
+        v += *reinterpret_cast<const f32x4*>(dy + (((size_t)n * Ho + oh) * Wo + ow) * C + q * 4) / (float)(ch * cw);
+      }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                           int H, int W, int C) {
+  const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
+  const long total4 = (long)N * Ho * Wo * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho), n = (int)(t / Ho);
+    const float* b = x + (((size_t)n * H + oh * 2) * W + ow * 2) * C + q * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(b);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(b + C);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(b + (size_t)W * C);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(b + (size_t)W * C + C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaxf(v[k], v1[k]), fmaxf(v2[k], v3[k]));
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// gradient goes to the FIRST maximum in scan order (torch CPU max_pool2d semantics)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dx, int N, int H, int W, int C) {
+  const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
+  const long total4 = (long)N * Ho * Wo * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho), n = (int)(t / Ho);
+    const size_t o0 = (((size_t)n * H + oh * 2) * W + ow * 2) * C + q * 4;
+    const size_t offs[4] = {o0, o0 + C, o0 + (size_t)W * C, o0 + (size_t)W * C + C};
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + offs[j]);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    f32x4 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int best = 0;
+      float bv = v[0][k];
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        if (v[j][k] > bv) {
+          bv = v[j][k];
+          best = j;
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j][k] = j == best ? g[k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dx + offs[j]) = r[j];
+  }
+}
+
+// ---- layout / input preparation
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
+                                    int Cs) {
+  const long total = (long)N * H * W * Cs;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cs);
+    long t = i / Cs;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    y[i] = c < C ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f;
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
+                                    int Cs) {
+  const long total = (long)N * C * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    long t = i / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C), n = (int)(t / C);
+    y[i] = x[(((size_t)n * H + h) * W + w) * Cs + c];
+  }
+}
+
+__global__ void label_to_u8_kernel(const float* __restrict__ lab, uint8_t* __restrict__ out, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    out[i] = (uint8_t)(long)lab[i];  // .long() truncation (base_manager.py:35-39)
+}
+
+// cat([one-hot(label), image]) in NHWC: channels [0,L) one-hot, [L,L+3) image, rest 0 (sr_model.py:655-668)
+__global__ void build_d_input_kernel(const uint8_t* __restrict__ lab, const float* __restrict__ img,
+                                     float* __restrict__ out, long pixels, int L, int Cs, int img_cs) {
+  const long total = pixels * Cs;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cs);
+    const long p = i / Cs;
+    float v = 0.f;
+    if (c < L) v = lab[p] == c ? 1.f : 0.f;
+    else if (c < L + 3) v = img[p * img_cs + (c - L)];
+    out[i] = v;
+  }
+}
+
+// d(image) from d(D input): dimg[p][k] = din[p][L+k]
+__global__ void extract_image_grad_kernel(const float* __restrict__ din, float* __restrict__ dimg, long pixels, int L,
+                                          int Cs, int img_cs) {
+  const long total = pixels * img_cs;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % img_cs);
+    const long p = i / img_cs;
+    dimg[i] = c < 3 ? din[p * Cs + L + c] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+  const float A = -0.75f;  // PyTorch bicubic
+  float x = t + 1.f;
+  w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+  x = t;
+  w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 1.f - t;
+  w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 2.f - t;
+  w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+
+// F.interpolate(mode='bicubic', align_corners=False) + clamp(-1,1); NHWC in (Cs_in) -> NHWC out (Cs_out), 3 channels
+__global__ void bicubic_down_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int S,
+                                    int cs_in, int cs_out) {
+  const long total = (long)N * S * S * cs_out;
+  const float sh = (float)H / S, sw = (float)W / S;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cs_out);
+    long t = i / cs_out;
+    const int ow = (int)(t % S);
+    t /= S;
+    const int oh = (int)(t % S), n = (int)(t / S);
+    if (c >= 3) {
+      y[i] = 0.f;
+      continue;
+    }
+    const float fy = sh * (oh + 0.5f) - 0.5f, fx = sw * (ow + 0.5f) - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_coeffs(fy - iy, wy);
+    cubic_coeffs(fx - ix, wx);
+    float acc = 0.f;
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max(iy - 1 + a, 0), H - 1);
+      float row = 0.f;
+      for (int b = 0; b < 4; ++b) {
+        const int xx = min(max(ix - 1 + b, 0), W - 1);
+        row += wx[b] * x[(((size_t)n * H + yy) * W + xx) * cs_in + c];
+      }
+      acc += wy[a] * row;
+    }
+    y[i] = fminf(fmaxf(acc, -1.f), 1.f);
+  }
+}
+
+// ---- Philox4x32-10 counter RNG
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+  c[0] = h1 ^ c[1] ^ k0;
+  c[1] = l1;
+  c[2] = h0 ^ c[3] ^ k1;
+  c[3] = l0;
+}
+
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = c[k];
+}
+
+__global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, long total4, uint64_t seed,
+                                                       uint64_t offset, int normal) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(seed, offset + (uint64_t)i, r);
+    f32x4 v;
+    if (normal) {
+      // Box-Muller on two pairs
+      const float u0 = ((float)r[0] + 1.f) * 2.3283064e-10f, u1 = (float)r[1] * 2.3283064e-10f;
+      const float u2 = ((float)r[2] + 1.f) * 2.3283064e-10f, u3 = (float)r[3] * 2.3283064e-10f;
+      const float a = sqrtf(-2.f * __logf(u0)), b = sqrtf(-2.f * __logf(u2));
+      float s0, c0, s1, c1;
+      __sincosf(6.2831853f * u1, &s0, &c0);
+      __sincosf(6.2831853f * u3, &s1, &c1);
+      v = (f32x4){a * c0, a * s0, b * c1, b * s1};
+    } else {
+      v = (f32x4){(float)(r[0] >> 8), (float)(r[1] >> 8), (float)(r[2] >> 8), (float)(r[3] >> 8)} * 5.9604645e-8f;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise_w, float* y, int N, int H, int W, int C,
+                            int ups, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && C % 4 == 0 && (eps == nullptr || noise_w != nullptr));
+  up_noise_fwd_kernel<<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, eps, noise_w, y, N, H, W, C, ups);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dx && C % 4 == 0 && ups >= 1);
+  sumpool_kernel<<<egrid((long)N * (H >> ups) * (W >> ups) * C / 4), 256, 0, st>>>(dy, dx, N, H, W, C, ups);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+size_t dsee_channel_dot_workspace(long M, int C) {
+  long cp = (M + 1023) / 1024;
+  if (cp < 64) cp = 64;
+  return (size_t)((M + cp - 1) / cp) * C * sizeof(float);
+}
+
+/* out[c] = sum_m a[m][c] * b[m][c]   (b == NULL: column sums).  d(noise weight) = sum dy*eps
+ * (normalization.py:303-304), conv bias gradients. */
+int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(a && out && workspace && C % 4 == 0 && C <= 1024);
+  long cp = (M + 1023) / 1024;
+  if (cp < 64) cp = 64;
+  const int parts = (int)((M + cp - 1) / cp);
+  chdot_partial_kernel<<<parts, 256, 0, st>>>(a, b, workspace, M, C, (int)cp);
+  DSEE_LAUNCH_CHECK();
+  chdot_finalize_kernel<<<dsee_cdiv(C, 256), 256, 0, st>>>(workspace, parts, C, out);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && n % 4 == 0);
+  act_fwd_kernel<<<egrid(n / 4), 256, 0, st>>>(x, y, n / 4, act, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && y && dx && n % 4 == 0);
+  act_bwd_kernel<<<egrid(n / 4), 256, 0, st>>>(dy, y, dx, n / 4, act, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_axpby(const float* a, float alpha, const float* b, float beta, float* y, long n, hipStream_t st) {
+  DSEE_CHECK_ARG(a && y && n % 4 == 0);
+  axpby_kernel<<<egrid(n / 4), 256, 0, st>>>(a, alpha, b, beta, y, n / 4);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && C % 4 == 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  avgpool3s2_fwd_kernel<<<egrid((long)N * Ho * Wo * C / 4), 256, 0, st>>>(x, y, N, H, W, Ho, Wo, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dx && C % 4 == 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  avgpool3s2_bwd_kernel<<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(dy, dx, N, H, W, Ho, Wo, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && C % 4 == 0 && H % 2 == 0 && W % 2 == 0);
+  maxpool2_fwd_kernel<<<egrid((long)N * (H / 2) * (W / 2) * C / 4), 256, 0, st>>>(x, y, N, H, W, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && x && dx && C % 4 == 0 && H % 2 == 0 && W % 2 == 0);
+  maxpool2_bwd_kernel<<<egrid((long)N * (H / 2) * (W / 2) * C / 4), 256, 0, st>>>(dy, x, dx, N, H, W, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cs, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && Cs >= C);
+  nchw_to_nhwc_kernel<<<egrid((long)N * H * W * Cs), 256, 0, st>>>(x, y, N, C, H, W, Cs);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cs, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && Cs >= C);
+  nhwc_to_nchw_kernel<<<egrid((long)N * C * H * W), 256, 0, st>>>(x, y, N, C, H, W, Cs);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_label_to_u8(const float* label, uint8_t* out, long n, hipStream_t st) {
+  DSEE_CHECK_ARG(label && out);
+  label_to_u8_kernel<<<egrid(n), 256, 0, st>>>(label, out, n);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_build_d_input(const uint8_t* lab, const float* img, float* out, long pixels, int L, int Cs, int img_cs,
+                       hipStream_t st) {
+  DSEE_CHECK_ARG(lab && img && out && Cs >= L + 3 && img_cs >= 3);
+  build_d_input_kernel<<<egrid(pixels * Cs), 256, 0, st>>>(lab, img, out, pixels, L, Cs, img_cs);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_extract_image_grad(const float* din, float* dimg, long pixels, int L, int Cs, int img_cs, hipStream_t st) {
+  DSEE_CHECK_ARG(din && dimg && Cs >= L + 3 && img_cs >= 3);
+  extract_image_grad_kernel<<<egrid(pixels * img_cs), 256, 0, st>>>(din, dimg, pixels, L, Cs, img_cs);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_bicubic_down(const float* x, float* y, int N, int H, int W, int S, int cs_in, int cs_out, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && cs_in >= 3 && cs_out >= 3);
+  bicubic_down_kernel<<<egrid((long)N * S * S * cs_out), 256, 0, st>>>(x, y, N, H, W, S, cs_in, cs_out);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_rng_fill(float* out, long n, uint64_t seed, uint64_t offset, int normal, hipStream_t st) {
+  DSEE_CHECK_ARG(out && n % 4 == 0);
+  rng_fill_kernel<<<egrid(n / 4), 256, 0, st>>>(out, n / 4, seed, offset, normal);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"

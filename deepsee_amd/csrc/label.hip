@@ -1,0 +1,275 @@
+// Label-map indexed kernels: everything the reference does with the 19-channel one-hot `input_semantics`
+// tensor (data/preprocessor.py:35-41) is restated on a uint8 label map [N][H][W] (76x fewer bytes).
+//
+//  * onehot_conv3x3: mlp_shared = ReLU(conv3x3(one-hot seg)) (normalization.py:98-101,110-114,174-175) is a
+//    9-tap gather-sum of weight columns; its weight gradient is a label-segmented sum.
+//  * label_gather:   style_map[b,:,h,w] = style[b, label[b,h,w], :]   (normalization.py:179-185), also the
+//    backward of style pooling.
+//  * label_segsum:   S[b,r,c] = scale * sum_{hw: label=r} f[b,h,w,c]   (encoder.py:36-49 extract_style_matrix,
+//    divides by H*W not by region area), also the backward of label_gather.
+//  * nearest resize of the label map is index math: src = dst << shift  (F.interpolate 'nearest', SURVEY B-3).
+#include "dsee_common.h"
+
+namespace {
+
+__device__ __forceinline__ int lab_at(const uint8_t* lab, int n, int H, int W, int shift, int h, int w) {
+  return lab[((size_t)n * H + ((size_t)h << shift)) * W + ((size_t)w << shift)];
+}
+
+// wt: [9][L][Co] (tap-major table), out[m][out_ld] at channel offset coff, Co % 4 == 0
+__global__ __launch_bounds__(256) void onehot_conv_fwd_kernel(const uint8_t* __restrict__ lab,
+                                                              const float* __restrict__ wt,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int N, int H, int W, int shift, int R, int Rw, int L,
+                                                              int Co, int out_ld, int coff, int relu) {
+  const int tpp = Co / 4, ppb = 256 / tpp;
+  const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
+  if (s >= ppb) return;
+  const long M = (long)N * R * Rw;
+  const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long m = (long)blockIdx.x * ppb + s; m < M; m += (long)gridDim.x * ppb) {
+    const int w = (int)(m % Rw);
+    const long t = m / Rw;
+    const int h = (int)(t % R), n = (int)(t / R);
+    f32x4 acc = b;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int hh = h + dy, ww = w + dx;
+        if (hh >= 0 && hh < R && ww >= 0 && ww < Rw) {
+          const int r = lab_at(lab, n, H, W, shift, hh, ww);
+          const int tap = (dy + 1) * 3 + (dx + 1);
+          acc += *reinterpret_cast<const f32x4*>(wt + ((size_t)tap * L + r) * Co + q * 4);
+        }
+      }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + m * out_ld + coff + q * 4) = acc;
+  }
+}
+
+__global__ void onehot_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int L) {
+  // w [Co][L][3][3] -> wt [9][L][Co]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * L * Co) return;
+  const int co = i % Co, r = (i / Co) % L, tap = i / (Co * L);
+  wt[i] = w[((size_t)co * L + r) * 9 + tap];
+}
+
+// Weight gradient of the one-hot conv.  Block = 128 channels x 2 tap groups; each thread owns its channel's
+// accumulator column in LDS ([9*L][128] floats), so no atomics and a fixed summation order.
+__global__ __launch_bounds__(256) void onehot_conv_wgrad_kernel(const uint8_t* __restrict__ lab,
+                                                                const float* __restrict__ dact,
+                                                                const float* __restrict__ act, int ld, int coff, int N,
+                                                                int H, int W, int shift, int R, int Rw, int L,
+                                                                int chunk_px, float* __restrict__ part) {
+  extern __shared__ float accs[];  // [9*L + 1][128]   (last row: bias gradient)
+  const int c = threadIdx.x & 127, tg = threadIdx.x >> 7;
+  const int rows = 9 * L + 1;
+  for (int i = threadIdx.x; i < rows * 128; i += 256) accs[i] = 0.f;
+  __syncthreads();
+  const long M = (long)N * R * Rw;
+  const long m0 = (long)blockIdx.x * chunk_px, m1 = min(M, m0 + chunk_px);
+  const int t0 = tg == 0 ? 0 : 5, t1 = tg == 0 ? 5 : 9;
+  for (long m = m0; m < m1; ++m) {
+    const size_t o = (size_t)m * ld + coff + c;
+    const float g = act[o] > 0.f ? dact[o] : 0.f;
+    const int w = (int)(m % Rw);
+    const long t = m / Rw;
+    const int h = (int)(t % R), n = (int)(t / R);
+    for (int tap = t0; tap < t1; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      if (hh >= 0 && hh < R && ww >= 0 && ww < Rw) {
+        const int r = lab_at(lab, n, H, W, shift, hh, ww);
+        accs[(tap * L + r) * 128 + c] += g;
+      }
+    }
+    if (tg == 0) accs[(9 * L) * 128 + c] += g;
+  }
+  __syncthreads();
+  float* o = part + (size_t)blockIdx.x * rows * 128;
+  for (int i = threadIdx.x; i < rows * 128; i += 256) o[i] = accs[i];
+}
+
+__global__ void onehot_wgrad_finalize_kernel(const float* __restrict__ part, int nparts, int L, float* __restrict__ dw,
+                                             float* __restrict__ db) {
+  // dw [128][L][3][3], db [128]
+  const int rows = 9 * L + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * 128) return;
+  const int c = i % 128, row = i / 128;
+  float v = 0.f;
+  for (int p = 0; p < nparts; ++p) v += part[(size_t)p * rows * 128 + i];
+  if (row == 9 * L) {
+    db[c] = v;
+  } else {
+    const int tap = row / L, r = row % L;
+    dw[((size_t)c * L + r) * 9 + tap] = v;
+  }
+}
+
+// out[m][ld] @coff = scale * table[n][lab(m)][:]
+__global__ __launch_bounds__(256) void label_gather_kernel(const uint8_t* __restrict__ lab,
+                                                           const float* __restrict__ table, float* __restrict__ out,
+                                                           int N, int H, int W, int shift, int R, int Rw, int L, int Cs,
+                                                           int ld, int coff, float scale) {
+  const int tpp = Cs / 4, ppb = 256 / tpp;
+  const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
+  if (s >= ppb) return;
+  const long M = (long)N * R * Rw;
+  for (long m = (long)blockIdx.x * ppb + s; m < M; m += (long)gridDim.x * ppb) {
+    const int w = (int)(m % Rw);
+    const long t = m / Rw;
+    const int h = (int)(t % R), n = (int)(t / R);
+    const int r = lab_at(lab, n, H, W, shift, h, w);
+    f32x4 v = *reinterpret_cast<const f32x4*>(table + ((size_t)n * L + r) * Cs + q * 4) * scale;
+    *reinterpret_cast<f32x4*>(out + m * ld + coff + q * 4) = v;
+  }
+}
+
+// part[n][chunk][L][Cs] = sum_{pixels of chunk with label r} in[m][coff + c]
+__global__ __launch_bounds__(256) void label_segsum_kernel(const uint8_t* __restrict__ lab,
+                                                           const float* __restrict__ in, int ld, int coff, int H, int W,
+                                                           int shift, int R, int Rw, int L, int Cs, int chunk_px,
+                                                           int chunks, float* __restrict__ part) {
+  extern __shared__ float accs[];  // [slots][L][Cs]
+  const int slots = 256 / Cs > 0 ? 256 / Cs : 1;
+  const int c = threadIdx.x % Cs, s = threadIdx.x / Cs;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  for (int i = threadIdx.x; i < slots * L * Cs; i += 256) accs[i] = 0.f;
+  __syncthreads();
+  const int P = R * Rw;
+  const int p0 = chunk * chunk_px, p1 = min(P, p0 + chunk_px);
+  if (s < slots && threadIdx.x < slots * Cs) {
+    for (int p = p0 + s; p < p1; p += slots) {
+      const int h = p / Rw, w = p % Rw;
+      const int r = lab_at(lab, n, H, W, shift, h, w);
+      accs[(s * L + r) * Cs + c] += in[((size_t)n * P + p) * ld + coff + c];
+    }
+  }
+  __syncthreads();
+  float* o = part + ((size_t)n * chunks + chunk) * L * Cs;
+  for (int i = threadIdx.x; i < L * Cs; i += 256) {
+    float v = 0.f;
+    for (int k = 0; k < slots; ++k) v += accs[k * L * Cs + i];
+    o[i] = v;
+  }
+}
+
+__global__ void segsum_finalize_kernel(const float* __restrict__ part, int chunks, int LC, int N, float scale,
+                                       float* __restrict__ table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * LC) return;
+  const int n = i / LC, j = i % LC;
+  float v = 0.f;
+  for (int k = 0; k < chunks; ++k) v += part[((size_t)n * chunks + k) * LC + j];
+  table[i] = v * scale;
+}
+
+int seg_chunks(int N, int P, int* chunk_px) {
+  int want = 1024 / (N > 0 ? N : 1);
+  if (want < 1) want = 1;
+  int cp = (P + want - 1) / want;
+  if (cp < 256) cp = 256;
+  *chunk_px = cp;
+  return (P + cp - 1) / cp;
+}
+
+int wgrad_parts(long M, int* chunk_px) {
+  long cp = (M + 511) / 512;
+  if (cp < 256) cp = 256;
+  *chunk_px = (int)cp;
+  return (int)((M + cp - 1) / cp);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsee_onehot_conv3x3_pack(const float* w_oihw, float* table, int Co, int L, hipStream_t st) {
+  DSEE_CHECK_ARG(w_oihw && table && Co > 0 && L > 0);
+  onehot_pack_kernel<<<dsee_cdiv((long)9 * L * Co, 256), 256, 0, st>>>(w_oihw, table, Co, L);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float* bias, float* out, int N, int H, int W,
+                            int shift, int L, int Co, int out_ld, int coff, int relu, hipStream_t st) {
+  DSEE_CHECK_ARG(lab && table && out && Co % 4 == 0 && Co <= 1024 && out_ld % 4 == 0 && coff % 4 == 0);
+  const int R = H >> shift, Rw = W >> shift;
+  const long M = (long)N * R * Rw;
+  const int ppb = 256 / (Co / 4);
+  onehot_conv_fwd_kernel<<<(int)min(4096L, (M + ppb - 1) / ppb), 256, 0, st>>>(lab, table, bias, out, N, H, W, shift, R,
+                                                                                Rw, L, Co, out_ld, coff, relu);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+size_t dsee_onehot_conv3x3_wgrad_workspace(int N, int H, int W, int shift, int L) {
+  int cp;
+  const long M = (long)N * (H >> shift) * (W >> shift);
+  return (size_t)wgrad_parts(M, &cp) * (9 * L + 1) * 128 * sizeof(float);
+}
+
+/* dW_sh[:, r, tap] = sum_{p : lab(p+tap)=r} relu'(act[p]) * dact[p]  (SURVEY Appendix E); Co fixed at 128
+ * (normalization.py:95 nhidden).  act/dact are [M][ld] with the 128 channels at offset coff. */
+int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, const float* act, int ld, int coff, int N, int H,
+                              int W, int shift, int L, float* dw_oihw, float* dbias, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(lab && dact && act && dw_oihw && dbias && workspace && L <= 32);
+  const int R = H >> shift, Rw = W >> shift;
+  const long M = (long)N * R * Rw;
+  int cp;
+  const int parts = wgrad_parts(M, &cp);
+  const size_t lds = (size_t)(9 * L + 1) * 128 * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&onehot_conv_wgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  onehot_conv_wgrad_kernel<<<parts, 256, lds, st>>>(lab, dact, act, ld, coff, N, H, W, shift, R, Rw, L, cp, workspace);
+  DSEE_LAUNCH_CHECK();
+  onehot_wgrad_finalize_kernel<<<dsee_cdiv((long)(9 * L + 1) * 128, 256), 256, 0, st>>>(workspace, parts, L, dw_oihw,
+                                                                                        dbias);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_label_gather(const uint8_t* lab, const float* table, float* out, int N, int H, int W, int shift, int L, int Cs,
+                      int out_ld, int coff, float scale, hipStream_t st) {
+  DSEE_CHECK_ARG(lab && table && out && Cs % 4 == 0 && Cs <= 1024 && out_ld % 4 == 0 && coff % 4 == 0);
+  const int R = H >> shift, Rw = W >> shift;
+  const long M = (long)N * R * Rw;
+  const int ppb = 256 / (Cs / 4);
+  label_gather_kernel<<<(int)min(4096L, (M + ppb - 1) / ppb), 256, 0, st>>>(lab, table, out, N, H, W, shift, R, Rw, L,
+                                                                             Cs, out_ld, coff, scale);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+size_t dsee_label_segsum_workspace(int N, int H, int W, int shift, int L, int Cs) {
+  int cp;
+  const int chunks = seg_chunks(N, (H >> shift) * (W >> shift), &cp);
+  return (size_t)N * chunks * L * Cs * sizeof(float);
+}
+
+int dsee_label_segsum(const uint8_t* lab, const float* in, int ld, int coff, float* table, int N, int H, int W,
+                      int shift, int L, int Cs, float scale, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(lab && in && table && workspace && Cs <= 256 && L <= 32);
+  const int R = H >> shift, Rw = W >> shift;
+  int cp;
+  const int chunks = seg_chunks(N, R * Rw, &cp);
+  const int slots = 256 / Cs > 0 ? 256 / Cs : 1;
+  const size_t lds = (size_t)slots * L * Cs * sizeof(float);
+  label_segsum_kernel<<<dim3(chunks, N), 256, lds, st>>>(lab, in, ld, coff, H, W, shift, R, Rw, L, Cs, cp, chunks,
+                                                         workspace);
+  DSEE_LAUNCH_CHECK();
+  segsum_finalize_kernel<<<dsee_cdiv((long)N * L * Cs, 256), 256, 0, st>>>(workspace, chunks, L * Cs, N, scale, table);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,334 @@
+// Per-channel statistics and the backward halves of the normalisation layers (NHWC fp32, HBM-bound).
+//
+//  * sync-free BatchNorm batch statistics (sync_batchnorm/batchnorm.py:65-68 == F.batch_norm, biased var + eps,
+//    running stats momentum .1 with unbiased var) and InstanceNorm2d(affine=False) statistics
+//    (normalization.py:47-48) are the same kernel with `groups` = 1 or N.
+//  * InstanceNorm + LeakyReLU / tanh apply (discriminator.py:88-93, encoder.py:24-27,83-99).
+//  * backward of IN+act and of the fused BN + SPADE/SEAN modulate + LeakyReLU.
+//
+// Layout of every reduction: a block owns a contiguous pixel range of one group; thread t owns the channel
+// quad (t % tpp) of pixel slot (t / tpp), streams float4 loads (16 B/lane, coalesced across the quad
+// dimension), combines the slots through LDS in a fixed order and writes one partial row; a finalize kernel
+// folds the partial rows in index order, so results are bit-reproducible run to run.
+#include "dsee_common.h"
+
+namespace {
+
+struct RedGeom {
+  int C, tpp, ppb;      // channels, threads per pixel (C/4), pixels per block iteration
+  int groups, P;        // pixels per group
+  int chunks, chunk_px; // per group
+};
+
+RedGeom make_geom(int N, int HW, int C, int groups) {
+  RedGeom g;
+  g.C = C;
+  g.tpp = C / 4;
+  g.ppb = 256 / g.tpp;
+  if (g.ppb < 1) g.ppb = 1;
+  g.groups = groups;
+  g.P = (N / groups) * HW;
+  long want = ((long)g.P * groups + 2047) / 2048;
+  long cp = want > (long)g.ppb * 4 ? want : (long)g.ppb * 4;
+  cp = (cp + g.ppb - 1) / g.ppb * g.ppb;
+  g.chunk_px = (int)cp;
+  g.chunks = (g.P + g.chunk_px - 1) / g.chunk_px;
+  return g;
+}
+
+// combine K float4 accumulators over the pixel slots of a block (fixed order), result valid for slot 0
+template <int K>
+__device__ __forceinline__ void block_combine(f32x4 (&acc)[K], int q, int s, int tpp, int ppb, bool active) {
+  __shared__ f32x4 red[K * 256];
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(k * ppb + s) * tpp + q] = acc[k];
+  }
+  __syncthreads();
+  if (active && s == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      f32x4 v = red[(k * ppb) * tpp + q];
+      for (int j = 1; j < ppb; ++j) v += red[(k * ppb + j) * tpp + q];
+      acc[k] = v;
+    }
+  }
+}
+
+// ---- statistics: shifted sums (shift = first pixel of the chunk) -> (count, mean, M2) partials
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                            RedGeom g) {
+  const int tid = threadIdx.x, q = tid % g.tpp, s = tid / g.tpp;
+  const bool active = s < g.ppb && q < g.tpp && tid < g.ppb * g.tpp;
+  const int grp = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * g.chunk_px, p1 = min(g.P, p0 + g.chunk_px);
+  const float* xb = x + (size_t)grp * g.P * g.C;
+  f32x4 acc[2];
+  acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 shift = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    shift = *reinterpret_cast<const f32x4*>(xb + (size_t)p0 * g.C + q * 4);
+    for (int p = p0 + s; p < p1; p += g.ppb) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)p * g.C + q * 4) - shift;
+      acc[0] += v;
+      acc[1] += v * v;
+    }
+  }
+  block_combine<2>(acc, q, s, g.tpp, g.ppb, active);
+  if (active && s == 0) {
+    const float n = (float)(p1 - p0);
+    f32x4 mean = shift + acc[0] / n;
+    f32x4 m2 = acc[1] - acc[0] * acc[0] / n;
+    float* o = part + ((size_t)(grp * g.chunks + chunk) * 2) * g.C + q * 4;
+    *reinterpret_cast<f32x4*>(o) = mean;
+    *reinterpret_cast<f32x4*>(o + g.C) = m2;
+  }
+}
+
+__global__ void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_out,
+                                      float* __restrict__ invstd_out, float* __restrict__ run_mean,
+                                      float* __restrict__ run_var, RedGeom g, float eps, float momentum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.groups * g.C) return;
+  const int grp = i / g.C, c = i % g.C;
+  // Chan's parallel merge, chunks in index order
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int k = 0; k < g.chunks; ++k) {
+    const int p0 = k * g.chunk_px, p1 = min(g.P, p0 + g.chunk_px);
+    const float nb = (float)(p1 - p0);
+    const float mb = part[((size_t)(grp * g.chunks + k) * 2) * g.C + c];
+    const float m2b = part[((size_t)(grp * g.chunks + k) * 2 + 1) * g.C + c];
+    const float d = mb - mean, nt = n + nb;
+    mean += d * nb / nt;
+    m2 += m2b + d * d * n * nb / nt;
+    n = nt;
+  }
+  const float var = m2 / n;  // biased
+  mean_out[i] = mean;
+  invstd_out[i] = 1.0f / sqrtf(var + eps);  // precise form (not rsqrtf) for parity with torch
+  if (run_mean && g.groups == 1) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+  }
+}
+
+__global__ void eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                  float* __restrict__ mean_out, float* __restrict__ invstd_out, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    mean_out[c] = run_mean[c];
+    invstd_out[c] = 1.0f / sqrtf(run_var[c] + eps);
+  }
+}
+
+// ---- y = act((x - mean[g][c]) * invstd[g][c])
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ y,
+                                                           long total4, int C, long group_elems, int act, float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const int c = (int)(e % C);
+    const int grp = (int)(e / group_elems);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)grp * C + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)grp * C + c);
+    f32x4 r = (v - mu) * is;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = dsee_act(r[k], act, slope);
+    *reinterpret_cast<f32x4*>(y + e) = r;
+  }
+}
+
+// ---- backward, pass 1: per-(group,channel) sums.
+// MODE 0 (IN + act):   g = dy * act'(y);            S0 = sum g,        S1 = sum g*xhat
+// MODE 1 (BN modulate): g = dh * lrelu'(h); d = g*scale; S0 = sum d, S1 = sum d*xhat, S2 = sum g*xhat, S3 = sum g
+//   and writes dgb[m][packed(gamma c)] = g*xhat, dgb[m][packed(beta c)] = g  (the "dout" of the gamma/beta conv).
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              float* __restrict__ dgb, int dgb_ld,
+                                                              float* __restrict__ part, RedGeom g, int act,
+                                                              float slope) {
+  constexpr int K = MODE == 0 ? 2 : 4;
+  const int tid = threadIdx.x, q = tid % g.tpp, s = tid / g.tpp;
+  const bool active = tid < g.ppb * g.tpp;
+  const int grp = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * g.chunk_px, p1 = min(g.P, p0 + g.chunk_px);
+  const size_t gb = (size_t)grp * g.P;
+  f32x4 acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)grp * g.C + q * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)grp * g.C + q * 4);
+    // packed gamma/beta column of channel c: b*128 + w*64 + h*32 + cc with c = b*64 + w*32 + cc
+    const int c0 = q * 4;
+    const int pcol = (c0 >> 6) * 128 + ((c0 >> 5) & 1) * 64 + (c0 & 31);
+    for (int p = p0 + s; p < p1; p += g.ppb) {
+      const size_t o = (gb + p) * g.C + c0;
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+      f32x4 gg;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gg[k] = dv[k] * dsee_act_grad_from_out(yv[k], act, slope);
+      if constexpr (MODE == 0) {
+        acc[0] += gg;
+        acc[1] += gg * xh;
+      } else {
+        const f32x4 d = gg * *reinterpret_cast<const f32x4*>(scale + o);
+        const f32x4 gx = gg * xh;
+        acc[0] += d;
+        acc[1] += d * xh;
+        acc[2] += gx;
+        acc[3] += gg;
+        float* row = dgb + (gb + p) * (size_t)dgb_ld + pcol;
+        *reinterpret_cast<f32x4*>(row) = gx;
+        *reinterpret_cast<f32x4*>(row + 32) = gg;
+      }
+    }
+  }
+  block_combine<K>(acc, q, s, g.tpp, g.ppb, active);
+  if (active && s == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      *reinterpret_cast<f32x4*>(part + ((size_t)(grp * g.chunks + chunk) * K + k) * g.C + q * 4) = acc[k];
+  }
+}
+
+__global__ void sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums, int K, RedGeom g) {
+  // sums[k][grp][c] = sum over chunks (index order)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * g.groups * g.C) return;
+  const int c = i % g.C, grp = (i / g.C) % g.groups, k = i / (g.C * g.groups);
+  float v = 0.f;
+  for (int ch = 0; ch < g.chunks; ++ch) v += part[((size_t)(grp * g.chunks + ch) * K + k) * g.C + c];
+  sums[i] = v;
+}
+
+// ---- backward, pass 2: dx = invstd * (d - S0/M - xhat * S1/M) [+ add]
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ sums,
+                                                             const float* __restrict__ add, float* __restrict__ dx,
+                                                             long total4, int C, long group_elems, int groups,
+                                                             float inv_count, int act, float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const int c = (int)(e % C);
+    const int grp = (int)(e / group_elems);
+    const size_t sc = (size_t)grp * C + c;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + sc);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + sc);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + sc);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + (size_t)groups * C + sc);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + e);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e);
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + e) - mu) * is;
+    f32x4 d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = dv[k] * dsee_act_grad_from_out(yv[k], act, slope);
+    if constexpr (MODE == 1) d = d * *reinterpret_cast<const f32x4*>(scale + e);
+    f32x4 r = is * (d - s0 * inv_count - xh * (s1 * inv_count));
+    if (add) r += *reinterpret_cast<const f32x4*>(add + e);
+    *reinterpret_cast<f32x4*>(dx + e) = r;
+  }
+}
+
+int grid_for(long total4) { return (int)min(8192L, (total4 + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+size_t dsee_norm_workspace(int N, int HW, int C, int groups) {
+  if (C % 4 || C > 1024 || groups < 1 || N % groups) return 0;
+  RedGeom g = make_geom(N, HW, C, groups);
+  return (size_t)g.groups * g.chunks * 4 * g.C * sizeof(float) + (size_t)4 * g.groups * g.C * sizeof(float);
+}
+
+int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps, float momentum, float* mean,
+                    float* invstd, float* running_mean, float* running_var, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(x && mean && invstd && workspace);
+  DSEE_CHECK_ARG(C % 4 == 0 && C <= 1024 && groups >= 1 && N % groups == 0);
+  RedGeom g = make_geom(N, HW, C, groups);
+  stats_partial_kernel<<<dim3(g.chunks, g.groups), 256, 0, st>>>(x, workspace, g);
+  DSEE_LAUNCH_CHECK();
+  stats_finalize_kernel<<<dsee_cdiv((long)g.groups * C, 256), 256, 0, st>>>(workspace, mean, invstd, running_mean,
+                                                                            running_var, g, eps, momentum);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_norm_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                         float* invstd, hipStream_t st) {
+  DSEE_CHECK_ARG(running_mean && running_var && mean && invstd);
+  eval_stats_kernel<<<dsee_cdiv(C, 256), 256, 0, st>>>(running_mean, running_var, mean, invstd, C, eps);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_norm_act_fwd(const float* x, const float* mean, const float* invstd, float* y, int N, int HW, int C,
+                      int groups, int act, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(x && mean && invstd && y && C % 4 == 0 && N % groups == 0);
+  const long total4 = (long)N * HW * C / 4;
+  norm_act_fwd_kernel<<<grid_for(total4), 256, 0, st>>>(x, mean, invstd, y, total4, C, (long)(N / groups) * HW * C, act,
+                                                        slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* IN + act backward: dx from (dy, y, x). */
+int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                      float* dx, int N, int HW, int C, int groups, int act, float slope, float* workspace,
+                      hipStream_t st) {
+  DSEE_CHECK_ARG(dy && y && x && mean && invstd && dx && workspace);
+  DSEE_CHECK_ARG(C % 4 == 0 && C <= 1024 && N % groups == 0);
+  RedGeom g = make_geom(N, HW, C, groups);
+  float* sums = workspace + (size_t)g.groups * g.chunks * 4 * g.C;
+  norm_bwd_reduce_kernel<0><<<dim3(g.chunks, g.groups), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, nullptr, 0,
+                                                                       workspace, g, act, slope);
+  DSEE_LAUNCH_CHECK();
+  sums_finalize_kernel<<<dsee_cdiv((long)2 * g.groups * C, 256), 256, 0, st>>>(workspace, sums, 2, g);
+  DSEE_LAUNCH_CHECK();
+  const long total4 = (long)N * HW * C / 4;
+  norm_bwd_apply_kernel<0><<<grid_for(total4), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, sums, nullptr, dx, total4,
+                                                             C, (long)(N / groups) * HW * C, g.groups,
+                                                             1.0f / (float)g.P, act, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* BN + modulate + LeakyReLU backward:
+ *   in : dh, h (saved output), x, scale (saved), mean/invstd [C]
+ *   out: dgb [M][dgb_ld] in packed gamma/beta order (g*xhat | g), col_sums [2][C] = (sum g*xhat, sum g),
+ *        dx = invstd*(g*scale - mean(g*scale) - xhat*mean(g*scale*xhat)) + add */
+int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                      const float* invstd, const float* add, float* dx, float* dgb, int dgb_ld, float* col_sums, int N,
+                      int HW, int C, float slope, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && dx && dgb && col_sums && workspace);
+  DSEE_CHECK_ARG(C % 4 == 0 && C <= 1024 && dgb_ld >= (C + 63) / 64 * 128);
+  RedGeom g = make_geom(N, HW, C, 1);
+  float* sums = workspace + (size_t)g.chunks * 4 * g.C;
+  norm_bwd_reduce_kernel<1><<<dim3(g.chunks, 1), 256, 0, st>>>(dh, h, x, scale, mean, invstd, dgb, dgb_ld, workspace, g,
+                                                                DSEE_ACT_LRELU, slope);
+  DSEE_LAUNCH_CHECK();
+  sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 256), 256, 0, st>>>(workspace, sums, 4, g);
+  DSEE_LAUNCH_CHECK();
+  (void)hipMemcpyAsync(col_sums, sums + 2 * C, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  const long total4 = (long)N * HW * C / 4;
+  norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
+                                                             (long)N * HW * C, 1, 1.0f / (float)g.P, DSEE_ACT_LRELU,
+                                                             slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"

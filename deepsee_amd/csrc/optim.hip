@@ -1,0 +1,185 @@
+// Parameter-space kernels: spectral normalisation and the fused multi-tensor Adam step.
+//
+//  * spectral norm = torch.nn.utils.spectral_norm, hook form (call sites architecture.py:40-44,
+//    normalization.py:29-30): one power iteration per train-mode forward, in place on u/v (eps 1e-12),
+//    sigma = u^T W v, W = W_orig / sigma; backward dW_orig = (dW - <dW, W> u v^T) / sigma.
+//  * Adam = torch.optim.Adam(betas=(beta1,beta2), eps=1e-8) over flat fp32 buffers (sr_model.py:469-495),
+//    with the reference's "parameter without gradient is skipped" semantics kept per tensor
+//    (the unused encoder branch) and optional clip_grad_value_ (trainer_manager.py:39-41).
+#include "dsee_common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum256(float v) {
+  __shared__ float red[4];
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// t[j] = sum_i W[i][j] * u[i]      (W [R][K] row-major); one thread per column, coalesced over j
+__global__ void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t, int R,
+                               int K) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  float acc = 0.f;
+  for (int i = 0; i < R; ++i) acc += W[(size_t)i * K + j] * u[i];
+  t[j] = acc;
+}
+
+// s[i] = sum_j W[i][j] * v[j]; one block per row
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                     float* __restrict__ s, int K) {
+  const int i = blockIdx.x;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < K; j += 256) acc += W[(size_t)i * K + j] * v[j];
+  acc = block_sum256(acc);
+  if (threadIdx.x == 0) s[i] = acc;
+}
+
+// out = in / max(||in||, eps); single block
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ in, float* __restrict__ out, int n,
+                                                           float eps) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += in[i] * in[i];
+  acc = block_sum256(acc);
+  const float d = fmaxf(sqrtf(acc), eps);
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = in[i] / d;
+}
+
+// sigma = dot(u, s)   (s = W v)
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ out, int n) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += a[i] * b[i];
+  acc = block_sum256(acc);
+  if (threadIdx.x == 0) *out = acc;
+}
+
+__global__ __launch_bounds__(256) void scale_by_inv_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+                                                           float* __restrict__ out, long n) {
+  const float s = *sigma;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = w[i] / s;
+}
+
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          long n, float* __restrict__ part) {
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc += a[i] * b[i];
+  acc = block_sum256(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// dWo[i][j] = (dW[i][j] - <dW,Wsn> * u[i] * v[j]) / sigma
+__global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ u,
+                                                     const float* __restrict__ v, const float* __restrict__ sigma,
+                                                     const float* __restrict__ part, int parts,
+                                                     float* __restrict__ dWo, int R, int K) {
+  __shared__ float dot_s;
+  if (threadIdx.x == 0) {
+    float d = 0.f;
+    for (int p = 0; p < parts; ++p) d += part[p];
+    dot_s = d;
+  }
+  __syncthreads();
+  const float d = dot_s, s = *sigma;
+  const long n = (long)R * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / K), c = (int)(i % K);
+    dWo[i] = (dW[i] - d * u[r] * v[c]) / s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* One spectral-norm forward.  W_orig [R][K] (= weight_orig viewed [Cout, Cin*k*k]); u [R], v [K] are updated IN
+ * PLACE when power_iter != 0 (train-mode forward, also under no_grad); writes sigma (device scalar) and
+ * w_sn = W_orig / sigma.  scratch: R + K floats. */
+int dsee_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* sigma, float* w_sn, int R, int K,
+                           int power_iter, float eps, float* scratch, hipStream_t st) {
+  DSEE_CHECK_ARG(w_orig && u && v && sigma && w_sn && scratch && R > 0 && K > 0);
+  float* tK = scratch;
+  float* tR = scratch + K;
+  if (power_iter) {
+    sn_wt_u_kernel<<<dsee_cdiv(K, 256), 256, 0, st>>>(w_orig, u, tK, R, K);
+    sn_normalize_kernel<<<1, 256, 0, st>>>(tK, v, K, eps);
+    sn_w_v_kernel<<<R, 256, 0, st>>>(w_orig, v, tR, K);
+    sn_normalize_kernel<<<1, 256, 0, st>>>(tR, u, R, eps);
+  } else {
+    sn_w_v_kernel<<<R, 256, 0, st>>>(w_orig, v, tR, K);
+  }
+  sn_dot_kernel<<<1, 256, 0, st>>>(u, tR, sigma, R);
+  const long n = (long)R * K;
+  scale_by_inv_kernel<<<(int)min(2048L, (n + 255) / 256), 256, 0, st>>>(w_orig, sigma, w_sn, n);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* dW_orig = (dW - <dW, W_sn> u v^T) / sigma.  scratch: 256 floats. */
+int dsee_spectral_norm_bwd(const float* dw, const float* w_sn, const float* u, const float* v, const float* sigma,
+                           float* dw_orig, int R, int K, float* scratch, hipStream_t st) {
+  DSEE_CHECK_ARG(dw && w_sn && u && v && sigma && dw_orig && scratch);
+  const long n = (long)R * K;
+  const int parts = (int)min(256L, (n + 255) / 256);
+  dot_partial_kernel<<<parts, 256, 0, st>>>(dw, w_sn, n, scratch);
+  sn_bwd_kernel<<<(int)min(2048L, (n + 255) / 256), 256, 0, st>>>(dw, u, v, sigma, scratch, parts, dw_orig, R, K);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// One block-range per tensor: blocks [first_block, first_block + nblocks) work on tensor t.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                   const dsee_adam_tensor* __restrict__ tensors,
+                                                   const int* __restrict__ block_tensor, float beta1, float beta2,
+                                                   float eps, float grad_scale, float clip) {
+  const int t = block_tensor[blockIdx.x];
+  const dsee_adam_tensor d = tensors[t];
+  if (!d.active) return;
+  const int step = d.step + 1;  // the host bumps d.step after the launch (same value on every block)
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  const float step_size = d.lr / bc1;
+  const float bc2_sqrt = sqrtf(bc2);
+  const long b0 = (long)(blockIdx.x - d.first_block) * 1024;
+  for (long i = b0 + threadIdx.x; i < d.numel && i < b0 + 1024; i += 256) {
+    const long o = d.offset + i;
+    float g = grad[o] * grad_scale;
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    const float m = beta1 * exp_avg[o] + (1.f - beta1) * g;
+    const float v = beta2 * exp_avg_sq[o] + (1.f - beta2) * g * g;
+    exp_avg[o] = m;
+    exp_avg_sq[o] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    param[o] -= step_size * (m / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Fused Adam over a flat parameter buffer.  `tensors` / `block_tensor` are DEVICE arrays: descriptor t covers
+ * elements [offset, offset+numel) and owns blocks [first_block, first_block + ceil(numel/1024)); block_tensor maps
+ * each launched block to its descriptor.  `step` in the descriptor is the number of updates already applied to
+ * that tensor (torch's state['step']); inactive tensors (grad is None in the reference) are skipped entirely.
+ * grad_scale = 1/world_size after the RCCL sum all-reduce. */
+int dsee_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks, float beta1, float beta2,
+                   float eps, float grad_scale, float clip, hipStream_t st) {
+  DSEE_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && tensors && block_tensor && nblocks > 0);
+  adam_kernel<<<nblocks, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, tensors, block_tensor, beta1, beta2, eps,
+                                       grad_scale, clip);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"

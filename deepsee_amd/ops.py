@@ -1,0 +1,554 @@
+"""torch.autograd.Function wrappers over the C ABI (include/deepsee_hip.h).
+
+Everything here works on fp32 NHWC device tensors whose channel count is padded to a multiple of 4.
+PyTorch supplies allocation, the stream and the autograd graph; every activation-sized computation
+is a hand-written HIP kernel in libdeepsee_hip.so.  There is no CPU / ATen fallback: without the
+library these functions raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+LRELU_SLOPE = 0.2
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+SN_EPS = 1e-12
+NHIDDEN = 128
+
+_scratch = {}
+
+
+def scratch(nbytes, tag="ws"):
+    """Grow-only device scratch (fp32).  Safe to share: all kernels run in stream order and every
+    workspace is consumed inside the C call that fills it."""
+    n = (int(nbytes) + 3) // 4
+    key = (tag, torch.cuda.current_device())
+    t = _scratch.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1024), dtype=torch.float32, device="cuda")
+        _scratch[key] = t
+    return t
+
+
+def new(*shape):
+    return torch.empty(*shape, dtype=torch.float32, device="cuda")
+
+
+def pad_vec(v, n):
+    """[c] -> [n] zero padded (bias vectors for padded channel counts)."""
+    if v is None or v.numel() == n:
+        return v
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v
+    return out
+
+
+# ------------------------------------------------------------------------------------ layout
+def to_nhwc(x_nchw, cs=None):
+    n, c, h, w = x_nchw.shape
+    cs = cs or L.pad4(c)
+    y = new(n, h, w, cs)
+    L.call("nchw_to_nhwc", x_nchw.contiguous().float(), y, n, c, h, w, cs)
+    return y
+
+
+def to_nchw(x_nhwc, c):
+    n, h, w, cs = x_nhwc.shape
+    y = new(n, c, h, w)
+    L.call("nhwc_to_nchw", x_nhwc.contiguous(), y, n, c, h, w, cs)
+    return y
+
+
+class ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.cs = x.shape[3]
+        return to_nchw(x, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return to_nhwc(dy, ctx.cs), None
+
+
+def label_to_u8(label):
+    """float label map [N,1,H,W] -> uint8 [N,H,W]  (.long() of base_manager.py:35-39)."""
+    n, _, h, w = label.shape
+    out = torch.empty(n, h, w, dtype=torch.uint8, device="cuda")
+    L.call("label_to_u8", label.contiguous().float(), out, C.c_long(n * h * w))
+    return out
+
+
+def bicubic_down(img_nhwc, size):
+    n, h, w, cs = img_nhwc.shape
+    y = new(n, size, size, 4)
+    L.call("bicubic_down", img_nhwc, y, n, h, w, size, cs, 4)
+    return y
+
+
+class Labels:
+    """uint8 HR label map + the shift for a given resolution (nearest resize as index math)."""
+
+    def __init__(self, lab_u8, nc):
+        self.t = lab_u8
+        self.n, self.h, self.w = lab_u8.shape
+        self.nc = nc
+
+    def shift_for(self, r):
+        s = 0
+        while (self.h >> s) > r:
+            s += 1
+        assert (self.h >> s) == r, "resolution %d is not a power-of-two fraction of %d" % (r, self.h)
+        return s
+
+
+def rng_fill(shape, seed, offset, normal=True):
+    t = new(*shape)
+    assert t.numel() % 4 == 0
+    L.call("rng_fill", t, C.c_long(t.numel()), C.c_uint64(seed), C.c_uint64(offset), int(normal))
+    return t
+
+
+# ------------------------------------------------------------------------------------ convolution
+def _pack_fwd(w, cin_s):
+    co, ci, kh, kw = w.shape
+    wp = new(L.wrows(L.pad4(co)), L.kpad(kh, kw, cin_s))
+    L.call("pack_weight_fwd", w, None, None, wp, co, ci, kh, kw, cin_s)
+    return wp
+
+
+def _pack_dgrad(w, cout_s):
+    co, ci, kh, kw = w.shape
+    wp = new(L.wrows(L.pad4(ci)), L.kpad(kh, kw, cout_s))
+    L.call("pack_weight_dgrad", w, None, None, wp, co, ci, kh, kw, cout_s)
+    return wp
+
+
+def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE):
+    out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
+    L.call("conv2d_fwd", C.byref(geom), x, wp, bias, res, out, act, float(slope))
+    return out
+
+
+def wgrad_raw(x, dout, geom, cout, cin, kh, kw):
+    nbytes = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
+    ws = scratch(nbytes, "wgrad")
+    dw = new(cout, cin, kh, kw)
+    L.call("conv2d_wgrad", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin)
+    return dw
+
+
+def channel_dot(a, b, c):
+    """[c] = sum over rows of a*b (b None: column sums); a viewed as [M, C]."""
+    cs = a.shape[-1]
+    m = a.numel() // cs
+    ws = scratch(L.lib().dsee_channel_dot_workspace(C.c_long(m), cs), "chdot")
+    out = new(cs)
+    L.call("channel_dot", a, b, out, C.c_long(m), cs, ws)
+    return out[:c]
+
+
+class Conv2d(torch.autograd.Function):
+    """out = act(conv(x, w) + bias + residual); x stored [N,H,W,pad4(Cin)], w OIHW (real channel counts)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, stride, pad, ups, act):
+        co, ci, kh, kw = w.shape
+        n, hi, wi, cin_s = x.shape
+        assert cin_s == L.pad4(ci), (cin_s, ci)
+        cout_s = L.pad4(co)
+        geom = L.geom_fwd(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
+        w = w.contiguous()
+        out = conv_raw(x, _pack_fwd(w, cin_s), geom, pad_vec(bias, cout_s), res, act)
+        ctx.geom, ctx.act, ctx.has_bias, ctx.has_res = geom, act, bias is not None, res is not None
+        ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, out = ctx.saved_tensors
+        geom = ctx.geom
+        co, ci, kh, kw = w.shape
+        dy = dy.contiguous()
+        if ctx.act != L.ACT_NONE:
+            g = torch.empty_like(dy)
+            L.call("act_bwd", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE)
+        else:
+            g = dy
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            gd = L.geom_dgrad(geom)
+            dxl = conv_raw(g, _pack_dgrad(w, geom.Cout), gd)
+            if geom.ups:
+                dx = torch.empty_like(x)
+                L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
+            else:
+                dx = dxl
+        if ctx.needs_input_grad[1]:
+            dw = wgrad_raw(x, g, geom, co, ci, kh, kw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = channel_dot(g, None, co).clone()
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = g
+        return dx, dw, db, dres, None, None, None, None
+
+
+def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE):
+    return Conv2d.apply(x, w, bias, res, stride, pad, ups, act)
+
+
+# ------------------------------------------------------------------------------------ spectral norm
+class SpectralNorm(torch.autograd.Function):
+    """W = W_orig / sigma with one in-place power iteration on (u, v) when `power_iter`
+    (torch.nn.utils.spectral_norm hook semantics; SURVEY B-2)."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, power_iter):
+        r = w_orig.shape[0]
+        k = w_orig.numel() // r
+        w_orig = w_orig.contiguous()
+        sigma = new(1)
+        w_sn = torch.empty_like(w_orig)
+        L.call("spectral_norm_fwd", w_orig, u, v, sigma, w_sn, r, k, int(power_iter), SN_EPS, scratch((r + k) * 4, "sn"))
+        ctx.save_for_backward(w_sn, u.clone(), v.clone(), sigma)
+        return w_sn
+
+    @staticmethod
+    def backward(ctx, dw):
+        w_sn, u, v, sigma = ctx.saved_tensors
+        r = w_sn.shape[0]
+        k = w_sn.numel() // r
+        dwo = torch.empty_like(w_sn)
+        L.call("spectral_norm_bwd", dw.contiguous(), w_sn, u, v, sigma, dwo, r, k, scratch(1024, "sn"))
+        return dwo, None, None, None
+
+
+# ------------------------------------------------------------------------------------ instance norm + act
+class InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        n, h, w, c = x.shape
+        mean, invstd = new(n, c), new(n, c)
+        ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, n), "norm")
+        L.call("norm_stats", x, n, h * w, c, n, BN_EPS, 0.0, mean, invstd, None, None, ws)
+        y = torch.empty_like(x)
+        L.call("norm_act_fwd", x, mean, invstd, y, n, h * w, c, n, act, LRELU_SLOPE)
+        ctx.act = act
+        ctx.save_for_backward(x, y, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd = ctx.saved_tensors
+        n, h, w, c = x.shape
+        dx = torch.empty_like(x)
+        ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, n), "norm")
+        L.call("norm_act_bwd", dy.contiguous(), y, x, mean, invstd, dx, n, h * w, c, n, ctx.act, LRELU_SLOPE, ws)
+        return dx, None
+
+
+class Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        y = torch.empty_like(x)
+        L.call("act_fwd", x, y, C.c_long(x.numel()), act, LRELU_SLOPE)
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        L.call("act_bwd", dy.contiguous(), y, dx, C.c_long(y.numel()), ctx.act, LRELU_SLOPE)
+        return dx, None
+
+
+# ------------------------------------------------------------------------------------ upsample + noise
+class UpNoise(torch.autograd.Function):
+    """y = nearest_up(x, 2^ups) + w[c] * eps   (eps/w may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, noise_w, eps, ups):
+        n, h0, w0, c = x.shape
+        y = new(n, h0 << ups, w0 << ups, c)
+        L.call("upsample_noise_fwd", x, eps, noise_w if eps is not None else None, y, n, h0 << ups, w0 << ups, c, ups)
+        ctx.ups = ups
+        ctx.save_for_backward(eps)
+        ctx.xshape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (eps,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, h, w, c = dy.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.ups:
+                dx = new(*ctx.xshape)
+                L.call("sumpool", dy, dx, n, h, w, c, ctx.ups)
+            else:
+                dx = dy
+        if eps is not None and ctx.needs_input_grad[1]:
+            dw = channel_dot(dy, eps, c).clone()
+        return dx, dw, None, None
+
+
+# ------------------------------------------------------------------------------------ SPADE/SEAN inputs
+class SeanInput(torch.autograd.Function):
+    """cat([ReLU(conv3x3(one-hot label; W_sh) + b_sh), style[label]]) at resolution H>>shift, from the uint8
+    label map (normalization.py:174-185).  `style` None -> SPADE (128 channels only)."""
+
+    @staticmethod
+    def forward(ctx, w_sh, b_sh, style, labels, shift, want_actv, want_style):
+        n, h, w, nc = labels.n, labels.h, labels.w, labels.nc
+        r, rw = h >> shift, w >> shift
+        ld = (NHIDDEN if want_actv else 0) + (style.shape[2] if want_style else 0)
+        cat = new(n, r, rw, ld)
+        coff = 0
+        if want_actv:
+            table = new(9, nc, NHIDDEN)
+            L.call("onehot_conv3x3_pack", w_sh.contiguous(), table, NHIDDEN, nc)
+            L.call("onehot_conv3x3_fwd", labels.t, table, b_sh, cat, n, h, w, shift, nc, NHIDDEN, ld, 0, 1)
+            coff = NHIDDEN
+        if want_style:
+            L.call("label_gather", labels.t, style.contiguous(), cat, n, h, w, shift, nc, style.shape[2], ld, coff, 1.0)
+        ctx.labels, ctx.shift, ctx.want_actv, ctx.want_style, ctx.coff = labels, shift, want_actv, want_style, coff
+        ctx.sshape = style.shape if want_style else None
+        ctx.save_for_backward(cat)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        (cat,) = ctx.saved_tensors
+        lab, shift = ctx.labels, ctx.shift
+        dcat = dcat.contiguous()
+        n, r, rw, ld = cat.shape
+        dw = db = dstyle = None
+        if ctx.want_actv and ctx.needs_input_grad[0]:
+            dw, db = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
+            ws = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
+            L.call("onehot_conv3x3_wgrad", lab.t, dcat, cat, ld, 0, n, lab.h, lab.w, shift, lab.nc, dw, db, ws)
+        if ctx.want_style and ctx.needs_input_grad[2]:
+            s = ctx.sshape[2]
+            dstyle = new(*ctx.sshape)
+            ws = scratch(L.lib().dsee_label_segsum_workspace(n, lab.h, lab.w, shift, lab.nc, s), "seg")
+            L.call("label_segsum", lab.t, dcat, ld, ctx.coff, dstyle, n, lab.h, lab.w, shift, lab.nc, s, 1.0, ws)
+        return dw, db, dstyle, None, None, None, None
+
+
+class StylePool(torch.autograd.Function):
+    """S[b,r,c] = (1/HW) sum_{hw: label=r} f[b,h,w,c]   (encoder.py:36-49; SURVEY B-4)."""
+
+    @staticmethod
+    def forward(ctx, feat, labels, shift):
+        n, hf, wf, c = feat.shape
+        assert hf == labels.h >> shift
+        out = new(n, labels.nc, c)
+        ws = scratch(L.lib().dsee_label_segsum_workspace(n, labels.h, labels.w, shift, labels.nc, c), "seg")
+        L.call("label_segsum", labels.t, feat, c, 0, out, n, labels.h, labels.w, shift, labels.nc, c,
+               1.0 / (hf * wf), ws)
+        ctx.labels, ctx.shift, ctx.fshape = labels, shift, feat.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, ds):
+        lab = ctx.labels
+        n, hf, wf, c = ctx.fshape
+        df = new(*ctx.fshape)
+        L.call("label_gather", lab.t, ds.contiguous(), df, n, lab.h, lab.w, ctx.shift, lab.nc, c, c, 0, 1.0 / (hf * wf))
+        return df, None, None
+
+
+# ------------------------------------------------------------------------------------ fused BN + modulate + lrelu
+_perm_cache = {}
+
+
+def packed_perm(c, device):
+    """Row order of the gamma/beta GEMM: packed row b*128 + w*64 + h*32 + cc <-> (h ? beta : gamma)[b*64 + w*32 + cc].
+    Returns (index into cat([gamma rows, beta rows, one zero row]), number of packed rows)."""
+    key = (c, str(device))
+    if key not in _perm_cache:
+        rows = (c + 63) // 64 * 128
+        idx = torch.full((rows,), 2 * c, dtype=torch.long)
+        for p in range(rows):
+            b, rem = divmod(p, 128)
+            w, rem = divmod(rem, 64)
+            h, cc = divmod(rem, 32)
+            ch = b * 64 + w * 32 + cc
+            if ch < c:
+                idx[p] = h * c + ch
+        _perm_cache[key] = (idx.to(device), rows)
+    return _perm_cache[key]
+
+
+def pack_gamma_beta(w_gamma, w_beta, b_gamma, b_beta):
+    """OIHW [C,K,3,3] x2 (+ biases) -> the row-permuted [rows,K,3,3] / [rows] the modulate kernel expects.
+    Parameter-space glue on <= 5 MB tensors (differentiable torch indexing)."""
+    c = w_gamma.shape[0]
+    idx, rows = packed_perm(c, w_gamma.device)
+    zw = torch.zeros((1,) + tuple(w_gamma.shape[1:]), dtype=w_gamma.dtype, device=w_gamma.device)
+    zb = torch.zeros(1, dtype=w_gamma.dtype, device=w_gamma.device)
+    w2 = torch.cat([w_gamma, w_beta, zw], 0).index_select(0, idx)
+    b2 = torch.cat([b_gamma, b_beta, zb], 0).index_select(0, idx)
+    return w2, b2
+
+
+class SpadeNormAct(torch.autograd.Function):
+    """h = lrelu(BN(x) * (conv_gamma(cat) + add_one) + conv_beta(cat)) with gamma/beta formed inside the GEMM
+    epilogue; BN = sync-free batch statistics in training, running statistics in eval."""
+
+    @staticmethod
+    def forward(ctx, x, cat, w2, b2, running_mean, running_var, training, add_one, cat_ups):
+        n, h, w, c = x.shape
+        rows, kin = w2.shape[0], w2.shape[1]
+        assert cat.shape[3] == kin and kin % 4 == 0
+        mean, invstd = new(c), new(c)
+        if training:
+            ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
+            L.call("norm_stats", x, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var, ws)
+        else:
+            L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
+        geom = L.geom_fwd(n, cat.shape[1], cat.shape[2], kin, rows, 3, 1, 1, cat_ups)
+        assert geom.Ho == h and geom.Wo == w
+        w2 = w2.contiguous()
+        out, scale = torch.empty_like(x), torch.empty_like(x)
+        L.call("conv2d_modulate_fwd", C.byref(geom), cat, _pack_fwd(w2, kin), b2.contiguous(), x, mean, invstd, out,
+               scale, c, float(add_one), LRELU_SLOPE)
+        ctx.geom = geom
+        ctx.save_for_backward(x, cat, w2, out, scale, mean, invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, cat, w2, out, scale, mean, invstd = ctx.saved_tensors
+        geom = ctx.geom
+        n, h, w, c = x.shape
+        rows, kin = w2.shape[0], w2.shape[1]
+        dgb = (torch.zeros if c % 64 else torch.empty)(n, h, w, rows, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        cs = new(2, c)
+        ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
+        L.call("modulate_bwd", dh.contiguous(), out, x, scale, mean, invstd, None, dx, dgb, rows, cs, n, h * w, c,
+               LRELU_SLOPE, ws)
+        dcat = dw2 = db2 = None
+        if ctx.needs_input_grad[1]:
+            gd = L.geom_dgrad(geom)
+            dcl = conv_raw(dgb, _pack_dgrad(w2, rows), gd)
+            if geom.ups:
+                dcat = torch.empty_like(cat)
+                L.call("sumpool", dcl, dcat, n, gd.Ho, gd.Wo, kin, geom.ups)
+            else:
+                dcat = dcl
+        if ctx.needs_input_grad[2]:
+            dw2 = wgrad_raw(cat, dgb, geom, rows, kin, 3, 3)
+        if ctx.needs_input_grad[3]:
+            idx, _ = packed_perm(c, x.device)
+            db2 = torch.cat([cs.reshape(-1), torch.zeros(1, device=x.device)]).index_select(0, idx)
+        return dx, dcat, dw2, db2, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------ pooling
+class AvgPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, c = x.shape
+        y = new(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c)
+        L.call("avgpool3s2_fwd", x, y, n, h, w, c)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c = ctx.shape
+        dx = new(n, h, w, c)
+        L.call("avgpool3s2_bwd", dy.contiguous(), dx, n, h, w, c)
+        return dx
+
+
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, c = x.shape
+        y = new(n, h // 2, w // 2, c)
+        L.call("maxpool2_fwd", x, y, n, h, w, c)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, h, w, c = x.shape
+        dx = torch.empty_like(x)
+        L.call("maxpool2_bwd", dy.contiguous(), x, dx, n, h, w, c)
+        return dx
+
+
+# ------------------------------------------------------------------------------------ discriminator input
+class DInput(torch.autograd.Function):
+    """cat([one-hot(label), image]) in NHWC (19 + 3 channels, stored 24) for a list of images that share the
+    label map, stacked on N like sr_model.py:655-668 (fake first, real second)."""
+
+    @staticmethod
+    def forward(ctx, labels, *imgs):
+        n, h, w, cs = imgs[0].shape
+        ld = L.pad4(labels.nc + 3)
+        out = new(n * len(imgs), h, w, ld)
+        for i, img in enumerate(imgs):
+            L.call("build_d_input", labels.t, img.contiguous(), out[i * n:(i + 1) * n], C.c_long(n * h * w), labels.nc,
+                   ld, cs)
+        ctx.nc, ctx.cs, ctx.k, ctx.n = labels.nc, cs, len(imgs), n
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _, h, w, ld = dout.shape
+        dout = dout.contiguous()
+        grads = []
+        for i in range(ctx.k):
+            if not ctx.needs_input_grad[1 + i]:
+                grads.append(None)
+                continue
+            dimg = new(ctx.n, h, w, ctx.cs)
+            L.call("extract_image_grad", dout[i * ctx.n:(i + 1) * ctx.n], dimg, C.c_long(ctx.n * h * w), ctx.nc, ld,
+                   ctx.cs)
+            grads.append(dimg)
+        return (None,) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------ losses
+MODE_L1, MODE_NEG, MODE_HINGE_REAL, MODE_HINGE_FAKE = 0, 1, 2, 3
+
+
+class MeanLoss(torch.autograd.Function):
+    """weight * mean(l(a[lo:hi][, b])) with the gradient w.r.t. `a` produced in the same pass (zero outside
+    [lo,hi)).  The backward returns the stored gradient unscaled: the train step calls backward() on
+    sum(losses).mean(), i.e. with unit upstream gradient (trainer_manager.py:36-37,53-54)."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode, weight, valid_c, lo, hi):
+        a = a.contiguous()
+        ld = a.shape[-1]
+        sub = a[lo:hi]
+        rows = sub.numel() // ld
+        loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+        grad = gsub = None
+        if ctx.needs_input_grad[0]:
+            grad = torch.empty_like(a) if (lo == 0 and hi == a.shape[0]) else torch.zeros_like(a)
+            gsub = grad[lo:hi]
+        L.call("loss_fwd_bwd", mode, sub, b.contiguous() if b is not None else None, gsub, C.c_long(rows), ld,
+               valid_c, float(weight), loss, scratch(L.lib().dsee_loss_workspace(), "loss"))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        (grad,) = ctx.saved_tensors
+        return grad, None, None, None, None, None, None
+
+
+def mean_loss(a, b, mode, weight, valid_c=None, lo=0, hi=None):
+    return MeanLoss.apply(a, b, mode, weight, a.shape[-1] if valid_c is None else valid_c, lo,
+                          a.shape[0] if hi is None else hi)

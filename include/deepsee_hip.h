@@ -89,6 +89,103 @@ size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g);
 int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
                       size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_real, hipStream_t stream);
 
+/* ------------------------------------------------------------------ normalisation statistics / backward
+ * Replaces F.batch_norm(training) of the single-device SynchronizedBatchNorm2d branch
+ * (sync_batchnorm/batchnorm.py:65-68; biased var + eps, running stats momentum with unbiased var) with
+ * groups = 1, and nn.InstanceNorm2d(affine=False) (normalization.py:47-48) with groups = N.
+ * mean/invstd are [groups][C].  workspace: dsee_norm_workspace() bytes. */
+size_t dsee_norm_workspace(int N, int HW, int C, int groups);
+int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps, float momentum, float* mean,
+                    float* invstd, float* running_mean, float* running_var, float* workspace, hipStream_t stream);
+/* eval-mode BN: mean = running_mean, invstd = 1/sqrt(running_var + eps) (sr_model.py:85-91 inference) */
+int dsee_norm_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                         float* invstd, hipStream_t stream);
+/* y = act((x - mean) * invstd): InstanceNorm + LeakyReLU (discriminator.py:88-93, encoder.py:83-99) / + tanh
+ * (encoder.py:24-27) */
+int dsee_norm_act_fwd(const float* x, const float* mean, const float* invstd, float* y, int N, int HW, int C,
+                      int groups, int act, float slope, hipStream_t stream);
+int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                      float* dx, int N, int HW, int C, int groups, int act, float slope, float* workspace,
+                      hipStream_t stream);
+/* backward of dsee_conv2d_modulate_fwd w.r.t. x and (gamma,beta): see SURVEY.md Appendix E.
+ * dgb [M][dgb_ld] is written in the packed gamma/beta column order and is the `dout` for the wgrad/dgrad of the
+ * gamma/beta convolution; col_sums [2][C] = (sum g*xhat, sum g) are its bias gradients; dx gets `add` added. */
+int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                      const float* invstd, const float* add, float* dx, float* dgb, int dgb_ld, float* col_sums, int N,
+                      int HW, int C, float slope, float* workspace, hipStream_t stream);
+
+/* ------------------------------------------------------------------ label-map kernels (uint8 [N][H][W])
+ * mlp_shared = ReLU(conv3x3(one-hot)) (normalization.py:98-101) as a 9-tap gather-sum of weight columns. */
+int dsee_onehot_conv3x3_pack(const float* w_oihw, float* table, int Co, int L, hipStream_t stream);
+int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float* bias, float* out, int N, int H, int W,
+                            int shift, int L, int Co, int out_ld, int coff, int relu, hipStream_t stream);
+size_t dsee_onehot_conv3x3_wgrad_workspace(int N, int H, int W, int shift, int L);
+int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, const float* act, int ld, int coff, int N, int H,
+                              int W, int shift, int L, float* dw_oihw, float* dbias, float* workspace,
+                              hipStream_t stream);
+/* out[m][coff..] = scale * table[n][label(m)][:]   — SEAN style_map (normalization.py:179-185); backward of
+ * extract_style_matrix */
+int dsee_label_gather(const uint8_t* lab, const float* table, float* out, int N, int H, int W, int shift, int L, int Cs,
+                      int out_ld, int coff, float scale, hipStream_t stream);
+/* table[n][r][:] = scale * sum_{m in image n, label(m)=r} in[m][coff..]  — extract_style_matrix
+ * (encoder.py:36-49, scale = 1/(H*W)); backward of the style_map gather */
+size_t dsee_label_segsum_workspace(int N, int H, int W, int shift, int L, int Cs);
+int dsee_label_segsum(const uint8_t* lab, const float* in, int ld, int coff, float* table, int N, int H, int W,
+                      int shift, int L, int Cs, float scale, float* workspace, hipStream_t stream);
+
+/* ------------------------------------------------------------------ streaming element-wise kernels */
+/* y = nearest_up(x, 2^ups) + noise_w[c] * eps   (nn.Upsample sr.py:57 + NoiseInjection normalization.py:299-304) */
+int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise_w, float* y, int N, int H, int W, int C,
+                            int ups, hipStream_t stream);
+int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t stream);
+size_t dsee_channel_dot_workspace(long M, int C);
+int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, float* workspace, hipStream_t stream);
+int dsee_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t stream);
+int dsee_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float slope, hipStream_t stream);
+int dsee_axpby(const float* a, float alpha, const float* b, float beta, float* y, long n, hipStream_t stream);
+/* F.avg_pool2d(3, stride 2, pad 1, count_include_pad=False)  (discriminator.py:46-49) */
+int dsee_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
+int dsee_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, hipStream_t stream);
+/* VGG19 MaxPool2d(2,2) (architecture.py:151-181) */
+int dsee_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
+int dsee_maxpool2_bwd(const float* dy, const float* x, float* dx, int N, int H, int W, int C, hipStream_t stream);
+/* input preparation (base_manager.py:28-66, data/preprocessor.py:17-41) */
+int dsee_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cs, hipStream_t stream);
+int dsee_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cs, hipStream_t stream);
+int dsee_label_to_u8(const float* label, uint8_t* out, long n, hipStream_t stream);
+int dsee_bicubic_down(const float* x, float* y, int N, int H, int W, int S, int cs_in, int cs_out, hipStream_t stream);
+/* cat([input_semantics, image], dim=1) of sr_model.py:655-668 in NHWC, and the image part of its gradient */
+int dsee_build_d_input(const uint8_t* lab, const float* img, float* out, long pixels, int L, int Cs, int img_cs,
+                       hipStream_t stream);
+int dsee_extract_image_grad(const float* din, float* dimg, long pixels, int L, int Cs, int img_cs, hipStream_t stream);
+/* Philox4x32-10 fill: N(0,1) (normal != 0) or U[0,1) — replaces tensor.normal_() / torch.rand_like on device */
+int dsee_rng_fill(float* out, long n, uint64_t seed, uint64_t offset, int normal, hipStream_t stream);
+
+/* ------------------------------------------------------------------ losses (loss.py:68-79,114-119; sr_model.py:529-539)
+ * mode 0: L1(a,b)  1: -x (hinge, generator)  2: -min(x-1,0) (D, real)  3: -min(-x-1,0) (D, fake).
+ * *loss_out += weight*mean; grad = weight * d mean / d a. */
+size_t dsee_loss_workspace(void);
+int dsee_loss_fwd_bwd(int mode, const float* a, const float* b, float* grad, long rows, int ld, int valid_c,
+                      float weight, float* loss_out, float* workspace, hipStream_t stream);
+
+/* ------------------------------------------------------------------ spectral norm + Adam */
+int dsee_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* sigma, float* w_sn, int R, int K,
+                           int power_iter, float eps, float* scratch, hipStream_t stream);
+int dsee_spectral_norm_bwd(const float* dw, const float* w_sn, const float* u, const float* v, const float* sigma,
+                           float* dw_orig, int R, int K, float* scratch, hipStream_t stream);
+
+typedef struct dsee_adam_tensor {
+  int64_t offset;      /* first element in the flat buffers */
+  int64_t numel;
+  int32_t first_block; /* blocks [first_block, first_block + ceil(numel/1024)) belong to this tensor */
+  int32_t step;        /* updates already applied (torch state['step']) */
+  float lr;
+  int32_t active;      /* 0: the reference's p.grad is None -> skipped */
+} dsee_adam_tensor;
+int dsee_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks, float beta1, float beta2,
+                   float eps, float grad_scale, float clip, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,260 @@
+"""Layer-level parity of the HIP ops (through the C ABI) against torch-CPU fp32 restatements / the oracle,
+forward and backward, on the same seeded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import deepsee_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-20))
+
+
+def nhwc(x):
+    from deepsee_amd import ops
+    return ops.to_nhwc(x.cuda())
+
+
+def nchw(x, c):
+    from deepsee_amd import ops
+    return ops.to_nchw(x.contiguous(), c).cpu()
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("kind,C,R,N", [("spade", 8, 8, 2), ("sean", 64, 16, 2), ("sean", 128, 8, 3), ("puresean", 32, 8, 2)])
+def test_spade_sean_norm_fwd_bwd(kind, C, R, N):
+    from deepsee_amd import ops, lib as L
+    g = gen(C * R + N)
+    Lc, S, H = 19, 128, 32
+    label = torch.randint(0, Lc, (N, 1, H, H), generator=g).float()
+    seg = O.onehot_labels(label, Lc)
+    style = (torch.rand(N, Lc, S, generator=g) * 2 - 1).requires_grad_()
+    x = torch.randn(N, C, R, R, generator=g).requires_grad_()
+    spec = {"n.param_free_norm.running_mean": (C,), "n.param_free_norm.running_var": (C,),
+            "n.param_free_norm.num_batches_tracked": (), "n.mlp_shared.0.weight": (128, Lc, 3, 3),
+            "n.mlp_shared.0.bias": (128,)}
+    if kind in ("spade", "sean"):
+        for q in ("mlp_gamma", "mlp_beta"):
+            spec["n.%s.weight" % q] = (C, 128, 3, 3)
+            spec["n.%s.bias" % q] = (C,)
+    if kind in ("sean", "puresean"):
+        for q in ("mlp_style_gamma", "mlp_style_beta"):
+            spec["n.%s.weight" % q] = (C, S, 3, 3)
+            spec["n.%s.bias" % q] = (C,)
+    if kind == "sean":
+        spec["n.alpha_beta"] = (1,)
+        spec["n.alpha_gamma"] = (1,)
+    st = {k: O.recipe_tensor("t_" + kind, k, s, 1.0) for k, s in spec.items()}
+    orc = O.Oracle(O.make_opt(), {"SR": st})
+    P = orc.S["SR"]
+    y = F.leaky_relu(orc._norm(kind, P, "n", x, seg, style), 0.2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+
+    # ---- HIP
+    dev = "cuda"
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
+    shift = labels.shift_for(R)
+    p = {k: v.detach().clone().to(dev).requires_grad_(v.requires_grad) for k, v in st.items() if v.is_floating_point()}
+    for k in p:
+        if not O.is_buffer(k):
+            p[k].requires_grad_(True)
+    xs = nhwc(x.detach()).requires_grad_()
+    sty = style.detach().to(dev).requires_grad_()
+    rm = st["n.param_free_norm.running_mean"].clone().to(dev)
+    rv = st["n.param_free_norm.running_var"].clone().to(dev)
+    want_actv = kind != "puresean"
+    want_style = kind != "spade"
+    cat = ops.SeanInput.apply(p["n.mlp_shared.0.weight"], p["n.mlp_shared.0.bias"], sty if want_style else None,
+                              labels, shift, want_actv, want_style)
+    if kind == "spade":
+        w2, b2 = ops.pack_gamma_beta(p["n.mlp_gamma.weight"], p["n.mlp_beta.weight"], p["n.mlp_gamma.bias"],
+                                     p["n.mlp_beta.bias"])
+        add_one = 1.0
+    elif kind == "puresean":
+        w2, b2 = ops.pack_gamma_beta(p["n.mlp_style_gamma.weight"], p["n.mlp_style_beta.weight"],
+                                     p["n.mlp_style_gamma.bias"], p["n.mlp_style_beta.bias"])
+        add_one = 0.0
+    else:
+        wg, wb = torch.sigmoid(p["n.alpha_gamma"]), torch.sigmoid(p["n.alpha_beta"])
+        Wg = torch.cat([(1 - wg) * p["n.mlp_gamma.weight"], wg * p["n.mlp_style_gamma.weight"]], 1)
+        Wb = torch.cat([(1 - wb) * p["n.mlp_beta.weight"], wb * p["n.mlp_style_beta.weight"]], 1)
+        bg = (1 - wg) * p["n.mlp_gamma.bias"] + wg * p["n.mlp_style_gamma.bias"]
+        bb = (1 - wb) * p["n.mlp_beta.bias"] + wb * p["n.mlp_style_beta.bias"]
+        w2, b2 = ops.pack_gamma_beta(Wg, Wb, bg, bb)
+        add_one = 1.0
+    h = ops.SpadeNormAct.apply(xs, cat, w2, b2, rm, rv, True, add_one, 0)
+    h.backward(nhwc(gy))
+    torch.cuda.synchronize()
+    assert rel(nchw(h.detach(), C), y.detach()) < TOL
+    assert rel(nchw(xs.grad, C), x.grad) < 5 * TOL
+    assert rel(rm.cpu(), P["n.param_free_norm.running_mean"]) < TOL
+    assert rel(rv.cpu(), P["n.param_free_norm.running_var"]) < TOL
+    if want_style:
+        assert rel(sty.grad.cpu(), style.grad) < 5 * TOL
+    for k, v in P.items():
+        if v.requires_grad and v.grad is not None and k in p:
+            assert rel(p[k].grad.cpu(), v.grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("act", [1, 3])
+def test_instnorm_act(act):
+    from deepsee_amd import ops
+    g = gen(act)
+    x = torch.randn(3, 24, 9, 11, generator=g).requires_grad_()
+    f = (lambda t: F.leaky_relu(t, 0.2)) if act == 1 else torch.tanh
+    y = f(O.instance_norm(x))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xs = nhwc(x.detach()).requires_grad_()
+    ys = ops.InstNormAct.apply(xs, act)
+    ys.backward(nhwc(gy))
+    assert rel(nchw(ys.detach(), 24), y.detach()) < TOL
+    assert rel(nchw(xs.grad, 24), x.grad) < 5 * TOL
+
+
+def test_upsample_noise_and_sumpool():
+    from deepsee_amd import ops
+    g = gen(5)
+    x = torch.randn(2, 16, 6, 6, generator=g).requires_grad_()
+    w = torch.randn(16, generator=g).requires_grad_()
+    eps = torch.randn(2, 16, 12, 12, generator=g)
+    y = F.interpolate(x, scale_factor=2, mode="nearest") + w[None, :, None, None] * eps
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xs, ws = nhwc(x.detach()).requires_grad_(), w.detach().cuda().requires_grad_()
+    ys = ops.UpNoise.apply(xs, ws, nhwc(eps), 1)
+    ys.backward(nhwc(gy))
+    assert rel(nchw(ys.detach(), 16), y.detach()) < TOL
+    assert rel(nchw(xs.grad, 16), x.grad) < TOL
+    assert rel(ws.grad.cpu(), w.grad) < TOL
+
+
+def test_spectral_norm_fwd_bwd_and_buffers():
+    from deepsee_amd import ops
+    g = gen(7)
+    st = {"c.weight_orig": torch.randn(48, 20, 3, 3, generator=g).requires_grad_(),
+          "c.weight_u": F.normalize(torch.randn(48, generator=g), dim=0),
+          "c.weight_v": F.normalize(torch.randn(180, generator=g), dim=0)}
+    w_d = st["c.weight_orig"].detach().cuda().requires_grad_()
+    u_d, v_d = st["c.weight_u"].clone().cuda(), st["c.weight_v"].clone().cuda()
+    for power in (True, True, False):
+        w = O.spectral_weight(st, "c", power)
+        gw = torch.randn(w.shape, generator=g)
+        st["c.weight_orig"].grad = None
+        w.backward(gw)
+        w_d.grad = None
+        wd = ops.SpectralNorm.apply(w_d, u_d, v_d, power)
+        wd.backward(gw.cuda())
+        assert rel(wd.detach().cpu(), w.detach()) < TOL
+        assert rel(u_d.cpu(), st["c.weight_u"]) < TOL and rel(v_d.cpu(), st["c.weight_v"]) < TOL
+        assert rel(w_d.grad.cpu(), st["c.weight_orig"].grad) < 5 * TOL
+
+
+def test_style_pool_fwd_bwd():
+    from deepsee_amd import ops
+    g = gen(9)
+    N, C, Hf, H = 2, 128, 16, 32
+    label = torch.randint(0, 19, (N, 1, H, H), generator=g).float()
+    seg = O.onehot_labels(label, 19)
+    f = torch.randn(N, C, Hf, Hf, generator=g).requires_grad_()
+    s = O.style_pool(f, seg)
+    gs = torch.randn(s.shape, generator=g)
+    s.backward(gs)
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), 19)
+    fs = nhwc(f.detach()).requires_grad_()
+    sd = ops.StylePool.apply(fs, labels, labels.shift_for(Hf))
+    sd.backward(gs.cuda())
+    assert rel(sd.detach().cpu(), s.detach()) < TOL
+    assert rel(nchw(fs.grad, C), f.grad) < TOL
+
+
+def test_pools():
+    from deepsee_amd import ops
+    g = gen(11)
+    x = torch.randn(2, 24, 17, 17, generator=g).requires_grad_()
+    y = F.avg_pool2d(x, 3, 2, [1, 1], count_include_pad=False)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xs = nhwc(x.detach()).requires_grad_()
+    ys = ops.AvgPool3s2.apply(xs)
+    ys.backward(nhwc(gy))
+    assert rel(nchw(ys.detach(), 24), y.detach()) < TOL
+    assert rel(nchw(xs.grad, 24), x.grad) < TOL
+    x = F.relu(torch.randn(2, 8, 12, 12, generator=g)).requires_grad_()  # ties at 0 like VGG after ReLU
+    y = F.max_pool2d(x, 2, 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xs = nhwc(x.detach()).requires_grad_()
+    ys = ops.MaxPool2.apply(xs)
+    ys.backward(nhwc(gy))
+    assert rel(nchw(ys.detach(), 8), y.detach()) == 0.0
+    assert rel(nchw(xs.grad, 8), x.grad) == 0.0
+
+
+def test_preprocess_bicubic_labels_dinput():
+    from deepsee_amd import ops
+    g = gen(13)
+    img = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    lr = O.bicubic_down(img, 8)
+    lr_d = ops.bicubic_down(nhwc(img), 8)
+    assert rel(nchw(lr_d, 3), lr) < 1e-6
+    label = torch.randint(0, 19, (2, 1, 64, 64), generator=g).float()
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), 19)
+    assert torch.equal(labels.t.cpu().long(), label[:, 0].long())
+    seg = O.onehot_labels(label, 19)
+    fake = torch.randn(2, 3, 64, 64, generator=g)
+    want = torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, img], 1)], 0)
+    fk = nhwc(fake).requires_grad_()
+    din = ops.DInput.apply(labels, fk, nhwc(img))
+    assert rel(nchw(din.detach(), 22), want) == 0.0
+    assert float(din[..., 22:].abs().max()) == 0.0
+    gd = torch.randn(4, 22, 64, 64, generator=g)
+    din.backward(nhwc(gd))
+    assert rel(nchw(fk.grad, 3), gd[:2, 19:22]) == 0.0
+
+
+def test_losses():
+    from deepsee_amd import ops
+    g = gen(15)
+    a = torch.randn(4, 1, 9, 9, generator=g).requires_grad_()
+    ad = nhwc(a.detach()).requires_grad_()
+    want = O.Oracle.hinge([[a[:2]]], True, False)
+    got = ops.mean_loss(ad, None, ops.MODE_NEG, 1.0, valid_c=1, lo=0, hi=2)
+    assert abs(float(got) - float(want)) < 1e-6
+    for mode, real in ((ops.MODE_HINGE_REAL, True), (ops.MODE_HINGE_FAKE, False)):
+        a.grad = None
+        ad.grad = None
+        want = O.Oracle.hinge([[a[2:]]], real, True)
+        want.backward()
+        got = ops.mean_loss(ad, None, mode, 1.0, valid_c=1, lo=2, hi=4)
+        got.backward()
+        assert abs(float(got) - float(want)) < 1e-6
+        assert rel(nchw(ad.grad, 1), a.grad) < 1e-6
+    x = torch.randn(2, 32, 5, 5, generator=g).requires_grad_()
+    y = torch.randn(2, 32, 5, 5, generator=g)
+    want = F.l1_loss(x, y) * 2.5
+    want.backward()
+    xd = nhwc(x.detach()).requires_grad_()
+    got = ops.mean_loss(xd, nhwc(y), ops.MODE_L1, 2.5)
+    got.backward()
+    assert abs(float(got) - float(want)) < 1e-5
+    assert rel(nchw(xd.grad, 32), x.grad) < 1e-6
+
+
+def test_rng_statistics():
+    from deepsee_amd import ops
+    z = ops.rng_fill((1 << 20,), 1234, 0, normal=True)
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    u = ops.rng_fill((1 << 20,), 1234, 1 << 20, normal=False)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3
+    z2 = ops.rng_fill((1 << 20,), 1234, 0, normal=True)
+    assert torch.equal(z, z2)
