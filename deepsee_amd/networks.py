@@ -1,0 +1,423 @@
+"""Networks of the DeepSEE train-step hot path on the HIP ops.
+
+Module/parameter names reproduce the reference ``state_dict()`` keys exactly so
+``{epoch}_net_{SR,D,E}.pth`` checkpoints interchange; the computation is re-designed for MI355X:
+NHWC fp32, uint8 label maps instead of one-hot tensors, gamma/beta convolutions fused with the
+sync-free BatchNorm + modulation + LeakyReLU in one MFMA kernel, upsample/noise/residual folded
+into producers/consumers.
+
+Reference: deepsee_models/networks/{sr,architecture,normalization,encoder,discriminator,loss}.py.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+
+NHIDDEN = ops.NHIDDEN
+
+
+# ------------------------------------------------------------------------------------ parameter holders
+class Holder(nn.Module):
+    """Pure container used to reproduce nn.Sequential-style key paths ('mlp_shared.0.weight')."""
+
+
+def attach(root, dotted, module):
+    parts = dotted.split(".")
+    cur = root
+    for p in parts[:-1]:
+        if not hasattr(cur, p):
+            cur.add_module(p, Holder())
+        cur = getattr(cur, p)
+    cur.add_module(parts[-1], module)
+    return module
+
+
+class ConvP(nn.Module):
+    def __init__(self, cout, cin, k, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+
+class SNConvP(nn.Module):
+    """Parameters of spectral_norm(nn.Conv2d): weight_orig (+bias), buffers weight_u / weight_v."""
+
+    def __init__(self, cout, cin, k, bias):
+        super().__init__()
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout))
+        else:
+            self.bias = None
+        self.weight_orig = nn.Parameter(torch.zeros(cout, cin, k, k))
+        self.register_buffer("weight_u", torch.zeros(cout))
+        self.register_buffer("weight_v", torch.zeros(cin * k * k))
+
+    def weight(self, power_iter):
+        return ops.SpectralNorm.apply(self.weight_orig, self.weight_u, self.weight_v, bool(power_iter))
+
+
+class BNStats(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))  # never incremented
+
+
+class VecP(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(n))
+
+
+class Conv1dP(nn.Module):
+    """style_conv = nn.Conv1d(19, 19, 1): defined by the reference, never used (normalization.py:156)."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(19, 19, 1))
+        self.bias = nn.Parameter(torch.zeros(19))
+
+
+# ------------------------------------------------------------------------------------ noise / randomness
+class DeviceNoise:
+    """Production source of the path's random draws: Philox counter RNG on the device for N(0,1)/U(0,1)
+    tensors, python ``random`` for the two per-forward branch coins (sr_model.py:616,643)."""
+
+    def __init__(self, seed=0):
+        import random as _r
+        self.seed, self.offset, self._r = int(seed), 0, _r
+
+    def coin(self, tag):
+        return self._r.random()
+
+    def _fill(self, shape_nhwc, normal):
+        n = 1
+        for s in shape_nhwc:
+            n *= s
+        t = ops.rng_fill(tuple(shape_nhwc), self.seed, self.offset, normal)
+        self.offset += (n + 3) // 4
+        return t
+
+    def normal_nhwc(self, shape_nhwc, tag):
+        return self._fill(shape_nhwc, True)
+
+    def uniform(self, shape, tag):
+        return self._fill(shape, False)
+
+
+class ReplayNoise:
+    """Test-time source: replays a tape recorded from the oracle (oracle.RecordingCtl) so both sides see the
+    same noise tensors and branch decisions."""
+
+    def __init__(self, tape):
+        self.tape, self.pos = list(tape), 0
+
+    def _next(self, kind, tag):
+        k, t, v = self.tape[self.pos]
+        assert k == kind and t == tag, "replay mismatch: want %s/%s, tape has %s/%s" % (kind, tag, k, t)
+        self.pos += 1
+        return v
+
+    def coin(self, tag):
+        return self._next("coin", tag)
+
+    def normal_nhwc(self, shape_nhwc, tag):
+        v = self._next("normal", tag)  # NCHW cpu
+        t = ops.to_nhwc(v.cuda(), shape_nhwc[3])
+        assert tuple(t.shape) == tuple(shape_nhwc)
+        return t
+
+    def uniform(self, shape, tag):
+        v = self._next("uniform", tag)
+        assert tuple(v.shape) == tuple(shape)
+        return v.cuda()
+
+
+# ------------------------------------------------------------------------------------ SPADE / SEAN / PureSEAN
+class SpadeNorm(nn.Module):
+    """normalization.py: SPADE (:71-120), SEAN_Block (:123-213), PureSEAN_Block (:216-286) followed by the
+    resblock's LeakyReLU (architecture.py:92,114)."""
+
+    def __init__(self, kind, c, label_nc, style_size, max_fm_size):
+        super().__init__()
+        self.kind, self.c, self.max_fm = kind, c, max_fm_size
+        self.param_free_norm = BNStats(c)
+        attach(self, "mlp_shared.0", ConvP(NHIDDEN, label_nc, 3))
+        if kind in ("spade", "sean"):
+            self.mlp_gamma = ConvP(c, NHIDDEN, 3)
+            self.mlp_beta = ConvP(c, NHIDDEN, 3)
+        if kind in ("sean", "puresean"):
+            self.style_conv = Conv1dP()
+            self.mlp_style_gamma = ConvP(c, style_size, 3)
+            self.mlp_style_beta = ConvP(c, style_size, 3)
+        if kind == "sean":
+            self.alpha_beta = nn.Parameter(torch.rand(1))
+            self.alpha_gamma = nn.Parameter(torch.rand(1))
+
+    def forward(self, x, labels, style, training):
+        n, h, w, c = x.shape
+        fm = h if self.kind == "spade" else min(h, self.max_fm)  # SPADE.forward has no fm cap
+        shift = labels.shift_for(fm)
+        cat_ups = 0
+        sh = self.mlp_shared._modules["0"]
+        capped = fm != h
+        if capped:
+            # normalization.py:188-190 / 275-277: actv AND style_map both become the nearest-upsampled SPADE
+            # activation (style is ignored; only type-checks because nhidden == style size).
+            cat_ups = int(round(math.log2(h // fm)))
+            actv = ops.SeanInput.apply(sh.weight, sh.bias, None, labels, shift, True, False)
+        if self.kind == "spade":
+            cat = ops.SeanInput.apply(sh.weight, sh.bias, None, labels, shift, True, False)
+            w2, b2 = ops.pack_gamma_beta(self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_gamma.bias,
+                                         self.mlp_beta.bias)
+            add_one = 1.0
+        elif self.kind == "sean":
+            wg, wb = torch.sigmoid(self.alpha_gamma), torch.sigmoid(self.alpha_beta)
+            if capped:
+                # both halves of the concatenated input are `actv`: fold the two weight sets together
+                wgam = (1.0 - wg) * self.mlp_gamma.weight + wg * self.mlp_style_gamma.weight
+                wbet = (1.0 - wb) * self.mlp_beta.weight + wb * self.mlp_style_beta.weight
+                cat = actv
+            else:
+                cat = ops.SeanInput.apply(sh.weight, sh.bias, style, labels, shift, True, True)
+                wgam = torch.cat([(1.0 - wg) * self.mlp_gamma.weight, wg * self.mlp_style_gamma.weight], 1)
+                wbet = torch.cat([(1.0 - wb) * self.mlp_beta.weight, wb * self.mlp_style_beta.weight], 1)
+            bg = (1.0 - wg) * self.mlp_gamma.bias + wg * self.mlp_style_gamma.bias
+            bb = (1.0 - wb) * self.mlp_beta.bias + wb * self.mlp_style_beta.bias
+            w2, b2 = ops.pack_gamma_beta(wgam, wbet, bg, bb)
+            add_one = 1.0
+        else:  # puresean: out = xhat * gamma_s + beta_s
+            cat = actv if capped else ops.SeanInput.apply(sh.weight, sh.bias, style, labels, shift, False, True)
+            w2, b2 = ops.pack_gamma_beta(self.mlp_style_gamma.weight, self.mlp_style_beta.weight,
+                                         self.mlp_style_gamma.bias, self.mlp_style_beta.bias)
+            add_one = 0.0
+        st = self.param_free_norm
+        return ops.SpadeNormAct.apply(x, cat, w2, b2, st.running_mean, st.running_var, training, add_one, cat_ups)
+
+
+class SPADEResnetBlock(nn.Module):
+    """architecture.py:24-147 with fin == fout (identity shortcut)."""
+
+    def __init__(self, c, opt, kind):
+        super().__init__()
+        self.kind, self.add_noise_cfg = kind, bool(opt.add_noise)
+        self.conv_0 = SNConvP(c, c, 3, True)
+        self.conv_1 = SNConvP(c, c, 3, True)
+        self.norm_0 = SpadeNorm(kind, c, opt.semantic_nc, opt.regional_style_size, opt.max_fm_size)
+        self.norm_1 = SpadeNorm(kind, c, opt.semantic_nc, opt.regional_style_size, opt.max_fm_size)
+        if self.add_noise_cfg:
+            self.noise_in, self.noise_skip, self.noise_middle = VecP(c), VecP(c), VecP(c)
+
+    def forward(self, x, labels, style, noise, tag, ups, training, out_act=L.ACT_NONE):
+        noisy = self.add_noise_cfg and training
+        n, h0, w0, c = x.shape
+        shp = (n, h0 << ups, w0 << ups, c)
+        if noisy:
+            x = ops.UpNoise.apply(x, self.noise_in.weight, noise.normal_nhwc(shp, tag + ".noise_in"), ups)
+            x_s = ops.UpNoise.apply(x, self.noise_skip.weight, noise.normal_nhwc(shp, tag + ".noise_skip"), 0)
+        else:
+            if ups:
+                x = ops.UpNoise.apply(x, None, None, ups)
+            x_s = x
+        h = self.norm_0(x, labels, style, training)
+        dx = ops.conv2d(h, self.conv_0.weight(training), self.conv_0.bias)
+        if noisy:
+            dx = ops.UpNoise.apply(dx, self.noise_middle.weight, noise.normal_nhwc(shp, tag + ".noise_middle"), 0)
+        h = self.norm_1(dx, labels, style, training)
+        return ops.conv2d(h, self.conv_1.weight(training), self.conv_1.bias, res=x_s, act=out_act)
+
+
+class DeepSEESR(nn.Module):
+    """sr.py:10-98."""
+
+    def __init__(self, opt, plan):
+        super().__init__()
+        c = 16 * opt.ngf
+        self.c = c
+        self.initial = ConvP(c, 3, 3)
+        self.head_0 = SPADEResnetBlock(c, opt, plan[0][1])
+        self.G_middle_0 = SPADEResnetBlock(c, opt, plan[1][1])
+        self.G_middle_1 = SPADEResnetBlock(c, opt, plan[2][1])
+        self.up_list = nn.ModuleList([SPADEResnetBlock(c, opt, k) for _, k in plan[3:]])
+        self.conv_img = ConvP(3, c, 3)
+
+    def forward(self, image_lr, labels, style, noise, training):
+        x = ops.conv2d(image_lr, self.initial.weight, self.initial.bias)
+        blocks = [("head_0", self.head_0, 0), ("G_middle_0", self.G_middle_0, 1), ("G_middle_1", self.G_middle_1, 0)]
+        blocks += [("up_list.%d" % i, b, 1) for i, b in enumerate(self.up_list)]
+        for i, (tag, blk, ups) in enumerate(blocks):
+            # the LeakyReLU in front of conv_img (sr.py:94) rides in the last block's epilogue
+            last = i == len(blocks) - 1
+            x = blk(x, labels, style, noise, tag, ups, training, L.ACT_LRELU if last else L.ACT_NONE)
+        return ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, act=L.ACT_TANH)
+
+
+# ------------------------------------------------------------------------------------ style encoders
+class EncBranch(nn.Module):
+    """conv(SN, no bias) + InstanceNorm + LeakyReLU stacks of encoder.py:83-99 (full) / :142-158 (mini)."""
+
+    def __init__(self, names, strides, ups, nf, cin):
+        super().__init__()
+        chans = [(nf, cin), (2 * nf, nf), (4 * nf, 2 * nf), (8 * nf, 4 * nf)]
+        self.names, self.strides, self.ups = names, strides, ups
+        for nm, (co, ci) in zip(names, chans):
+            attach(self, nm, SNConvP(co, ci, 3, False))
+
+    def layer(self, nm):
+        m = self
+        for p in nm.split("."):
+            m = m._modules[p]
+        return m
+
+    def forward_main(self, x, training):
+        for nm, s, u in zip(self.names, self.strides, self.ups):
+            x = ops.conv2d(x, self.layer(nm).weight(training), None, stride=s, pad=1, ups=u)
+            x = ops.InstNormAct.apply(x, L.ACT_LRELU)
+        return x
+
+
+FULL_NAMES = ["initial.0.0", "down0.0.0", "down1.0.0", "up_conv.1.0"]
+MINI_NAMES = ["initial.0.0", "conv0.0.0", "conv1.0.0", "conv2.1.0"]
+
+
+class StyleEncoder(nn.Module):
+    """CombinedstyleEncoder (encoder.py:178-210) or FullStyleEncoder (:73-132)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        nf, s = opt.nef, opt.regional_style_size
+        self.combined = opt.netE == "combinedstyle"
+        self.scale = opt.noisy_style_scale
+        self.dist = opt.noisy_style_dist
+        if self.scale > 0:
+            self.noise_weights = nn.Parameter(torch.zeros(opt.label_nc))
+        attach(self, "final.0.0", SNConvP(s, 8 * nf, 3, False))
+        if self.combined:
+            self.encoder_full = EncBranch(FULL_NAMES, [1, 2, 2, 1], [0, 0, 0, 1], nf, 3)
+            attach(self.encoder_full, "final.0.0", SNConvP(s, 8 * nf, 3, False))  # constructed, unused
+            self.encoder_mini = EncBranch(MINI_NAMES, [1, 1, 1, 1], [0, 0, 0, 1], nf, 3)
+            attach(self.encoder_mini, "final.0.0", SNConvP(s, 8 * nf, 3, False))  # constructed, unused
+        elif opt.netE == "fullstyle":
+            # FullStyleEncoder keeps its layers at the root of the state dict
+            chans = [(nf, 3), (2 * nf, nf), (4 * nf, 2 * nf), (8 * nf, 4 * nf)]
+            for nm, (co, ci) in zip(FULL_NAMES, chans):
+                attach(self, nm, SNConvP(co, ci, 3, False))
+        else:
+            raise NotImplementedError("netE=%s (ministyle crashes in the reference too)" % opt.netE)
+
+    def _root_layer(self, nm):
+        m = self
+        for p in nm.split("."):
+            m = m._modules[p]
+        return m
+
+    def forward(self, x, labels, mode, no_noise, noise, training):
+        if self.combined:
+            x = (self.encoder_full if mode == "full" else self.encoder_mini).forward_main(x, training)
+        else:
+            for nm, s, u in zip(FULL_NAMES, [1, 2, 2, 1], [0, 0, 0, 1]):
+                x = ops.conv2d(x, self._root_layer(nm).weight(training), None, stride=s, pad=1, ups=u)
+                x = ops.InstNormAct.apply(x, L.ACT_LRELU)
+        fin = self._root_layer("final.0.0")
+        x = ops.conv2d(x, fin.weight(training), None)
+        x = ops.InstNormAct.apply(x, L.ACT_TANH)
+        sm = ops.StylePool.apply(x, labels, labels.shift_for(x.shape[1]))
+        if self.scale > 0 and not no_noise:
+            # encoder.py:51-70 on the [N,19,S] style matrix (KB-sized parameter-space glue)
+            nw = torch.sigmoid(self.noise_weights)[None, :, None]
+            if self.dist == "uniform":
+                z = noise.uniform(tuple(sm.shape), "style_noise")
+            else:
+                raise NotImplementedError("noisy_style_dist=%s" % self.dist)
+            sm = (sm + ((z * 2 - 1) * self.scale) * nw).clamp(-1, 1)
+        return sm
+
+
+# ------------------------------------------------------------------------------------ discriminator
+class NLayerD(nn.Module):
+    """discriminator.py:67-120."""
+
+    def __init__(self, opt):
+        super().__init__()
+        nf = opt.ndf
+        cin = opt.label_nc + opt.output_nc + (1 if opt.contain_dontcare_label else 0)
+        self.nl = opt.n_layers_D
+        attach(self, "model0.0", ConvP(nf, cin, 4))
+        for n in range(1, self.nl):
+            prev, nf = nf, min(nf * 2, 512)
+            attach(self, "model%d.0.0" % n, SNConvP(nf, prev, 4, False))
+        attach(self, "model%d.0" % self.nl, ConvP(1, nf, 4))
+
+    def forward(self, x, training):
+        outs = []
+        m0 = self.model0._modules["0"]
+        x = ops.conv2d(x, m0.weight, m0.bias, stride=2, pad=2, act=L.ACT_LRELU)
+        outs.append(x)
+        for n in range(1, self.nl):
+            m = getattr(self, "model%d" % n)._modules["0"]._modules["0"]
+            x = ops.conv2d(x, m.weight(training), None, stride=1 if n == self.nl - 1 else 2, pad=2)
+            x = ops.InstNormAct.apply(x, L.ACT_LRELU)
+            outs.append(x)
+        ml = getattr(self, "model%d" % self.nl)._modules["0"]
+        outs.append(ops.conv2d(x, ml.weight, ml.bias, stride=1, pad=2))
+        return outs
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """discriminator.py:14-63."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.num_d = opt.num_D
+        for i in range(opt.num_D):
+            self.add_module("discriminator_%d" % i, NLayerD(opt))
+
+    def forward(self, x, training):
+        res = []
+        for i in range(self.num_d):
+            res.append(getattr(self, "discriminator_%d" % i)(x, training))
+            if i + 1 < self.num_d:
+                x = ops.AvgPool3s2.apply(x)
+        return res
+
+
+# ------------------------------------------------------------------------------------ VGG19 perceptual taps
+VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512]
+VGG_TAPS = (1, 6, 11, 20, 29)
+VGG_WEIGHTS = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+
+class VGG19Taps(nn.Module):
+    """architecture.py:151-181 (frozen).  Keys follow torchvision's vgg19().features indices."""
+
+    def __init__(self):
+        super().__init__()
+        self.features = Holder()
+        cin, idx = 3, 0
+        for v in VGG_CFG:
+            if v == "M":
+                idx += 1
+                continue
+            self.features.add_module(str(idx), ConvP(v, cin, 3))
+            cin = v
+            idx += 2
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        feats, idx = [], 0
+        for v in VGG_CFG:
+            if v == "M":
+                x = ops.MaxPool2.apply(x)
+                idx += 1
+                continue
+            m = self.features._modules[str(idx)]
+            x = ops.conv2d(x, m.weight, m.bias, act=L.ACT_RELU)
+            if idx + 1 in VGG_TAPS:
+                feats.append(x)
+            idx += 2
+        return feats

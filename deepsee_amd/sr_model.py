@@ -1,0 +1,286 @@
+"""SRModel — the model facade of the hot path, same surface as the reference's
+deepsee_models/sr_model.py::SRModel: attributes netSR / netD / netE / opt / model_variant / logs /
+last_encoded_style_is_full / last_encoded_style_is_noisy; forward(data, mode) with modes 'generator',
+'discriminator', 'inference' (anything else raises ValueError like sr_model.py:445-446); create_optimizers(opt);
+save(epoch) / load_weights().  All activation-space compute runs in libdeepsee_hip.so.
+"""
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import networks as N
+from . import ops
+from .optim import FlatAdam
+
+
+def block_plan(opt):
+    """sr.py:27-51: head_0 SPADE ('late' in norm_G), SEAN blocks, PureSEAN tail iff
+    load_size >= 512."""
+    nb = int(round(math.log2(opt.crop_size) - math.log2(opt.start_size)))
+    cfg = opt.norm_G.replace("spectral", "")
+    sk = "sean" if "sean" in cfg else "spade"
+    early = "late" not in opt.norm_G
+    plan = [("head_0", sk if early else "spade"), ("G_middle_0", sk), ("G_middle_1", sk)]
+    max_nb = 4 if opt.load_size >= 512 else 99
+    kinds = [sk] * max(0, min(nb, max_nb) - 1)
+    if max_nb != 99:
+        kinds += ["puresean"] * max(0, nb - max_nb)
+    return plan + [("up_list.%d" % i, k) for i, k in enumerate(kinds)]
+
+
+def init_weights(net, init_type, gain, gen):
+    """base_network.py:28-59 semantics on our parameter holders: xavier_normal(gain) (or kaiming / normal) on
+    every conv weight incl. spectral-norm weight_orig and the unused Conv1d; biases 0; noise weights 0;
+    alpha ~ U(0,1); SN u/v ~ normalised N(0,1)."""
+    for name, p in list(net.named_parameters()) + list(net.named_buffers()):
+        leaf = name.split(".")[-1]
+        if leaf in ("running_mean", "num_batches_tracked"):
+            p.data.zero_()
+        elif leaf == "running_var":
+            p.data.fill_(1.0)
+        elif leaf in ("weight_u", "weight_v"):
+            t = torch.randn(p.shape, generator=gen)
+            p.data.copy_(t / t.norm().clamp_min(1e-12))
+        elif leaf in ("alpha_beta", "alpha_gamma"):
+            p.data.copy_(torch.rand(p.shape, generator=gen))
+        elif leaf == "bias" or leaf == "noise_weights" or ".noise_" in name:
+            p.data.zero_()
+        elif p.dim() >= 3:
+            rf = 1
+            for s in p.shape[2:]:
+                rf *= s
+            fan_in, fan_out = p.shape[1] * rf, p.shape[0] * rf
+            if init_type == "xavier":
+                std = gain * math.sqrt(2.0 / (fan_in + fan_out))
+            elif init_type == "kaiming":
+                std = math.sqrt(2.0 / fan_in)
+            elif init_type == "normal":
+                std = gain
+            else:
+                raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+            p.data.copy_(torch.randn(p.shape, generator=gen) * std)
+
+
+class SRModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError("deepsee_amd.SRModel needs an MI355X (HIP) device: there is no CPU fallback")
+        L.lib()  # fail loudly if libdeepsee_hip.so is missing
+        self.opt = opt
+        self.use_E = opt.netE is not None and len(opt.netE) > 0
+        self.model_variant = "guided" if "full" in opt.netE else "independent"
+        gen = torch.Generator().manual_seed(int(getattr(opt, "seed", 0)))
+        self.netSR = N.DeepSEESR(opt, block_plan(opt))
+        init_weights(self.netSR, opt.init_type, opt.init_variance, gen)
+        self.netD = None
+        if opt.isTrain:
+            self.netD = N.MultiscaleDiscriminator(opt)
+            init_weights(self.netD, opt.init_type, opt.init_variance, gen)
+        self.netE = None
+        if self.use_E:
+            self.netE = N.StyleEncoder(opt)
+            init_weights(self.netE, opt.init_type, opt.init_variance, gen)
+        self.vgg = None
+        if opt.isTrain and not opt.no_vgg_loss:
+            # the reference downloads torchvision's pretrained VGG19 (architecture.py:154); without network access
+            # the weights are He-initialised here and can be replaced with load_vgg_state().
+            self.vgg = N.VGG19Taps()
+            init_weights(self.vgg, "kaiming", 1.0, gen)
+        self.cuda()
+        self.noise = N.DeviceNoise(seed=int(getattr(opt, "seed", 0)) * 7919 + 17)
+        self.logs = OrderedDict()
+        self.last_encoded_style_is_full = True
+        self.last_encoded_style_is_noisy = False
+        if not opt.isTrain or opt.continue_train:
+            self.load_weights()
+
+    # ---- reference surface
+    def get_logs(self):
+        return self.logs
+
+    def use_gpu(self):
+        return True
+
+    def forward(self, data, mode, **kwargs):
+        d = self._native(data)
+        if mode == "generator":
+            g_loss, generated = self.compute_generator_loss(d)
+            self.logs["image/downsized"] = d["image_lr"]
+            return g_loss, generated
+        elif mode == "discriminator":
+            return self.compute_discriminator_loss(d)
+        elif mode == "inference":
+            with torch.no_grad():
+                fake, _ = self.generate_fake(d, no_noise=True)
+            data["fake_image"] = ops.to_nchw(fake, 3)
+            return {k: v for k, v in data.items() if v is not None}
+        else:
+            raise ValueError("|mode| is invalid")
+
+    def create_optimizers(self, opt):
+        """sr_model.py:469-495: G = SR params + non-'mini' E params @ lr/2 (group 0), 'mini' E params @ lr/8
+        (group 1); D @ 2*lr; betas (beta1, beta2)."""
+        g_main = [("SR." + k, p) for k, p in self.netSR.named_parameters()]
+        g_low = []
+        if self.use_E:
+            for k, p in self.netE.named_parameters():
+                (g_low if "mini" in k else g_main).append(("E." + k, p))
+        lr_g, lr_d = (opt.lr, opt.lr) if opt.no_TTUR else (opt.lr / 2, opt.lr * 2)
+        print("lr G: {}, lr D: {}".format(lr_g, lr_d))
+        groups = [{"params": g_main, "lr": lr_g}]
+        if g_low:
+            groups.append({"params": g_low, "lr": lr_g / 4})
+        opt_g = FlatAdam(groups, betas=(opt.beta1, opt.beta2))
+        opt_d = FlatAdam([{"params": [("D." + k, p) for k, p in self.netD.named_parameters()], "lr": lr_d}],
+                         betas=(opt.beta1, opt.beta2))
+        return opt_g, opt_d
+
+    def _ckpt(self, label, epoch):
+        return os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_net_%s.pth" % (epoch, label))
+
+    def save(self, epoch):
+        """util/util.py:217-226: {epoch}_net_{SR,D,E}.pth = {"model": state_dict} with the reference's keys."""
+        os.makedirs(os.path.join(self.opt.checkpoints_dir, self.opt.name), exist_ok=True)
+        for label, net in (("SR", self.netSR), ("D", self.netD), ("E", self.netE)):
+            if net is not None:
+                torch.save({"model": OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())},
+                           self._ckpt(label, epoch))
+
+    def load_weights(self):
+        opt = self.opt
+        for label, net in (("SR", self.netSR), ("D", self.netD if opt.isTrain else None), ("E", self.netE)):
+            if net is None:
+                continue
+            ck = torch.load(self._ckpt(label, opt.which_epoch), map_location="cpu")
+            self.load_net_state(net, ck["model"] if "model" in ck else ck)
+
+    @staticmethod
+    def load_net_state(net, state):
+        """load_state_dict that keeps parameter storage (flat optimizer buffers stay valid)."""
+        own = net.state_dict()
+        missing = set(own) - set(state)
+        extra = set(state) - set(own)
+        if missing or extra:
+            raise RuntimeError("state dict mismatch: missing %s, unexpected %s" % (sorted(missing), sorted(extra)))
+        with torch.no_grad():
+            for k, v in own.items():
+                v.copy_(state[k].to(v.device, v.dtype))
+
+    def load_states(self, states):
+        for label, net in (("SR", self.netSR), ("D", self.netD), ("E", self.netE), ("VGG", self.vgg)):
+            if net is not None and label in states:
+                self.load_net_state(net, states[label])
+
+    # ---- data plumbing
+    def _native(self, data):
+        """Accepts the manager's native dict (NHWC tensors + ops.Labels) or the reference's dict (one-hot NCHW
+        `input_semantics`, NCHW images) and returns the native form."""
+        d = {}
+        sem = data.get("input_semantics")
+        if isinstance(sem, torch.Tensor):
+            lab = sem.argmax(1, keepdim=True).float()
+            sem = ops.Labels(ops.label_to_u8(lab.cuda()), self.opt.label_nc)
+        d["labels"] = sem
+        gl = data.get("guiding_label")
+        if isinstance(gl, torch.Tensor):
+            gl = ops.Labels(ops.label_to_u8(gl.argmax(1, keepdim=True).float().cuda()), self.opt.label_nc)
+        d["guiding_labels"] = gl
+        for k in ("image_lr", "image_hr", "guiding_image"):
+            v = data.get(k)
+            if isinstance(v, torch.Tensor) and v.dim() == 4 and v.shape[1] == 3 and v.shape[3] != 4:
+                v = ops.to_nhwc(v.cuda())
+            d[k] = v
+        return d
+
+    # ---- losses (sr_model.py:518-564)
+    def compute_generator_loss(self, d):
+        opt = self.opt
+        losses = OrderedDict()
+        fake, _ = self.generate_fake(d)
+        pred = self.discriminate(d["labels"], fake, d["image_hr"], train_d=False)
+        n = fake.shape[0]
+        gan = 0
+        for p in pred:
+            gan = gan + ops.mean_loss(p[-1], None, ops.MODE_NEG, 1.0 / len(pred), valid_c=1, lo=0, hi=n)
+        losses["GAN"] = gan
+        if not opt.no_ganFeat_loss:
+            fm = 0
+            for p in pred:
+                for f in p[:-1]:
+                    real = f[n:].detach()
+                    fm = fm + ops.mean_loss(f, real, ops.MODE_L1, opt.lambda_feat / len(pred), lo=0, hi=n)
+            losses["GAN_Feat"] = fm
+        if not opt.no_vgg_loss:
+            fx = self.vgg(fake)
+            with torch.no_grad():
+                fy = self.vgg(d["image_hr"])
+            vl = 0
+            for w, a, b in zip(N.VGG_WEIGHTS, fx, fy):
+                vl = vl + ops.mean_loss(a, b, ops.MODE_L1, w * opt.lambda_vgg)
+            losses["VGG"] = vl
+        return losses, ops.ToNCHW.apply(fake, 3)
+
+    def compute_discriminator_loss(self, d):
+        with torch.no_grad():
+            fake, _ = self.generate_fake(d)
+        fake = fake.detach()
+        pred = self.discriminate(d["labels"], fake, d["image_hr"], train_d=True)
+        n = fake.shape[0]
+        losses = OrderedDict()
+        df = dr = 0
+        for p in pred:
+            df = df + ops.mean_loss(p[-1], None, ops.MODE_HINGE_FAKE, 1.0 / len(pred), valid_c=1, lo=0, hi=n)
+            dr = dr + ops.mean_loss(p[-1], None, ops.MODE_HINGE_REAL, 1.0 / len(pred), valid_c=1, lo=n, hi=2 * n)
+        losses["D_Fake"], losses["D_Real"] = df, dr
+        return losses
+
+    def discriminate(self, labels, fake, real, train_d):
+        """sr_model.py:655-683: one D pass over cat([fake; real]) on N.  In the generator step the D weights only
+        need data gradients (their .grad is zeroed before use), so they enter detached."""
+        x = ops.DInput.apply(labels, fake, real)
+        if train_d:
+            return self.netD(x, self.training)
+        req = [p.requires_grad for p in self.netD.parameters()]
+        for p in self.netD.parameters():
+            p.requires_grad_(False)
+        try:
+            return self.netD(x, self.training)
+        finally:
+            for p, r in zip(self.netD.parameters(), req):
+                p.requires_grad_(r)
+
+    # ---- generator path (sr_model.py:566-650)
+    def generate_fake(self, d, no_noise=False):
+        style = self.encode_style(d, no_noise)
+        fake = self.netSR(d["image_lr"], d["labels"], style, self.noise, self.training)
+        return fake, style
+
+    def encode_style(self, d, no_noise):
+        opt = self.opt
+        labels, img = d["labels"], d["image_lr"]
+        if self.model_variant == "guided":
+            mode = "full"
+            if opt.guiding_style_image:
+                labels, img = d["guiding_labels"], d["guiding_image"]
+            else:
+                img = d["image_hr"]
+            return self.netE(img, labels, mode, no_noise, self.noise, self.training)
+        if opt.full_style_image or (self.training and self.noise.coin("enc_full") < 0.5):
+            mode = "full"
+            self.last_encoded_style_is_full = True
+            if opt.guiding_style_image:
+                labels, img = d["guiding_labels"], d["guiding_image"]
+            else:
+                img = d["image_hr"]
+        else:
+            mode = "mini"
+            self.last_encoded_style_is_full = False
+        if not no_noise:
+            no_noise = self.noise.coin("enc_noise") < 0.5
+            self.last_encoded_style_is_noisy = not no_noise
+        return self.netE(img, labels, mode, no_noise, self.noise, self.training)
