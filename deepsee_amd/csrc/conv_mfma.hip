@@ -42,11 +42,12 @@ struct ConvArgs {
 
 constexpr int BK = 32;
 constexpr int LDK = 36;  // padded LDS row (floats)
+constexpr int FLUSH = 4; // K-slabs per partial-accumulator chain (power of two)
 
 enum { EPI_PLAIN = 0, EPI_MODULATE = 1 };
 
 template <int MT, int NT, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
   constexpr int A_CH = BM * 8 / 256, B_CH = (BN * 8 + 255) / 256;
   static_assert(WM * WN == 4, "4 waves");
@@ -117,13 +118,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
   };
 
-  f32x16 acc[MT][NT];
+  // Two-level accumulation: the MFMA chain runs over at most FLUSH*32 k's into `part`, which is then folded
+  // into `acc`.  A single fp32 chain over K = 4608 has ~eps*sqrt(K) relative error; this brings it to
+  // ~eps*(sqrt(128)+sqrt(K/128)), the same class as a blocked CPU GEMM (see tests/test_gpu_model.py).
+  f32x16 acc[MT][NT], part[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
 
   const int nk = a.Kpad / BK;
   load_tile(0);
@@ -148,9 +152,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
+            part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], part[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tile(cur ^ 1);
+    if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] += part[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+        }
+    }
     __syncthreads();
     cur ^= 1;
   }
@@ -215,7 +229,7 @@ struct WgradArgs {
 
 constexpr int WLD = 132;  // padded LDS row for the 32 x 128 wgrad tiles
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   // D[i = cout][j = k'] = sum over pixels.  A'[px][co] = dout tile, B'[px][k'] = shifted input tile.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][32][WLD]
@@ -272,13 +286,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], part[2][2];  // two-level accumulation over the pixel dimension (see the forward kernel)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
 
   const int nk = (m1 - m0 + 31) / 32;
   if (nk > 0) {
@@ -297,12 +311,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int k = kk * 2 + fk;
       const float a0 = Ac[k * WLD], a1 = Ac[k * WLD + 32];
       const float b0 = Bc[k * WLD], b1 = Bc[k * WLD + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      part[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, part[0][0], 0, 0, 0);
+      part[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, part[0][1], 0, 0, 0);
+      part[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, part[1][0], 0, 0, 0);
+      part[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, part[1][1], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tile(cur ^ 1);
+    if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] += part[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+        }
+    }
     __syncthreads();
     cur ^= 1;
   }

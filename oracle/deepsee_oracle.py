@@ -318,6 +318,20 @@ class RecordingCtl(Ctl):
         return v
 
 
+class _CastCtl(Ctl):
+    def __init__(self, inner, dtype):
+        self.inner, self.dtype = inner, dtype
+
+    def coin(self, tag):
+        return self.inner.coin(tag)
+
+    def normal(self, shape, tag):
+        return self.inner.normal(shape, tag).to(self.dtype)
+
+    def uniform(self, shape, tag):
+        return self.inner.uniform(shape, tag).to(self.dtype)
+
+
 class ReplayCtl(Ctl):
     def __init__(self, tape):
         self.tape, self.pos = list(tape), 0
@@ -347,11 +361,11 @@ def lrelu(x):
     return F.leaky_relu(x, LRELU)
 
 
-def onehot_labels(label, nc):
+def onehot_labels(label, nc, dtype=torch.float32):
     """data/preprocessor.py:35-41 — float label map [N,1,H,W] (0..nc-1) -> one-hot."""
     lab = label.long()
     n, _, h, w = lab.shape
-    return torch.zeros(n, nc, h, w).scatter_(1, lab, 1.0)
+    return torch.zeros(n, nc, h, w, dtype=dtype).scatter_(1, lab, 1.0)
 
 
 def bicubic_down(img, size):
@@ -425,14 +439,19 @@ def style_pool(feat, seg):
 class Oracle:
     """Holds the four state dicts and evaluates the path functionally."""
 
-    def __init__(self, opt, states, ctl=None):
+    def __init__(self, opt, states, ctl=None, dtype=torch.float32):
+        """dtype=torch.float64 turns the oracle into an exact-arithmetic yardstick: tests compare
+        err(HIP, f64) with err(this oracle in f32, f64)."""
         self.opt = opt
-        self.ctl = ctl or Ctl()
+        self.dtype = dtype
+        self.ctl = _CastCtl(ctl or Ctl(), dtype) if dtype != torch.float32 else (ctl or Ctl())
         self.S = {}
         for net, st in states.items():
             d = OrderedDict()
             for k, v in st.items():
                 t = v.detach().clone()
+                if t.is_floating_point():
+                    t = t.to(dtype)
                 if not is_buffer(k) and net != "VGG" and t.is_floating_point():
                     t.requires_grad_(True)
                 d[k] = t
@@ -652,7 +671,7 @@ class Oracle:
         for p in preds:
             x = p[-1]
             if for_d:
-                mv = torch.min((x - 1) if target_is_real else (-x - 1), torch.zeros(1))
+                mv = torch.min((x - 1) if target_is_real else (-x - 1), torch.zeros(1, dtype=x.dtype))
                 l = -mv.mean()
             else:
                 l = -x.mean()
@@ -666,7 +685,7 @@ class Oracle:
         losses = OrderedDict()
         losses["GAN"] = self.hinge(pf, True, False)
         if not opt.no_ganFeat_loss:
-            fm = torch.zeros(1)
+            fm = torch.zeros(1, dtype=fake.dtype)
             for i in range(len(pf)):
                 for j in range(len(pf[i]) - 1):
                     fm = fm + F.l1_loss(pf[i][j], pr[i][j].detach()) * opt.lambda_feat / len(pf)
@@ -687,15 +706,16 @@ class Oracle:
 
     # ---- manager level (base_manager.py:28-66, trainer_manager.py:32-96)
     def preprocess(self, batch):
-        opt = self.opt
+        opt, dt = self.opt, self.dtype
+        img = batch["image"].to(dt)
         out = {
-            "input_semantics": onehot_labels(batch["label"], opt.label_nc),
-            "image_lr": bicubic_down(batch["image"], opt.start_size),
-            "image_hr": batch["image"],
+            "input_semantics": onehot_labels(batch["label"], opt.label_nc, dt),
+            "image_lr": bicubic_down(img, opt.start_size),
+            "image_hr": img,
         }
         if opt.guiding_style_image:
-            out["guiding_image"] = batch["guiding_image"]
-            out["guiding_label"] = onehot_labels(batch["guiding_label"], opt.label_nc)
+            out["guiding_image"] = batch["guiding_image"].to(dt)
+            out["guiding_label"] = onehot_labels(batch["guiding_label"], opt.label_nc, dt)
         return out
 
     def params(self, net):

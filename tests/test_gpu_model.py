@@ -71,35 +71,138 @@ def run_case(over, seed, iters=1):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_train_step_matches_oracle(name):
+    """Full G+D step with the real losses.  Forward quantities are tight.  Gradients of the REAL loss are only
+    comparable up to the path's conditioning: the L1 (feature-matching, VGG) and hinge terms have sign-function
+    gradients, and at these tiny test resolutions a single near-tie element (|a-b| ~ 1e-6, found and printed by
+    tools/debug_vgg2.py) flips between any two fp32 implementations and moves a 4096-element tap's gradient by
+    2/sqrt(4096) = 3e-2.  The tight gradient check is test_smooth_loss_backward below; here the median over all
+    tensors must be small and no tensor may be far off."""
     orc, tm, out = run_case(CASES[name], seed=101 + len(name))
     r = out[0]
+    clip = CASES[name].get("gradient_clip", -1)
+    if clip > 0:  # clip_grad_value_ rewrites .grad in the reference; the HIP path clamps inside the Adam kernel
+        r["hg"] = {k: v.clamp(-clip, clip) for k, v in r["hg"].items()}
+        r["hd"] = {k: v.clamp(-clip, clip) for k, v in r["hd"].items()}
     for k, v in r["gl"].items():
-        assert abs(r["hgl"][k] - v) <= 1e-3 * abs(v), (k, r["hgl"][k], v)
-    assert rel(r["hfake"], r["fake"]) < 1e-3
+        assert abs(r["hgl"][k] - v) <= 1e-4 * abs(v), (k, r["hgl"][k], v)
+    assert rel(r["hfake"], r["fake"]) < 1e-4
     # the set of tensors that received a gradient equals the reference's "grad is not None" set
     assert r["touched_g"] == set(r["ggrads"]), r["touched_g"] ^ set(r["ggrads"])
     gmax = max(float(v.norm()) for v in r["ggrads"].values())
-    worst = 0.0
-    for k, v in r["ggrads"].items():
-        e = float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
-        worst = max(worst, e)
-        assert e < 5e-3, (k, e)
+    errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
+                  for k, v in r["ggrads"].items())
+    assert errs[len(errs) // 2] < 2e-2 and errs[-1] < 1e-1, (errs[len(errs) // 2], errs[-1])
     for k, v in r["dl"].items():
         assert abs(r["hdl"][k] - v) <= 2e-3 * abs(v), (k, r["hdl"][k], v)
     dmax = max(float(v.norm()) for v in r["dgrads"].values())
-    for k, v in r["dgrads"].items():
-        e = float((r["hd"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * dmax)
-        assert e < 5e-2, (k, e)
+    derrs = sorted(float((r["hd"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-2 * dmax)
+                   for k, v in r["dgrads"].items())
+    assert derrs[-1] < 2e-1, derrs[-1]
     # post-step state: parameters (Adam) and buffers (BN running stats twice, SN u/v twice)
     sd = {"SR": tm.sr_model.netSR.state_dict(), "D": tm.sr_model.netD.state_dict(), "E": tm.sr_model.netE.state_dict()}
     zero_grad = {k for k, v in {**r["ggrads"], **r["dgrads"]}.items() if float(v.norm()) < 1e-4 * max(gmax, dmax)}
     for net in ("SR", "D", "E"):
-        assert list(sd[net].keys()) == list(orc.S[net].keys())
+        assert set(sd[net].keys()) == set(orc.S[net].keys())
         for k, v in sd[net].items():
-            if "%s.%s" % (net, k) in zero_grad or not v.is_floating_point():
+            if not v.is_floating_point():
                 continue
-            assert rel(v.cpu(), orc.S[net][k].detach()) < 1e-3, (net, k)
-    print("worst G-grad rel err %.2e" % worst)
+            ref = orc.S[net][k].detach()
+            if O.is_buffer(k):
+                assert rel(v.cpu(), ref) < 2e-3, (net, k)
+            else:
+                # beta1=0 Adam moves every element by ~lr*sign(g): elements whose gradient is rounding noise may
+                # step the other way, so the bound is per element (2 steps of the largest lr) plus a small mean.
+                dlt = (v.cpu() - ref).abs()
+                assert float(dlt.max()) <= 2.5 * 4e-4, (net, k, float(dlt.max()))
+                if "%s.%s" % (net, k) not in zero_grad:   # (analytically-zero gradients are all noise)
+                    assert float(dlt.mean()) <= 4e-5, (net, k, float(dlt.mean()))
+    print("G-grad rel err: median %.2e max %.2e; D-grad max %.2e" % (errs[len(errs) // 2], errs[-1], derrs[-1]))
+
+
+@pytest.mark.parametrize("name", ["indep_8to64_ngf8", "guided_4to32_ngf8", "puresean_4to128_ngf4", "config1_4to32_full"])
+def test_smooth_loss_backward(name):
+    """Backward parity with the sign-function losses taken out: L_G = <fake, R>, L_D = sum_k <D_k(cat[fake;real]), R_k>,
+    L_V = sum_i <VGG_i(fake), R_i> with fixed random R.  Every HIP backward kernel of the path (SPADE/SEAN modulate,
+    BN, convs dgrad/wgrad, SN, noise, upsample, IN, pools, style pool/gather, one-hot conv) is exercised and compared
+    with the oracle in float64: the HIP error must be within 10x the CPU-fp32 oracle's own
+    error (floor 1e-4; the MFMA accumulates each output in one fp32 chain over K, oneDNN in blocked partial sums) and
+    below 2e-3 absolutely."""
+    from deepsee_amd import networks as N, ops
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt
+    over = CASES[name]
+    n = over["batchSize"]
+    oopt = O.make_opt(**over)
+    states = O.recipe_state(oopt, gain=1.0)
+    batch = O.synthetic_batch(oopt, n, seed=555)
+    gR = torch.Generator().manual_seed(9)
+
+    def oracle_run(dtype, tape=None):
+        ctl = O.RecordingCtl() if tape is None else O.ReplayCtl(tape)
+        orc = O.Oracle(oopt, states, ctl, dtype=dtype)
+        random.seed(3)
+        torch.manual_seed(3)
+        data = orc.preprocess({k: v.clone() for k, v in batch.items()})
+        fake, _ = orc.generate_fake(data)
+        Rs = {"fake": torch.randn(fake.shape, generator=torch.Generator().manual_seed(1)).to(dtype)}
+        loss = (fake * Rs["fake"]).sum()
+        both = torch.cat([torch.cat([data["input_semantics"], fake], 1),
+                          torch.cat([data["input_semantics"], data["image_hr"]], 1)], 0)
+        douts = orc.d_forward(both)
+        k = 0
+        for o in douts:
+            for t in o:
+                R = torch.randn(t.shape, generator=torch.Generator().manual_seed(100 + k)).to(dtype)
+                Rs["d%d" % k] = R
+                loss = loss + (t * R).sum() / t[0].numel() ** 0.5
+                k += 1
+        for i, t in enumerate(orc.vgg_features(fake)):
+            R = torch.randn(t.shape, generator=torch.Generator().manual_seed(200 + i)).to(dtype)
+            Rs["v%d" % i] = R
+            loss = loss + (t * R).sum() / t[0].numel() ** 0.5
+        loss.backward()
+        grads = {"%s.%s" % (net, kk): p.grad.clone() for net in ("SR", "E", "D") for kk, p in orc.params(net)
+                 if p.grad is not None}
+        return orc, ctl, fake.detach(), float(loss.detach()), grads, Rs
+
+    orc32, ctl, fake32, loss32, g32, Rs = oracle_run(torch.float32)
+    _, _, fake64, loss64, g64, _ = oracle_run(torch.float64, ctl.tape)
+
+    tm = TrainerManager(make_opt(**over))
+    m = tm.sr_model
+    m.load_states(states)
+    m.noise = N.ReplayNoise(ctl.tape)
+    tm.optimizer_G.zero_grad()
+    tm.optimizer_D.zero_grad()
+    d = m._native(tm.preprocess_input({k: v.clone() for k, v in batch.items()}))
+    fake, _ = m.generate_fake(d)
+    loss = (ops.ToNCHW.apply(fake, 3) * Rs["fake"].cuda()).sum()
+    douts = m.discriminate(d["labels"], fake, d["image_hr"], train_d=True)
+    k = 0
+    for o in douts:
+        for t in o:
+            c = Rs["d%d" % k].shape[1]
+            loss = loss + (ops.ToNCHW.apply(t, c) * Rs["d%d" % k].cuda()).sum() / Rs["d%d" % k][0].numel() ** 0.5
+            k += 1
+    for i, t in enumerate(m.vgg(fake)):
+        R = Rs["v%d" % i]
+        loss = loss + (ops.ToNCHW.apply(t, R.shape[1]) * R.cuda()).sum() / R[0].numel() ** 0.5
+    loss.backward()
+    torch.cuda.synchronize()
+    hg = {nm: p.grad.detach().cpu() for o in (tm.optimizer_G, tm.optimizer_D) for nm, p in zip(o.names, o.params)}
+    assert abs(float(loss) - loss64) <= 1e-4 * abs(loss64)
+    assert rel(ops.to_nchw(fake.detach(), 3).cpu(), fake64) < 1e-5
+    gmax = max(float(v.norm()) for v in g64.values())
+    worst = (0.0, "")
+    for kk, v in g64.items():
+        # alpha_gamma / alpha_beta (SEAN blend scalars) are differences of two ~1e6-term inner products in both
+        # implementations (cancellation): judge them against 1 % of the largest gradient instead of their own size
+        den = max(float(v.norm()), (1e-2 if v.numel() == 1 else 1e-3) * gmax)
+        eh = float((hg[kk].double() - v).norm()) / den
+        ec = float((g32[kk].double() - v).norm()) / den
+        assert eh <= max(10 * ec, 3e-4) and eh < 2e-3, (kk, eh, ec)
+        worst = max(worst, (eh, kk))
+    print("worst HIP-vs-f64 grad error %.2e (%s)" % worst)
 
 
 def test_inference_mode_matches_oracle():
