@@ -19,6 +19,34 @@ NHIDDEN = 128
 
 _scratch = {}
 
+# bench.py sets this to a dict to time every MFMA conv launch with HIP events on the launch stream:
+# PROFILE[kernel_name] = [(start_event, end_event, algorithmic_flops), ...]
+PROFILE = None
+
+
+def _variant(geom):
+    return "conv_igemm_128x128" if geom.Cout > 64 else ("conv_igemm_256x64" if geom.Cout > 32 else "conv_igemm_128x32")
+
+
+def _flops(geom):
+    m = geom.N * geom.Ho * geom.Wo
+    return 2.0 * m * geom.Cout * geom.KH * geom.KW * geom.Cin / (4 ** geom.dshift)
+
+
+class _timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.setdefault(self.name, []).append((self.s, self.e, self.flops))
+
 
 def scratch(nbytes, tag="ws"):
     """Grow-only device scratch (fp32).  Safe to share: all kernels run in stream order and every
@@ -127,7 +155,8 @@ def _pack_dgrad(w, cout_s):
 
 def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
-    L.call("conv2d_fwd", C.byref(geom), x, wp, bias, res, out, act, float(slope))
+    with _timed(_variant(geom), _flops(geom)):
+        L.call("conv2d_fwd", C.byref(geom), x, wp, bias, res, out, act, float(slope))
     return out
 
 
@@ -135,7 +164,8 @@ def wgrad_raw(x, dout, geom, cout, cin, kh, kw):
     nbytes = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
     ws = scratch(nbytes, "wgrad")
     dw = new(cout, cin, kh, kw)
-    L.call("conv2d_wgrad", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin)
+    with _timed("conv_wgrad_128x128(+slab reduce)", _flops(geom)):
+        L.call("conv2d_wgrad", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin)
     return dw
 
 
@@ -415,8 +445,10 @@ class SpadeNormAct(torch.autograd.Function):
         assert geom.Ho == h and geom.Wo == w
         w2 = w2.contiguous()
         out, scale = torch.empty_like(x), torch.empty_like(x)
-        L.call("conv2d_modulate_fwd", C.byref(geom), cat, _pack_fwd(w2, kin), b2.contiguous(), x, mean, invstd, out,
-               scale, c, float(add_one), LRELU_SLOPE)
+        wp = _pack_fwd(w2, kin)
+        with _timed("conv_igemm_128x128_modulate", _flops(geom)):
+            L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, b2.contiguous(), x, mean, invstd, out, scale, c,
+                   float(add_one), LRELU_SLOPE)
         ctx.geom = geom
         ctx.save_for_backward(x, cat, w2, out, scale, mean, invstd)
         return out
