@@ -15,6 +15,8 @@
 // K is walked in 32-float slabs staged global -> VGPR -> LDS (double-buffered, one barrier per
 // slab); LDS rows are padded to 36 floats so the ds_read_b128 fragment reads (lane<32: k..k+3,
 // lane>=32: k+4..k+7 of an 8-wide k group) are bank-conflict free.
+#include <stdlib.h>
+
 #include "dsee_common.h"
 
 namespace {
@@ -34,7 +36,8 @@ struct ConvArgs {
   int C;               // channels of mx / out in modulate mode
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
   int KH, KW, Ktot, Kpad;
-  int mul, off, kdir, dshift, ups;
+  int mul, off, kdir, dshift, ups, korder;
+  int margin;  // GEO 1: bytes the A buffer base is moved down so that every tap's scalar offset is >= 0
   int act;
   float slope;
   int M;
@@ -46,76 +49,175 @@ constexpr int FLUSH = 4; // K-slabs per partial-accumulator chain (power of two)
 
 enum { EPI_PLAIN = 0, EPI_MODULATE = 1 };
 
-template <int MT, int NT, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+// GEO = 1: source pixel is an affine function of the output pixel (dshift == 0, ups == 0) and Cin % 32 == 0, so the
+//          per-slab address work is a handful of selects; GEO = 0: general geometry (strided dgrads, fused upsample,
+//          odd channel counts) with a division per slab.  Both are branch-free inside the K loop so that the address
+//          arithmetic and the global loads of slab kt+1 interleave with the MFMAs of slab kt (the matrix pipe takes a
+//          new MFMA only every 64 cycles per wave; everything else issues in its shadow).
+template <int MT, int NT, int WM, int WN, int EPI, int GEO>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
-  constexpr int A_CH = BM * 8 / 256, B_CH = (BN * 8 + 255) / 256;
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int NTHR = WM * WN * 64, RPP = NTHR / 8;  // threads, LDS rows filled per pass
+  constexpr int A_CH = BM * 8 / NTHR, B_CH = BN * 8 / NTHR;
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+  static_assert(A_CH >= 1 && B_CH >= 1, "at least one chunk per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * BM * LDK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int bm = blockIdx.x, bn = blockIdx.y;
+  // XCD-aware tile order.  Hardware places workgroup b on XCD b % 8 (speed only, never correctness): give every XCD
+  // a contiguous range of logical tiles and walk the N tiles of one M tile back to back, so the (up to 4) blocks that
+  // read the same A rows, and the vertically adjacent M tiles that share halo rows, meet in one XCD's 4 MB L2.
+  int bm, bn;
+  {
+    const int nbn = gridDim.y, total = gridDim.x * nbn;
+    const int b = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bn = l % nbn;
+    bm = l / nbn;
+  }
   const int chunk = tid & 7, lrow = tid >> 3;
+  const int Hl = a.Hi << a.ups, Wl = a.Wi << a.ups;
+  const int dmask = (1 << a.dshift) - 1;
+  const int ntaps = a.KH * a.KW;
 
+  // per-row state
   int a_n[A_CH], a_oh[A_CH], a_ow[A_CH];
   bool a_ok[A_CH];
+  unsigned a_voff[A_CH];  // GEO 1: byte offset of the row's centre pixel (oh*mul, ow*mul) + this thread's 16-B chunk
+  unsigned a_mask[A_CH];  // GEO 1: bit t = tap t reads inside the image
 #pragma unroll
   for (int j = 0; j < A_CH; ++j) {
-    int m = bm * BM + lrow + 32 * j;
+    const int m = bm * BM + lrow + RPP * j;
     a_ok[j] = m < a.M;
-    int mm = a_ok[j] ? m : 0;
-    int ow = mm % a.Wo;
-    int t = mm / a.Wo;
+    const int mm = a_ok[j] ? m : 0;
+    const int ow = mm % a.Wo;
+    const int t = mm / a.Wo;
     a_ow[j] = ow;
     a_oh[j] = t % a.Ho;
     a_n[j] = t / a.Ho;
+    if constexpr (GEO == 1) {
+      const int h0 = a_oh[j] * a.mul + a.off, w0 = a_ow[j] * a.mul + a.off;
+      a_voff[j] = (unsigned)((((size_t)(a_n[j] * a.Hi + a_oh[j] * a.mul) * a.Wi + a_ow[j] * a.mul) * a.Cin + chunk * 4) * 4);
+      unsigned msk = 0;
+      for (int t2 = 0; t2 < ntaps; ++t2) {
+        const int ph = h0 + (t2 / a.KW) * a.kdir, pw = w0 + (t2 % a.KW) * a.kdir;
+        if (a_ok[j] && ph >= 0 && ph < a.Hi && pw >= 0 && pw < a.Wi) msk |= 1u << t2;
+      }
+      a_mask[j] = msk;
+    }
   }
-  const int Hl = a.Hi << a.ups, Wl = a.Wi << a.ups;
-  const int dmask = (1 << a.dshift) - 1;
+  // GEO 1 walks K chunk-major (korder 1): slab kt = (32-channel chunk kt / ntaps, tap kt % ntaps), so the 9 taps of a
+  // channel chunk re-read the same input pixels in consecutive slabs (L1/L2 hits) instead of 16 slabs apart.
+  // Its loads are buffer loads: per-row VGPR offset (constant for the whole kernel) + one SCALAR offset per slab
+  // (tap shift + channel chunk), out-of-image taps get offset 0xFFFFFFFF >= num_records and come back as zeros from
+  // the hardware range check.  Address work per slab: ~3 VALU per row instead of 64-bit pointer arithmetic.
+  int g_tap = 0, g_kh = 0, g_kw = 0, g_cc = 0;
+  const float* wrow[B_CH];
+  unsigned b_voff[B_CH];
+#pragma unroll
+  for (int j = 0; j < B_CH; ++j) {
+    wrow[j] = a.w + (size_t)(bn * BN + lrow + RPP * j) * a.Kpad + chunk * 4;
+    b_voff[j] = (unsigned)(((size_t)(lrow + RPP * j) * a.Kpad + chunk * 4) * 4);
+  }
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(a.in) - a.margin), 0, 0xFFFFFFFE, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.w + (size_t)bn * BN * a.Kpad), 0, 0xFFFFFFFE, 0x00020000);
 
+  // Loads are unconditional (masked rows read element 0 of the tensor); the zero fill is applied when the slab
+  // is written to LDS, so nothing in the load section depends on a load result.
   f32x4 ra[A_CH], rb[B_CH];
+  float ra_keep[A_CH];
   auto load_tile = [&](int kt) {
-    const int k = kt * BK + chunk * 4;
-    const int tap = k / a.Cin;
-    const int c = k - tap * a.Cin;
-    const int kh = tap / a.KW;
-    const int kw = tap - kh * a.KW;
-    const bool kok = k < a.Ktot;
+#if defined(DSEE_ABL) && DSEE_ABL == 7
+    // ablation: same number of loads, trivial addressing (wrong data)
 #pragma unroll
     for (int j = 0; j < A_CH; ++j) {
-      int ph = a_oh[j] * a.mul + a.off + kh * a.kdir;
-      int pw = a_ow[j] * a.mul + a.off + kw * a.kdir;
-      bool ok = a_ok[j] && kok && ph >= 0 && pw >= 0 && ((ph | pw) & dmask) == 0;
-      ph >>= a.dshift;
-      pw >>= a.dshift;
-      ok = ok && ph < Hl && pw < Wl;
-      ph >>= a.ups;
-      pw >>= a.ups;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(a_n[j] * a.Hi + ph) * a.Wi + pw) * a.Cin + c);
-      ra[j] = v;
+      ra[j] = *reinterpret_cast<const f32x4*>(a.in + (size_t)(lrow + 32 * j) * a.Cin + chunk * 4 + (size_t)kt * BK);
+      ra_keep[j] = 1.f;
     }
 #pragma unroll
-    for (int j = 0; j < B_CH; ++j) {
-      int row = lrow + 32 * j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < BN) v = *reinterpret_cast<const f32x4*>(a.w + (size_t)(bn * BN + row) * a.Kpad + k);
-      rb[j] = v;
+    for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
+    return;
+#endif
+    if constexpr (GEO == 1) {
+      const int s_tap = __builtin_amdgcn_readfirstlane(g_tap);
+      const bool kok = __builtin_amdgcn_readfirstlane(g_cc) * BK < a.Cin;
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(
+          ((a.off + g_kh * a.kdir) * a.Wi + (a.off + g_kw * a.kdir)) * a.Cin * 4 + a.margin + g_cc * (BK * 4));
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        const bool ok = kok && ((a_mask[j] >> s_tap) & 1u);
+#if defined(DSEE_ABL) && DSEE_ABL == 9
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              rsrc_a, ok ? (unsigned)((lrow + RPP * j) * 512 + chunk * 16) : 0xFFFFFFFFu,
+                                              (unsigned)a.margin, 0));
+#else
+        ra[j] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[j] : 0xFFFFFFFFu, soff, 0));
+#endif
+      }
+#if defined(DSEE_ABL) && DSEE_ABL == 8
+      const unsigned soff_b = 0;
+#else
+      const unsigned soff_b = (unsigned)__builtin_amdgcn_readfirstlane(kt * (BK * 4));
+#endif
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j)
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], soff_b, 0));
+      // advance to the next slab (scalar selects only): next tap, then next channel chunk
+      g_tap += 1;
+      g_kw += 1;
+      const int kwrap = g_kw == a.KW;
+      g_kw = kwrap ? 0 : g_kw;
+      g_kh += kwrap;
+      const int twrap = g_tap == ntaps;
+      g_tap = twrap ? 0 : g_tap;
+      g_kh = twrap ? 0 : g_kh;
+      g_cc += twrap;
+      return;
+    } else {
+      const int k = kt * BK + chunk * 4;
+      const int tap = k / a.Cin;
+      const int c = k - tap * a.Cin;
+      const int kh = tap / a.KW;
+      const int kw = tap - kh * a.KW;
+      const bool kok = k < a.Ktot;
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        int ph = a_oh[j] * a.mul + a.off + kh * a.kdir;
+        int pw = a_ow[j] * a.mul + a.off + kw * a.kdir;
+        bool ok = a_ok[j] && kok && ph >= 0 && pw >= 0 && ((ph | pw) & dmask) == 0;
+        ph >>= a.dshift;
+        pw >>= a.dshift;
+        ok = ok && ph < Hl && pw < Wl;
+        ph >>= a.ups;
+        pw >>= a.ups;
+        const size_t o = ok ? ((size_t)(a_n[j] * a.Hi + ph) * a.Wi + pw) * a.Cin + c : 0;
+        ra[j] = *reinterpret_cast<const f32x4*>(a.in + o);
+        ra_keep[j] = ok ? 1.f : 0.f;
+      }
     }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
   };
+  const int nk = a.Kpad / BK;
   auto store_tile = [&](int buf) {
     float* Ab = As + buf * BM * LDK;
     float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
-    for (int j = 0; j < A_CH; ++j) *reinterpret_cast<f32x4*>(Ab + (lrow + 32 * j) * LDK + chunk * 4) = ra[j];
-#pragma unroll
-    for (int j = 0; j < B_CH; ++j) {
-      int row = lrow + 32 * j;
-      if (row < BN) *reinterpret_cast<f32x4*>(Bb + row * LDK + chunk * 4) = rb[j];
+    for (int j = 0; j < A_CH; ++j) {
+      // GEO 1: the buffer range check already returned zeros.  GEO 0: select (not multiply: a masked row may have
+      // read Inf/NaN from an unrelated element)
+      const f32x4 v = (GEO == 1 || ra_keep[j] != 0.f) ? ra[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Ab + (lrow + RPP * j) * LDK + chunk * 4) = v;
     }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) *reinterpret_cast<f32x4*>(Bb + (lrow + RPP * j) * LDK + chunk * 4) = rb[j];
   };
 
   // Two-level accumulation: the MFMA chain runs over at most FLUSH*32 k's into `part`, which is then folded
@@ -129,32 +231,65 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
 
-  const int nk = a.Kpad / BK;
   load_tile(0);
   store_tile(0);
   __syncthreads();
   int cur = 0;
   const int frow = lane & 31, fk = (lane >> 5) * 4;
+  const int a_frag = (wm * MT * 32 + frow) * LDK + fk, b_frag = (wn * NT * 32 + frow) * LDK + fk;
+  // Fragment registers are double-buffered so that the K loop is software-pipelined ACROSS the barrier: the last
+  // MFMA group of slab kt (operands already in registers) executes while the block synchronises and while the first
+  // fragments of slab kt+1 come back from LDS, instead of leaving the matrix pipe empty for barrier + ds_read latency.
+  f32x4 af[2][MT], bf[2][NT];
+  auto read_frags = [&](int buf, int kk, int set) {
+#if defined(DSEE_ABL) && DSEE_ABL >= 4
+    if (kk >= 0) return;
+#endif
+    const float* Ac = As + buf * BM * LDK + a_frag + kk * 8;
+    const float* Bc = Bs + buf * BN * LDK + b_frag + kk * 8;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDK);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDK);
+  };
+  auto mma_group = [&](int set) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][q], bf[set][j][q], part[i][j], 0, 0, 0);
+  };
+  load_tile(min(1, nk - 1));  // staging registers now hold slab 1
+  read_frags(0, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const float* Ac = As + cur * BM * LDK + (wm * MT * 32 + frow) * LDK + fk;
-    const float* Bc = Bs + cur * BN * LDK + (wn * NT * 32 + frow) * LDK + fk;
+    read_frags(cur, 1, 1);
+    mma_group(0);
+    read_frags(cur, 2, 0);
+    mma_group(1);
+    read_frags(cur, 3, 1);
+    mma_group(0);
+    __builtin_amdgcn_sched_barrier(0);  // first use of slab kt+1's loads (issued one whole slab = 4096 MFMA cycles ago)
+#if !defined(DSEE_ABL) || DSEE_ABL < 1 || DSEE_ABL == 6
+    store_tile(cur ^ 1);
+#elif DSEE_ABL == 5
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      f32x4 af[MT], bf[NT];
+    for (int j = 0; j < A_CH; ++j) asm volatile("" ::"v"(ra[j]), "v"(ra_keep[j]));
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDK + kk * 8);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDK + kk * 8);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], part[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+    for (int j = 0; j < B_CH; ++j) asm volatile("" ::"v"(rb[j]));
+#endif
+#if !defined(DSEE_ABL) || DSEE_ABL < 3
+    __syncthreads();
+#endif
+    read_frags(cur ^ 1, 0, 0);          // next slab's first fragments ...
+    // ... and the global loads of slab kt+2 into the staging registers that were just drained: both issue under the
+    // last MFMA group of this slab.  Branch-free: past the end the final slab is simply fetched again.
+#if !defined(DSEE_ABL) || DSEE_ABL < 2 || DSEE_ABL == 5
+    load_tile(min(kt + 2, nk - 1));
+#endif
+    mma_group(1);
+    __builtin_amdgcn_sched_barrier(0);
     if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -165,7 +300,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
           for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
         }
     }
-    __syncthreads();
     cur ^= 1;
   }
 
@@ -346,16 +480,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------- pack / unpack
+// k index of (tap, ci): korder 0 = tap-major  tap*C + ci ; korder 1 = chunk-major (ci/32)*(taps*32) + tap*32 + ci%32
+__device__ __forceinline__ void k_to_tap_ci(int k, int C, int taps, int korder, int& tap, int& ci) {
+  if (korder == 0) {
+    tap = k / C;
+    ci = k % C;
+  } else {
+    const int cc = k / (taps * 32), rem = k % (taps * 32);
+    tap = rem / 32;
+    ci = cc * 32 + (rem & 31);
+  }
+}
+
 __global__ void pack_fwd_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale_num,
                                 const float* __restrict__ inv_scale_den, float* __restrict__ p, int Cout, int Cin,
-                                int KH, int KW, int Cin_s, int rows, int Kpad) {
-  // p[row][(kh*KW+kw)*Cin_s + ci] = w[row][ci][kh][kw] * s
+                                int KH, int KW, int Cin_s, int rows, int Kpad, int korder) {
+  // p[row][k(tap, ci)] = w[row][ci][kh][kw] * s
   const long total = (long)rows * Kpad;
   float s = 1.f;
   if (inv_scale_den) s = (inv_scale_num ? *inv_scale_num : 1.f) / *inv_scale_den;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / Kpad), k = (int)(i % Kpad);
-    const int tap = k / Cin_s, ci = k % Cin_s;
+    int tap, ci;
+    k_to_tap_ci(k, Cin_s, KH * KW, korder, tap, ci);
     float v = 0.f;
     if (row < Cout && tap < KH * KW && ci < Cin) v = w[((size_t)row * Cin + ci) * KH * KW + tap] * s;
     p[i] = v;
@@ -364,14 +511,15 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, const float* __rest
 
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale_num,
                                   const float* __restrict__ inv_scale_den, float* __restrict__ p, int Cout, int Cin,
-                                  int KH, int KW, int Cout_s, int rows, int Kpad) {
-  // p[ci][(kh*KW+kw)*Cout_s + co] = w[co][ci][kh][kw] * s      (rows index ci)
+                                  int KH, int KW, int Cout_s, int rows, int Kpad, int korder) {
+  // p[ci][k(tap, co)] = w[co][ci][kh][kw] * s      (rows index ci)
   const long total = (long)rows * Kpad;
   float s = 1.f;
   if (inv_scale_den) s = (inv_scale_num ? *inv_scale_num : 1.f) / *inv_scale_den;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / Kpad), k = (int)(i % Kpad);
-    const int tap = k / Cout_s, co = k % Cout_s;
+    int tap, co;
+    k_to_tap_ci(k, Cout_s, KH * KW, korder, tap, co);
     float v = 0.f;
     if (row < Cin && tap < KH * KW && co < Cout) v = w[((size_t)co * Cin + row) * KH * KW + tap] * s;
     p[i] = v;
@@ -393,20 +541,42 @@ __global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ slab, float
   }
 }
 
-template <int MT, int NT, int WM, int WN, int EPI>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+template <int MT, int NT, int WM, int WN, int EPI, int GEO>
+int launch_conv_geo(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MT, NT, WM, WN, EPI>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MT, NT, WM, WN, EPI, GEO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid(dsee_cdiv(a.M, BM), EPI == EPI_MODULATE ? dsee_cdiv(a.C, BN / 2) : dsee_cdiv(a.Cout, BN));
-  conv_igemm_kernel<MT, NT, WM, WN, EPI><<<grid, 256, lds, st>>>(a);
+  conv_igemm_kernel<MT, NT, WM, WN, EPI, GEO><<<grid, WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
+}
+
+template <int MT, int NT, int WM, int WN, int EPI>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  ConvArgs b = a;
+  bool fast = a.korder == 1;
+  if (fast) {
+    long mn = 0;  // most negative tap shift, in bytes
+    for (int kh = 0; kh < a.KH; kh += (a.KH > 1 ? a.KH - 1 : 1))
+      for (int kw = 0; kw < a.KW; kw += (a.KW > 1 ? a.KW - 1 : 1)) {
+        const long t = ((long)(a.off + kh * a.kdir) * a.Wi + (a.off + kw * a.kdir)) * a.Cin * 4;
+        if (t < mn) mn = t;
+      }
+    b.margin = (int)(-mn);
+    const long bytes = (long)a.N * a.Hi * a.Wi * a.Cin * 4;
+    if (bytes + b.margin + 65536 >= 0xFFFFFFFEL || -mn > (1L << 30)) fast = false;  // 32-bit buffer offsets
+  }
+  if (!fast && a.korder == 1) {
+    dsee_set_error("conv: tensor too large for 32-bit buffer addressing with korder=1 (pack with korder=0)");
+    return DSEE_EUNSUPPORTED;
+  }
+  return fast ? launch_conv_geo<MT, NT, WM, WN, EPI, 1>(b, st) : launch_conv_geo<MT, NT, WM, WN, EPI, 0>(b, st);
 }
 
 int fill_geom(ConvArgs& a, const dsee_conv_geom* g) {
@@ -416,7 +586,8 @@ int fill_geom(ConvArgs& a, const dsee_conv_geom* g) {
   DSEE_CHECK_ARG(g->dshift >= 0 && g->dshift <= 3 && g->ups >= 0 && g->ups <= 3);
   a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.Cin = g->Cin; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
   a.KH = g->KH; a.KW = g->KW; a.Ktot = g->KH * g->KW * g->Cin; a.Kpad = (a.Ktot + 31) / 32 * 32;
-  a.mul = g->mul; a.off = g->off; a.kdir = g->kdir; a.dshift = g->dshift; a.ups = g->ups;
+  a.mul = g->mul; a.off = g->off; a.kdir = g->kdir; a.dshift = g->dshift; a.ups = g->ups; a.korder = g->korder;
+  DSEE_CHECK_ARG(g->korder == 0 || (g->korder == 1 && g->dshift == 0 && g->ups == 0 && g->Cin % 32 == 0 && g->KH * g->KW <= 32));
   long M = (long)g->N * g->Ho * g->Wo;
   DSEE_CHECK_ARG(M < (1L << 31) && (long)g->N * g->Hi * g->Wi * g->Cin < (1L << 40));
   a.M = (int)M;
@@ -431,23 +602,25 @@ int dsee_conv_kpad(int KH, int KW, int Cin_stored) { return (KH * KW * Cin_store
 int dsee_conv_wrows(int Cout) { return (Cout + 127) / 128 * 128; }
 
 int dsee_pack_weight_fwd(const float* w_oihw, const float* scale_num, const float* scale_den, float* packed, int Cout,
-                         int Cin, int KH, int KW, int Cin_stored, hipStream_t st) {
+                         int Cin, int KH, int KW, int Cin_stored, int korder, hipStream_t st) {
   DSEE_CHECK_ARG(w_oihw && packed && Cin_stored >= Cin && Cin_stored % 4 == 0);
+  DSEE_CHECK_ARG(korder == 0 || (korder == 1 && Cin_stored % 32 == 0));
   const int rows = dsee_conv_wrows(Cout), Kpad = dsee_conv_kpad(KH, KW, Cin_stored);
   const long total = (long)rows * Kpad;
   pack_fwd_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(w_oihw, scale_num, scale_den, packed, Cout, Cin,
-                                                                        KH, KW, Cin_stored, rows, Kpad);
+                                                                        KH, KW, Cin_stored, rows, Kpad, korder);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
 int dsee_pack_weight_dgrad(const float* w_oihw, const float* scale_num, const float* scale_den, float* packed,
-                           int Cout, int Cin, int KH, int KW, int Cout_stored, hipStream_t st) {
+                           int Cout, int Cin, int KH, int KW, int Cout_stored, int korder, hipStream_t st) {
   DSEE_CHECK_ARG(w_oihw && packed && Cout_stored >= Cout && Cout_stored % 4 == 0);
+  DSEE_CHECK_ARG(korder == 0 || (korder == 1 && Cout_stored % 32 == 0));
   const int rows = dsee_conv_wrows(Cin), Kpad = dsee_conv_kpad(KH, KW, Cout_stored);
   const long total = (long)rows * Kpad;
   pack_dgrad_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(w_oihw, scale_num, scale_den, packed, Cout,
-                                                                          Cin, KH, KW, Cout_stored, rows, Kpad);
+                                                                          Cin, KH, KW, Cout_stored, rows, Kpad, korder);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

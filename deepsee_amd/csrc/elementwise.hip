@@ -73,12 +73,20 @@ __global__ __launch_bounds__(256) void chdot_partial_kernel(const float* __restr
   }
 }
 
-__global__ void chdot_finalize_kernel(const float* __restrict__ part, int parts, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void chdot_finalize_kernel(const float* __restrict__ part, int parts, int C,
+                                                             float* __restrict__ out) {
+  __shared__ float sv[8][32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float v = 0.f;
-  for (int p = 0; p < parts; ++p) v += part[(size_t)p * C + c];
-  out[c] = v;
+  if (c < C)
+    for (int p = lane; p < parts; p += 8) v += part[(size_t)p * C + c];
+  sv[lane][cl] = v;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    for (int l = 1; l < 8; ++l) v += sv[l][cl];
+    out[c] = v;
+  }
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -401,7 +409,7 @@ int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, 
   const int parts = (int)((M + cp - 1) / cp);
   chdot_partial_kernel<<<parts, 256, 0, st>>>(a, b, workspace, M, C, (int)cp);
   DSEE_LAUNCH_CHECK();
-  chdot_finalize_kernel<<<dsee_cdiv(C, 256), 256, 0, st>>>(workspace, parts, C, out);
+  chdot_finalize_kernel<<<dsee_cdiv(C, 32), 256, 0, st>>>(workspace, parts, C, out);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -74,20 +74,39 @@ __global__ __launch_bounds__(256) void onehot_conv_wgrad_kernel(const uint8_t* _
   const long M = (long)N * R * Rw;
   const long m0 = (long)blockIdx.x * chunk_px, m1 = min(M, m0 + chunk_px);
   const int t0 = tg == 0 ? 0 : 5, t1 = tg == 0 ? 5 : 9;
-  for (long m = m0; m < m1; ++m) {
-    const size_t o = (size_t)m * ld + coff + c;
-    const float g = act[o] > 0.f ? dact[o] : 0.f;
-    const int w = (int)(m % Rw);
-    const long t = m / Rw;
-    const int h = (int)(t % R), n = (int)(t / R);
-    for (int tap = t0; tap < t1; ++tap) {
-      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
-      if (hh >= 0 && hh < R && ww >= 0 && ww < Rw) {
-        const int r = lab_at(lab, n, H, W, shift, hh, ww);
-        accs[(tap * L + r) * 128 + c] += g;
+  // 8 pixels per trip: the global loads of a trip are issued together (the loop is latency-bound otherwise) and
+  // the LDS updates are fire-and-forget ds_add_f32 (each address is owned by exactly one thread, program order kept)
+  constexpr int U = 8;
+  for (long mb = m0; mb < m1; mb += U) {
+    float gv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const long m = mb + j;
+      float g = 0.f;
+      if (m < m1) {
+        const size_t o = (size_t)m * ld + coff + c;
+        g = act[o] > 0.f ? dact[o] : 0.f;
       }
+      gv[j] = g;
     }
-    if (tg == 0) accs[(9 * L) * 128 + c] += g;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const long m = mb + j;
+      if (m >= m1) break;
+      const float g = gv[j];
+      const int w = (int)(m % Rw);
+      const long t = m / Rw;
+      const int h = (int)(t % R), n = (int)(t / R);
+      for (int tap = t0; tap < t1; ++tap) {
+        const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+        if (hh >= 0 && hh < R && ww >= 0 && ww < Rw) {
+          const int r = lab_at(lab, n, H, W, shift, hh, ww);
+          __hip_atomic_fetch_add(&accs[(tap * L + r) * 128 + c], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      if (tg == 0)
+        __hip_atomic_fetch_add(&accs[(9 * L) * 128 + c], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   __syncthreads();
   float* o = part + (size_t)blockIdx.x * rows * 128;

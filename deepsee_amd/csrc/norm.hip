@@ -85,22 +85,41 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restr
   }
 }
 
-__global__ void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_out,
-                                      float* __restrict__ invstd_out, float* __restrict__ run_mean,
-                                      float* __restrict__ run_var, RedGeom g, float eps, float momentum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= g.groups * g.C) return;
-  const int grp = i / g.C, c = i % g.C;
-  // Chan's parallel merge, chunks in index order
+// block = 32 channels x 8 chunk-lanes: lane l merges chunks l, l+8, ... (Chan's parallel update), lane 0 then merges
+// the 8 partial triples in lane order -> fixed order, bit-reproducible.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part,
+                                                             float* __restrict__ mean_out,
+                                                             float* __restrict__ invstd_out,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                             RedGeom g, float eps, float momentum) {
+  __shared__ float sn[8][32], sm[8][32], s2[8][32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
+  const bool ok = i < g.groups * g.C;
+  const int grp = ok ? i / g.C : 0, c = ok ? i % g.C : 0;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int k = 0; k < g.chunks; ++k) {
-    const int p0 = k * g.chunk_px, p1 = min(g.P, p0 + g.chunk_px);
-    const float nb = (float)(p1 - p0);
-    const float mb = part[((size_t)(grp * g.chunks + k) * 2) * g.C + c];
-    const float m2b = part[((size_t)(grp * g.chunks + k) * 2 + 1) * g.C + c];
-    const float d = mb - mean, nt = n + nb;
+  if (ok)
+    for (int k = lane; k < g.chunks; k += 8) {
+      const int p0 = k * g.chunk_px, p1 = min(g.P, p0 + g.chunk_px);
+      const float nb = (float)(p1 - p0);
+      const float mb = part[((size_t)(grp * g.chunks + k) * 2) * g.C + c];
+      const float m2b = part[((size_t)(grp * g.chunks + k) * 2 + 1) * g.C + c];
+      const float d = mb - mean, nt = n + nb;
+      mean += d * nb / nt;
+      m2 += m2b + d * d * n * nb / nt;
+      n = nt;
+    }
+  sn[lane][cl] = n;
+  sm[lane][cl] = mean;
+  s2[lane][cl] = m2;
+  __syncthreads();
+  if (lane != 0 || !ok) return;
+  for (int l = 1; l < 8; ++l) {
+    const float nb = sn[l][cl];
+    if (nb == 0.f) continue;
+    const float d = sm[l][cl] - mean, nt = n + nb;
     mean += d * nb / nt;
-    m2 += m2b + d * d * n * nb / nt;
+    m2 += s2[l][cl] + d * d * n * nb / nt;
     n = nt;
   }
   const float var = m2 / n;  // biased
@@ -199,14 +218,24 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
   }
 }
 
-__global__ void sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums, int K, RedGeom g) {
-  // sums[k][grp][c] = sum over chunks (index order)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K * g.groups * g.C) return;
-  const int c = i % g.C, grp = (i / g.C) % g.groups, k = i / (g.C * g.groups);
+__global__ __launch_bounds__(256) void sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums,
+                                                            int K, RedGeom g) {
+  // sums[k][grp][c] = sum over chunks; 32 outputs x 8 chunk-lanes per block, lanes folded in order
+  __shared__ float sv[8][32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
+  const bool ok = i < K * g.groups * g.C;
   float v = 0.f;
-  for (int ch = 0; ch < g.chunks; ++ch) v += part[((size_t)(grp * g.chunks + ch) * K + k) * g.C + c];
-  sums[i] = v;
+  if (ok) {
+    const int c = i % g.C, grp = (i / g.C) % g.groups, k = i / (g.C * g.groups);
+    for (int ch = lane; ch < g.chunks; ch += 8) v += part[((size_t)(grp * g.chunks + ch) * K + k) * g.C + c];
+  }
+  sv[lane][cl] = v;
+  __syncthreads();
+  if (lane == 0 && ok) {
+    for (int l = 1; l < 8; ++l) v += sv[l][cl];
+    sums[i] = v;
+  }
 }
 
 // ---- backward, pass 2: dx = invstd * (d - S0/M - xhat * S1/M) [+ add]
@@ -261,8 +290,8 @@ int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps,
   RedGeom g = make_geom(N, HW, C, groups);
   stats_partial_kernel<<<dim3(g.chunks, g.groups), 256, 0, st>>>(x, workspace, g);
   DSEE_LAUNCH_CHECK();
-  stats_finalize_kernel<<<dsee_cdiv((long)g.groups * C, 256), 256, 0, st>>>(workspace, mean, invstd, running_mean,
-                                                                            running_var, g, eps, momentum);
+  stats_finalize_kernel<<<dsee_cdiv((long)g.groups * C, 32), 256, 0, st>>>(workspace, mean, invstd, running_mean,
+                                                                           running_var, g, eps, momentum);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -296,7 +325,7 @@ int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const flo
   norm_bwd_reduce_kernel<0><<<dim3(g.chunks, g.groups), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, nullptr, 0,
                                                                        workspace, g, act, slope);
   DSEE_LAUNCH_CHECK();
-  sums_finalize_kernel<<<dsee_cdiv((long)2 * g.groups * C, 256), 256, 0, st>>>(workspace, sums, 2, g);
+  sums_finalize_kernel<<<dsee_cdiv((long)2 * g.groups * C, 32), 256, 0, st>>>(workspace, sums, 2, g);
   DSEE_LAUNCH_CHECK();
   const long total4 = (long)N * HW * C / 4;
   norm_bwd_apply_kernel<0><<<grid_for(total4), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, sums, nullptr, dx, total4,
@@ -320,7 +349,7 @@ int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const flo
   norm_bwd_reduce_kernel<1><<<dim3(g.chunks, 1), 256, 0, st>>>(dh, h, x, scale, mean, invstd, dgb, dgb_ld, workspace, g,
                                                                 DSEE_ACT_LRELU, slope);
   DSEE_LAUNCH_CHECK();
-  sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 256), 256, 0, st>>>(workspace, sums, 4, g);
+  sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 32), 256, 0, st>>>(workspace, sums, 4, g);
   DSEE_LAUNCH_CHECK();
   (void)hipMemcpyAsync(col_sums, sums + 2 * C, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, st);
   const long total4 = (long)N * HW * C / 4;

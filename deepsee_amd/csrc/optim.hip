@@ -19,14 +19,21 @@ __device__ __forceinline__ float block_sum256(float v) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// t[j] = sum_i W[i][j] * u[i]      (W [R][K] row-major); one thread per column, coalesced over j
-__global__ void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t, int R,
-                               int K) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
+// t[j] = sum_i W[i][j] * u[i]      (W [R][K] row-major); block = 32 columns x 8 row-lanes, coalesced over j
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                      float* __restrict__ t, int R, int K) {
+  __shared__ float sv[8][32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl;
   float acc = 0.f;
-  for (int i = 0; i < R; ++i) acc += W[(size_t)i * K + j] * u[i];
-  t[j] = acc;
+  if (j < K)
+    for (int i = lane; i < R; i += 8) acc += W[(size_t)i * K + j] * u[i];
+  sv[lane][cl] = acc;
+  __syncthreads();
+  if (lane == 0 && j < K) {
+    for (int l = 1; l < 8; ++l) acc += sv[l][cl];
+    t[j] = acc;
+  }
 }
 
 // s[i] = sum_j W[i][j] * v[j]; one block per row
@@ -105,7 +112,7 @@ int dsee_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* sigma
   float* tK = scratch;
   float* tR = scratch + K;
   if (power_iter) {
-    sn_wt_u_kernel<<<dsee_cdiv(K, 256), 256, 0, st>>>(w_orig, u, tK, R, K);
+    sn_wt_u_kernel<<<dsee_cdiv(K, 32), 256, 0, st>>>(w_orig, u, tK, R, K);
     sn_normalize_kernel<<<1, 256, 0, st>>>(tK, v, K, eps);
     sn_w_v_kernel<<<R, 256, 0, st>>>(w_orig, v, tR, K);
     sn_normalize_kernel<<<1, 256, 0, st>>>(tR, u, R, eps);

@@ -10,14 +10,14 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeepsee_hip.so")
+LIB_PATH = os.environ.get("DSEE_LIB") or os.path.join(_HERE, "libdeepsee_hip.so")  # DSEE_LIB: kernel experiments only
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
 
 class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("N", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "mul", "off", "kdir", "dshift", "ups")]
+                ("N", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "mul", "off", "kdir", "dshift", "ups", "korder")]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)
@@ -91,12 +91,14 @@ def geom_fwd(n, hi, wi, cin_s, cout_s, k, stride, pad, ups=0):
     hl, wl = hi << ups, wi << ups
     ho = (hl + 2 * pad - k) // stride + 1
     wo = (wl + 2 * pad - k) // stride + 1
-    return ConvGeom(n, hi, wi, cin_s, ho, wo, cout_s, k, k, stride, -pad, 1, 0, ups)
+    korder = 1 if (ups == 0 and cin_s % 32 == 0 and k * k <= 32) else 0
+    return ConvGeom(n, hi, wi, cin_s, ho, wo, cout_s, k, k, stride, -pad, 1, 0, ups, korder)
 
 
 def geom_dgrad(fwd):
     """Data-gradient geometry of a forward conv (at the logical, i.e. possibly upsampled, input resolution)."""
     stride = fwd.mul
     dshift = {1: 0, 2: 1, 4: 2}[stride]
+    korder = 1 if (dshift == 0 and fwd.Cout % 32 == 0 and fwd.KH * fwd.KW <= 32) else 0
     return ConvGeom(fwd.N, fwd.Ho, fwd.Wo, fwd.Cout, fwd.Hi << fwd.ups, fwd.Wi << fwd.ups, fwd.Cin, fwd.KH, fwd.KW,
-                    1, -fwd.off, -1, dshift, 0)
+                    1, -fwd.off, -1, dshift, 0, korder)

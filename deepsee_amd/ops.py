@@ -139,17 +139,17 @@ def rng_fill(shape, seed, offset, normal=True):
 
 
 # ------------------------------------------------------------------------------------ convolution
-def _pack_fwd(w, cin_s):
+def _pack_fwd(w, cin_s, korder):
     co, ci, kh, kw = w.shape
     wp = new(L.wrows(L.pad4(co)), L.kpad(kh, kw, cin_s))
-    L.call("pack_weight_fwd", w, None, None, wp, co, ci, kh, kw, cin_s)
+    L.call("pack_weight_fwd", w, None, None, wp, co, ci, kh, kw, cin_s, korder)
     return wp
 
 
-def _pack_dgrad(w, cout_s):
+def _pack_dgrad(w, cout_s, korder):
     co, ci, kh, kw = w.shape
     wp = new(L.wrows(L.pad4(ci)), L.kpad(kh, kw, cout_s))
-    L.call("pack_weight_dgrad", w, None, None, wp, co, ci, kh, kw, cout_s)
+    L.call("pack_weight_dgrad", w, None, None, wp, co, ci, kh, kw, cout_s, korder)
     return wp
 
 
@@ -190,7 +190,7 @@ class Conv2d(torch.autograd.Function):
         cout_s = L.pad4(co)
         geom = L.geom_fwd(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
         w = w.contiguous()
-        out = conv_raw(x, _pack_fwd(w, cin_s), geom, pad_vec(bias, cout_s), res, act)
+        out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act)
         ctx.geom, ctx.act, ctx.has_bias, ctx.has_res = geom, act, bias is not None, res is not None
         ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None)
         return out
@@ -209,7 +209,7 @@ class Conv2d(torch.autograd.Function):
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             gd = L.geom_dgrad(geom)
-            dxl = conv_raw(g, _pack_dgrad(w, geom.Cout), gd)
+            dxl = conv_raw(g, _pack_dgrad(w, geom.Cout, gd.korder), gd)
             if geom.ups:
                 dx = torch.empty_like(x)
                 L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
@@ -445,7 +445,7 @@ class SpadeNormAct(torch.autograd.Function):
         assert geom.Ho == h and geom.Wo == w
         w2 = w2.contiguous()
         out, scale = torch.empty_like(x), torch.empty_like(x)
-        wp = _pack_fwd(w2, kin)
+        wp = _pack_fwd(w2, kin, geom.korder)
         with _timed("conv_igemm_128x128_modulate", _flops(geom)):
             L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, b2.contiguous(), x, mean, invstd, out, scale, c,
                    float(add_one), LRELU_SLOPE)
@@ -468,7 +468,7 @@ class SpadeNormAct(torch.autograd.Function):
         dcat = dw2 = db2 = None
         if ctx.needs_input_grad[1]:
             gd = L.geom_dgrad(geom)
-            dcl = conv_raw(dgb, _pack_dgrad(w2, rows), gd)
+            dcl = conv_raw(dgb, _pack_dgrad(w2, rows, gd.korder), gd)
             if geom.ups:
                 dcat = torch.empty_like(cat)
                 L.call("sumpool", dcl, dcat, n, gd.Ho, gd.Wo, kin, geom.ups)

@@ -53,6 +53,9 @@ typedef struct dsee_conv_geom {
   int32_t Ho, Wo, Cout;   /* output        [N][Ho][Wo][Cout], Cout % 4 == 0 */
   int32_t KH, KW;
   int32_t mul, off, kdir, dshift, ups;
+  int32_t korder;         /* K order of the packed weight this conv reads: 0 tap-major k = tap*Cin + c (any geometry);
+                             1 chunk-major k = (c/32)*(taps*32) + tap*32 + c%32 (needs dshift == 0, ups == 0,
+                             Cin % 32 == 0): the 9 taps of a 32-channel chunk are adjacent slabs -> L2 reuse */
 } dsee_conv_geom;
 
 /* packed weight shape helpers: rows = round_up(Cout,128), row length = round_up(KH*KW*Cin_stored,32) */
@@ -62,9 +65,9 @@ int dsee_conv_wrows(int Cout);
 /* OIHW fp32 -> GEMM-B layouts.  Optional device scalars: value multiplied by (*scale_num / *scale_den)
  * (scale_den = sigma of spectral norm: W = W_orig / sigma, torch.nn.utils.spectral_norm). */
 int dsee_pack_weight_fwd(const float* w_oihw, const float* scale_num, const float* scale_den, float* packed, int Cout,
-                         int Cin, int KH, int KW, int Cin_stored, hipStream_t stream);
+                         int Cin, int KH, int KW, int Cin_stored, int korder, hipStream_t stream);
 int dsee_pack_weight_dgrad(const float* w_oihw, const float* scale_num, const float* scale_den, float* packed,
-                           int Cout, int Cin, int KH, int KW, int Cout_stored, hipStream_t stream);
+                           int Cout, int Cin, int KH, int KW, int Cout_stored, int korder, hipStream_t stream);
 
 /* out = act(conv(in, W) + bias + residual).  Replaces nn.Conv2d / F.conv2d (+ the following
  * LeakyReLU/ReLU/tanh and the resblock's `x_s + dx`): architecture.py:98,122,127,146-147; sr.py:65,94-95;

@@ -66,7 +66,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     x_d = nhwc(x).to(dev)
     w_d = w.to(dev)
     wp = torch.empty(L.wrows(cout_s), L.kpad(k, k, cin_s), device=dev)
-    L.call("pack_weight_fwd", w_d, None, None, wp, cout, cin, k, k, cin_s)
+    L.call("pack_weight_fwd", w_d, None, None, wp, cout, cin, k, k, cin_s, geom.korder)
     b_d = None
     if use_bias:
         b_d = torch.zeros(cout_s, device=dev)
@@ -83,7 +83,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     # data gradient (w.r.t. the logical, possibly upsampled, input)
     gd = L.geom_dgrad(geom)
     wd = torch.empty(L.wrows(cin_s), L.kpad(k, k, cout_s), device=dev)
-    L.call("pack_weight_dgrad", w_d, None, None, wd, cout, cin, k, k, cout_s)
+    L.call("pack_weight_dgrad", w_d, None, None, wd, cout, cin, k, k, cout_s, gd.korder)
     gy_d = nhwc(gy).to(dev)
     dx = torch.empty(n, gd.Ho, gd.Wo, cin_s, device=dev)
     L.call("conv2d_fwd", C.byref(gd), gy_d, wd, None, None, dx, 0, 0.0)
