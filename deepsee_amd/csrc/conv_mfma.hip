@@ -359,10 +359,16 @@ struct WgradArgs {
   int KH, KW, Ktot, Kpad;
   int mul, off, kdir, dshift, ups;
   int M, msplit, rows;
+  int margin;  // WGEO 1: bytes the `in` buffer base is moved down (most negative tap shift)
 };
 
 constexpr int WLD = 132;  // padded LDS row for the 32 x 128 wgrad tiles
 
+// WGEO = 1: stride-1 "same" convolution (mul 1, dshift 0, ups 0, Hi == Ho, Wi == Wo): the source pixel of output
+//           pixel m under tap (kh,kw) is m + const, so both operands are read with buffer loads whose per-thread
+//           VGPR offset is fixed for the whole kernel and whose per-slab offset is ONE scalar; out-of-image taps
+//           get the out-of-range offset and come back as zeros.  WGEO = 0: general geometry (two divisions per row).
+template <int WGEO>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   // D[i = cout][j = k'] = sum over pixels.  A'[px][co] = dout tile, B'[px][k'] = shifted input tile.
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -370,7 +376,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   float* Bs = smem + 2 * 32 * WLD;  // [2][32][WLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int kx = blockIdx.x, cy = blockIdx.y, z = blockIdx.z;
+  // XCD-aware order (speed only): all (k', cout) tiles of one pixel split share dout/in slabs -> same XCD, adjacent
+  int kx, cy, z;
+  {
+    const int ntile = gridDim.x * gridDim.y, total = ntile * gridDim.z;
+    const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int t = l % ntile;
+    z = l / ntile;
+    kx = t % gridDim.x;
+    cy = t / gridDim.x;
+  }
   const int chunk = tid & 31, lrow = tid >> 5;  // 8 rows per pass, 4 passes
   const int m0 = z * a.msplit;
   const int m1 = min(a.M, m0 + a.msplit);
@@ -385,38 +402,86 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int Hl = a.Hi << a.ups, Wl = a.Wi << a.ups;
   const int dmask = (1 << a.dshift) - 1;
 
-  f32x4 ra[4], rb[4];
-  auto load_tile = [&](int mb) {
+  // WGEO 1 state: per-row (oh, ow) walked incrementally, fixed VGPR offsets
+  const int dy = a.off + kh * a.kdir, dx = a.off + kw * a.kdir;
+  int r_oh[4], r_ow[4];
+  unsigned va[4], vb[4];
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, 0xFFFFFFFE, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(a.in) - a.margin), 0, 0xFFFFFFFE, 0x00020000);
+  if constexpr (WGEO == 1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int m = mb + lrow + 8 * j;
-      const bool mok = m < m1;
-      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-      if (mok && cok) va = *reinterpret_cast<const f32x4*>(a.dout + (size_t)m * a.Cout + co);
-      if (mok && kok) {
-        const int ow = m % a.Wo;
-        const int t = m / a.Wo;
+      const int m = m0 + lrow + 8 * j;
+      r_ow[j] = m % a.Wo;
+      r_oh[j] = (m / a.Wo) % a.Ho;
+      va[j] = cok ? (unsigned)(((size_t)(lrow + 8 * j) * a.Cout + co) * 4) : 0xFFFFFFFFu;
+      vb[j] = kok ? (unsigned)(((long)(lrow + 8 * j + dy * a.Wi + dx) * a.Cin + cch) * 4 + a.margin) : 0xFFFFFFFFu;
+    }
+  }
+
+  f32x4 ra[4], rb[4];
+  float keep_a[4], keep_b[4];
+  // `live` = false for the branch-free dummy prefetches past the last slab: every row is masked, nothing is read
+  // (the incremental row state has moved past the split by then and must not be used to validate addresses).
+  auto load_tile = [&](int kt, bool live) {
+    const int mb = m0 + kt * 32;
+    if constexpr (WGEO == 1) {
+      const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane((int)(((size_t)mb * a.Cout) * 4));
+      const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)(((size_t)mb * a.Cin) * 4));
+      const int rem = __builtin_amdgcn_readfirstlane(live ? m1 - mb : 0);  // rows of this slab that exist
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool mok = lrow + 8 * j < rem;
+        const int ph = r_oh[j] + dy, pw = r_ow[j] + dx;
+        const bool ok = mok && ph >= 0 && ph < a.Hi && pw >= 0 && pw < a.Wi;
+        ra[j] = __builtin_bit_cast(f32x4,
+                                   __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, mok ? va[j] : 0xFFFFFFFFu, sa, 0));
+        rb[j] = __builtin_bit_cast(f32x4,
+                                   __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ok ? vb[j] : 0xFFFFFFFFu, sb, 0));
+        // advance the row by 32 pixels (Wo >= 32 guaranteed by the dispatcher -> at most one wrap)
+        int ow = r_ow[j] + 32;
+        const int wrap = ow >= a.Wo;
+        ow -= wrap ? a.Wo : 0;
+        int oh = r_oh[j] + wrap;
+        oh = oh == a.Ho ? 0 : oh;
+        r_ow[j] = ow;
+        r_oh[j] = oh;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mb + lrow + 8 * j;
+        const bool mok = live && m < m1;
+        const int mm = mok ? m : 0;
+        const int ow = mm % a.Wo;
+        const int t = mm / a.Wo;
         const int oh = t % a.Ho;
         const int n = t / a.Ho;
         int ph = oh * a.mul + a.off + kh * a.kdir;
         int pw = ow * a.mul + a.off + kw * a.kdir;
-        bool ok = ph >= 0 && pw >= 0 && ((ph | pw) & dmask) == 0;
+        bool ok = mok && kok && ph >= 0 && pw >= 0 && ((ph | pw) & dmask) == 0;
         ph >>= a.dshift;
         pw >>= a.dshift;
         ok = ok && ph < Hl && pw < Wl;
         ph >>= a.ups;
         pw >>= a.ups;
-        if (ok) vb = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(n * a.Hi + ph) * a.Wi + pw) * a.Cin + cch);
+        const bool oka = mok && cok;
+        ra[j] = *reinterpret_cast<const f32x4*>(a.dout + (oka ? (size_t)m * a.Cout + co : 0));
+        rb[j] = *reinterpret_cast<const f32x4*>(a.in + (ok ? ((size_t)(n * a.Hi + ph) * a.Wi + pw) * a.Cin + cch : 0));
+        keep_a[j] = oka ? 1.f : 0.f;
+        keep_b[j] = ok ? 1.f : 0.f;
       }
-      ra[j] = va;
-      rb[j] = vb;
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<f32x4*>(As + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) = ra[j];
-      *reinterpret_cast<f32x4*>(Bs + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) = rb[j];
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(As + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) =
+          (WGEO == 1 || keep_a[j] != 0.f) ? ra[j] : z4;
+      *reinterpret_cast<f32x4*>(Bs + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) =
+          (WGEO == 1 || keep_b[j] != 0.f) ? rb[j] : z4;
     }
   };
 
@@ -429,19 +494,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
 
   const int nk = (m1 - m0 + 31) / 32;
-  if (nk > 0) {
-    load_tile(m0);
-    store_tile(0);
-  }
-  __syncthreads();
-  int cur = 0;
   const int fcol = lane & 31, fk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(m0 + (kt + 1) * 32);
-    const float* Ac = As + cur * 32 * WLD + wm * 64 + fcol;
-    const float* Bc = Bs + cur * 32 * WLD + wn * 64 + fcol;
+  auto mma_steps = [&](int buf, int k0, int k1) {
+    const float* Ac = As + buf * 32 * WLD + wm * 64 + fcol;
+    const float* Bc = Bs + buf * 32 * WLD + wn * 64 + fcol;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
+    for (int kk = k0; kk < k1; ++kk) {
       const int k = kk * 2 + fk;
       const float a0 = Ac[k * WLD], a1 = Ac[k * WLD + 32];
       const float b0 = Bc[k * WLD], b1 = Bc[k * WLD + 32];
@@ -450,7 +508,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       part[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, part[1][0], 0, 0, 0);
       part[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, part[1][1], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+  };
+  if (nk > 0) {
+    load_tile(0, true);
+    store_tile(0);
+  }
+  __syncthreads();
+  if (nk > 0) load_tile(min(1, nk - 1), nk > 1);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    mma_steps(cur, 0, 12);
+    __builtin_amdgcn_sched_barrier(0);  // slab kt+1 was requested a full slab ago; its first use stays below
+    mma_steps(cur, 12, 16);
+    store_tile(cur ^ 1);
+    __syncthreads();
+    load_tile(min(kt + 2, nk - 1), kt + 2 < nk);  // next prefetch right after the barrier (branch-free)
     if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -461,7 +533,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
           for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
         }
     }
-    __syncthreads();
     cur ^= 1;
   }
   float* slab = a.slab + (size_t)z * a.rows * a.Kpad;
@@ -689,11 +760,27 @@ int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dou
   const size_t lds = (size_t)4 * 32 * WLD * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  conv_wgrad_kernel<<<dim3(tx, ty, S), 256, lds, st>>>(a);
+  // fast path: stride-1 "same" conv, rows at least 32 wide, everything addressable with 32-bit byte offsets
+  const long in_bytes = (long)a.N * a.Hi * a.Wi * a.Cin * 4, out_bytes = (long)a.M * a.Cout * 4;
+  long mn = 0;
+  for (int kh = 0; kh < a.KH; kh += (a.KH > 1 ? a.KH - 1 : 1))
+    for (int kw = 0; kw < a.KW; kw += (a.KW > 1 ? a.KW - 1 : 1)) {
+      const long t = ((long)(a.off + kh * a.kdir) * a.Wi + (a.off + kw * a.kdir)) * a.Cin * 4;
+      if (t < mn) mn = t;
+    }
+  a.margin = (int)(-mn);
+  const bool fast = a.mul == 1 && a.dshift == 0 && a.ups == 0 && a.Hi == a.Ho && a.Wi == a.Wo && a.Wo >= 32 &&
+                    in_bytes + a.margin + 65536 < 0xFFFFFFFEL && out_bytes + 65536 < 0xFFFFFFFEL && -mn < (1L << 30);
+  if (fast)
+    conv_wgrad_kernel<1><<<dim3(tx, ty, S), 256, lds, st>>>(a);
+  else
+    conv_wgrad_kernel<0><<<dim3(tx, ty, S), 256, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   const long total = (long)Cout_real * Cin_real * a.KH * a.KW;
   wgrad_reduce_unpack_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(

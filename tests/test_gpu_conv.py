@@ -37,6 +37,11 @@ CASES = [
     (1, 256, 1, 10, 4, 1, 2, 0, 0, True, False),      # Cout=1
     (2, 32, 64, 16, 3, 2, 1, 0, 1, False, False),     # encoder stride-2
     (1, 512, 512, 8, 3, 1, 1, 0, 0, True, True),
+    (2, 32, 64, 40, 3, 1, 1, 0, 0, True, False),      # W >= 32: wgrad fast path (buffer loads, incremental rows)
+    (1, 64, 160, 64, 3, 1, 1, 0, 1, False, False),    # W = 64, ragged Cout tile
+    (3, 128, 128, 32, 3, 1, 1, 0, 0, True, True),
+    (6, 128, 128, 64, 3, 1, 1, 0, 0, False, False),   # regression: 24 pixel splits; the dummy prefetch past the last
+                                                      # slab once read beyond the end of `in` (fault at x_end + 16 KB)
 ]
 
 
