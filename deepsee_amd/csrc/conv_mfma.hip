@@ -38,6 +38,11 @@ struct ConvArgs {
   int KH, KW, Ktot, Kpad;
   int mul, off, kdir, dshift, ups, korder;
   int margin;  // GEO 1: bytes the A buffer base is moved down so that every tap's scalar offset is >= 0
+  // SEAN style as a per-image table (GEO 1 only): K slabs kt >= nk_shared read their B rows from
+  // wt[n_img][kt - nk_shared][row][32] instead of the shared packed weight (n_img = image of this M tile)
+  const float* wt;
+  int nk_shared, wt_rows;
+  int wstride;  // row length (floats) of the shared packed weight (== Kpad unless a table supplies the K tail)
   int act;
   float slope;
   int M;
@@ -120,30 +125,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_ige
   unsigned b_voff[B_CH];
 #pragma unroll
   for (int j = 0; j < B_CH; ++j) {
-    wrow[j] = a.w + (size_t)(bn * BN + lrow + RPP * j) * a.Kpad + chunk * 4;
-    b_voff[j] = (unsigned)(((size_t)(lrow + RPP * j) * a.Kpad + chunk * 4) * 4);
+    wrow[j] = a.w + (size_t)(bn * BN + lrow + RPP * j) * a.wstride + chunk * 4;
+    b_voff[j] = (unsigned)(((size_t)(lrow + RPP * j) * a.wstride + chunk * 4) * 4);
   }
   __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(a.in) - a.margin), 0, 0xFFFFFFFE, 0x00020000);
   __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.w + (size_t)bn * BN * a.Kpad), 0, 0xFFFFFFFE, 0x00020000);
+      (void*)(a.w + (size_t)bn * BN * a.wstride), 0, 0xFFFFFFFE, 0x00020000);
+  // per-image table rows are 32 floats long; this block's rows start at bn*BN
+  __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((a.wt ? a.wt : a.w) + (size_t)bn * BN * BK), 0, 0xFFFFFFFE, 0x00020000);
+  unsigned t_voff[B_CH];
+#pragma unroll
+  for (int j = 0; j < B_CH; ++j) t_voff[j] = (unsigned)(((lrow + RPP * j) * BK + chunk * 4) * 4);
+  const int n_img = (bm * BM) / (a.Ho * a.Wo);  // only meaningful (and only used) when a.wt != nullptr
+  const int nk = a.Kpad / BK;
 
   // Loads are unconditional (masked rows read element 0 of the tensor); the zero fill is applied when the slab
   // is written to LDS, so nothing in the load section depends on a load result.
   f32x4 ra[A_CH], rb[B_CH];
   float ra_keep[A_CH];
   auto load_tile = [&](int kt) {
-#if defined(DSEE_ABL) && DSEE_ABL == 7
-    // ablation: same number of loads, trivial addressing (wrong data)
-#pragma unroll
-    for (int j = 0; j < A_CH; ++j) {
-      ra[j] = *reinterpret_cast<const f32x4*>(a.in + (size_t)(lrow + 32 * j) * a.Cin + chunk * 4 + (size_t)kt * BK);
-      ra_keep[j] = 1.f;
-    }
-#pragma unroll
-    for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
-    return;
-#endif
     if constexpr (GEO == 1) {
       const int s_tap = __builtin_amdgcn_readfirstlane(g_tap);
       const bool kok = __builtin_amdgcn_readfirstlane(g_cc) * BK < a.Cin;
@@ -152,23 +154,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_ige
 #pragma unroll
       for (int j = 0; j < A_CH; ++j) {
         const bool ok = kok && ((a_mask[j] >> s_tap) & 1u);
-#if defined(DSEE_ABL) && DSEE_ABL == 9
-        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                              rsrc_a, ok ? (unsigned)((lrow + RPP * j) * 512 + chunk * 16) : 0xFFFFFFFFu,
-                                              (unsigned)a.margin, 0));
-#else
         ra[j] = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[j] : 0xFFFFFFFFu, soff, 0));
-#endif
       }
-#if defined(DSEE_ABL) && DSEE_ABL == 8
-      const unsigned soff_b = 0;
-#else
-      const unsigned soff_b = (unsigned)__builtin_amdgcn_readfirstlane(kt * (BK * 4));
-#endif
+      const bool sty = a.wt != nullptr && kt >= a.nk_shared;  // block-uniform
+      const unsigned soff_b = (unsigned)__builtin_amdgcn_readfirstlane(
+          sty ? ((n_img * (nk - a.nk_shared) + (kt - a.nk_shared)) * a.wt_rows) * (BK * 4) : kt * (BK * 4));
 #pragma unroll
       for (int j = 0; j < B_CH; ++j)
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], soff_b, 0));
+        rb[j] = __builtin_bit_cast(f32x4, sty ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, t_voff[j], soff_b, 0)
+                                              : __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], soff_b, 0));
       // advance to the next slab (scalar selects only): next tap, then next channel chunk
       g_tap += 1;
       g_kw += 1;
@@ -205,7 +200,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_ige
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
   };
-  const int nk = a.Kpad / BK;
   auto store_tile = [&](int buf) {
     float* Ab = As + buf * BM * LDK;
     float* Bb = Bs + buf * BN * LDK;
@@ -242,9 +236,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_ige
   // fragments of slab kt+1 come back from LDS, instead of leaving the matrix pipe empty for barrier + ds_read latency.
   f32x4 af[2][MT], bf[2][NT];
   auto read_frags = [&](int buf, int kk, int set) {
-#if defined(DSEE_ABL) && DSEE_ABL >= 4
-    if (kk >= 0) return;
-#endif
     const float* Ac = As + buf * BM * LDK + a_frag + kk * 8;
     const float* Bc = Bs + buf * BN * LDK + b_frag + kk * 8;
 #pragma unroll
@@ -271,23 +262,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_ige
     read_frags(cur, 3, 1);
     mma_group(0);
     __builtin_amdgcn_sched_barrier(0);  // first use of slab kt+1's loads (issued one whole slab = 4096 MFMA cycles ago)
-#if !defined(DSEE_ABL) || DSEE_ABL < 1 || DSEE_ABL == 6
     store_tile(cur ^ 1);
-#elif DSEE_ABL == 5
-#pragma unroll
-    for (int j = 0; j < A_CH; ++j) asm volatile("" ::"v"(ra[j]), "v"(ra_keep[j]));
-#pragma unroll
-    for (int j = 0; j < B_CH; ++j) asm volatile("" ::"v"(rb[j]));
-#endif
-#if !defined(DSEE_ABL) || DSEE_ABL < 3
     __syncthreads();
-#endif
     read_frags(cur ^ 1, 0, 0);          // next slab's first fragments ...
     // ... and the global loads of slab kt+2 into the staging registers that were just drained: both issue under the
     // last MFMA group of this slab.  Branch-free: past the end the final slab is simply fetched again.
-#if !defined(DSEE_ABL) || DSEE_ABL < 2 || DSEE_ABL == 5
     load_tile(min(kt + 2, nk - 1));
-#endif
     mma_group(1);
     __builtin_amdgcn_sched_barrier(0);
     if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
@@ -359,6 +339,7 @@ struct WgradArgs {
   int KH, KW, Ktot, Kpad;
   int mul, off, kdir, dshift, ups;
   int M, msplit, rows;
+  int korder, Kuse;  // slab column order; number of slab columns actually computed (<= Ktot)
   int margin;  // WGEO 1: bytes the `in` buffer base is moved down (most negative tap shift)
 };
 
@@ -392,10 +373,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int m0 = z * a.msplit;
   const int m1 = min(a.M, m0 + a.msplit);
   // B' column (k') owned by this thread is fixed for the whole kernel
+  // (korder 1: chunk-major k' = (ci/32)*(taps*32) + tap*32 + ci%32, so that "only the first Kuse columns" means
+  //  "only the first Kuse/(taps*32) channel chunks" — the one-hot tail of the SEAN input needs no shared gradient)
   const int kq = kx * 128 + chunk * 4;
-  const bool kok = kq < a.Ktot;
-  const int tap = kok ? kq / a.Cin : 0;
-  const int cch = kq - tap * a.Cin;
+  const bool kok = kq < a.Kuse;
+  int tap = 0, cch = 0;
+  if (kok) {
+    if (a.korder == 0) {
+      tap = kq / a.Cin;
+      cch = kq - tap * a.Cin;
+    } else {
+      const int span = a.KH * a.KW * 32, cc = kq / span, rem = kq - cc * span;
+      tap = rem >> 5;
+      cch = cc * 32 + (rem & 31);
+    }
+  }
   const int kh = tap / a.KW, kw = tap - kh * a.KW;
   const int co = cy * 128 + chunk * 4;
   const bool cok = co < a.Cout;
@@ -539,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = kx * 128 + wn * 64 + j * 32 + (lane & 31);
-    if (col >= a.Kpad) continue;
+    if (col >= a.Kuse) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -598,17 +590,37 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
 }
 
 __global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int rows,
-                                           int Kpad, int Cout, int Cin, int KH, int KW, int Cin_s) {
-  // dw[co][ci][kh][kw] = sum_s slab[s][co][(kh*KW+kw)*Cin_s + ci]   (fixed order => deterministic)
+                                           int Kpad, int Cout, int Cin, int KH, int KW, int Cin_s, int korder) {
+  // dw[co][ci][kh][kw] = sum_s slab[s][co][k'(tap, ci)]   (fixed order => deterministic)
   const long total = (long)Cout * Cin * KH * KW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int tap = (int)(i % (KH * KW));
     const long t = i / (KH * KW);
     const int ci = (int)(t % Cin), co = (int)(t / Cin);
-    const size_t o = (size_t)co * Kpad + (size_t)tap * Cin_s + ci;
+    const size_t kcol = korder == 0 ? (size_t)tap * Cin_s + ci
+                                    : (size_t)(ci >> 5) * (KH * KW * 32) + (size_t)tap * 32 + (ci & 31);
+    const size_t o = (size_t)co * Kpad + kcol;
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += slab[(size_t)s * rows * Kpad + o];
     dw[i] = v;
+  }
+}
+
+// dT[n][tap][row][r] = sum_{j < s} slab[n*s + j][row][k0 + tap*32 + r]   (per-image style-table gradient)
+__global__ void wgrad_table_unpack_kernel(const float* __restrict__ slab, float* __restrict__ dt, int N, int sper,
+                                          int rows, int Kpad, int k0, int ntaps, int L) {
+  const long total = (long)N * ntaps * rows * 32;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i & 31);
+    long t = i >> 5;
+    const int row = (int)(t % rows);
+    t /= rows;
+    const int tap = (int)(t % ntaps), n = (int)(t / ntaps);
+    float v = 0.f;
+    if (r < L)
+      for (int j = 0; j < sper; ++j)
+        v += slab[((size_t)(n * sper + j) * rows + row) * Kpad + k0 + tap * 32 + r];
+    dt[i] = v;
   }
 }
 
@@ -658,6 +670,7 @@ int fill_geom(ConvArgs& a, const dsee_conv_geom* g) {
   a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.Cin = g->Cin; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
   a.KH = g->KH; a.KW = g->KW; a.Ktot = g->KH * g->KW * g->Cin; a.Kpad = (a.Ktot + 31) / 32 * 32;
   a.mul = g->mul; a.off = g->off; a.kdir = g->kdir; a.dshift = g->dshift; a.ups = g->ups; a.korder = g->korder;
+  a.wstride = a.Kpad; a.wt = nullptr; a.nk_shared = 0; a.wt_rows = 0;
   DSEE_CHECK_ARG(g->korder == 0 || (g->korder == 1 && g->dshift == 0 && g->ups == 0 && g->Cin % 32 == 0 && g->KH * g->KW <= 32));
   long M = (long)g->N * g->Ho * g->Wo;
   DSEE_CHECK_ARG(M < (1L << 31) && (long)g->N * g->Hi * g->Wi * g->Cin < (1L << 40));
@@ -709,15 +722,29 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
 }
 
 int dsee_conv2d_modulate_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed,
-                             const float* bias_packed, const float* x, const float* mean, const float* invstd,
-                             float* out_h, float* out_scale, int C, float add_one, float slope, hipStream_t st) {
+                             const float* style_table, int shared_cin, const float* bias_packed, const float* x,
+                             const float* mean, const float* invstd, float* out_h, float* out_scale, int C,
+                             float add_one, float slope, hipStream_t st) {
   ConvArgs a = {};
   int rc = fill_geom(a, g);
   if (rc) return rc;
-  DSEE_CHECK_ARG(in && w_packed && x && mean && invstd && out_h && out_scale && C > 0);
+  DSEE_CHECK_ARG(in && x && mean && invstd && out_h && out_scale && C > 0);
   DSEE_CHECK_ARG(g->Cout >= (C + 63) / 64 * 128);  // packed gamma/beta rows
   a.in = in; a.w = w_packed; a.bias = bias_packed; a.out = out_h; a.mx = x; a.mean = mean; a.invstd = invstd;
   a.scale_out = out_scale; a.add_one = add_one; a.C = C; a.slope = slope;
+  if (style_table) {
+    // the last 32 input channels are the one-hot label (19 padded to 32); their weights are per image
+    DSEE_CHECK_ARG(g->korder == 1 && shared_cin % 32 == 0 && shared_cin + 32 == g->Cin);
+    DSEE_CHECK_ARG((g->Ho * g->Wo) % 128 == 0);  // an M tile must not straddle two images
+    DSEE_CHECK_ARG(shared_cin == 0 || w_packed != nullptr);
+    a.wt = style_table;
+    a.nk_shared = shared_cin / 32 * g->KH * g->KW;
+    a.wt_rows = dsee_conv_wrows(g->Cout);
+    a.wstride = dsee_conv_kpad(g->KH, g->KW, shared_cin);
+    if (!a.w) a.w = style_table;  // never dereferenced when nk_shared == 0
+  } else {
+    DSEE_CHECK_ARG(w_packed != nullptr);
+  }
   return launch_conv<2, 2, 2, 2, EPI_MODULATE>(a, st);
 }
 
@@ -732,7 +759,7 @@ static int wgrad_splits(int M, int tiles) {
 
 size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g) {
   if (!g) return 0;
-  const int Kpad = dsee_conv_kpad(g->KH, g->KW, g->Cin);
+  const int Kpad = dsee_conv_kpad(g->KH, g->KW, g->Cin);  // upper bound for any Cin_real
   const int rows = g->Cout;
   const long M = (long)g->N * g->Ho * g->Wo;
   const int tiles = dsee_cdiv(Kpad, 128) * dsee_cdiv(rows, 128);
@@ -740,23 +767,8 @@ size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g) {
   return (size_t)S * rows * Kpad * sizeof(float);
 }
 
-int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
-                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_real, hipStream_t st) {
-  ConvArgs c = {};
-  int rc = fill_geom(c, g);
-  if (rc) return rc;
-  DSEE_CHECK_ARG(in && dout && workspace && dw_oihw);
-  DSEE_CHECK_ARG(Cout_real <= g->Cout && Cin_real <= g->Cin);
-  DSEE_CHECK_ARG(workspace_bytes >= dsee_conv2d_wgrad_workspace(g));
-  WgradArgs a = {};
-  a.dout = dout; a.in = in; a.slab = workspace;
-  a.N = c.N; a.Hi = c.Hi; a.Wi = c.Wi; a.Cin = c.Cin; a.Ho = c.Ho; a.Wo = c.Wo; a.Cout = c.Cout;
-  a.KH = c.KH; a.KW = c.KW; a.Ktot = c.Ktot; a.Kpad = c.Kpad;
-  a.mul = c.mul; a.off = c.off; a.kdir = c.kdir; a.dshift = c.dshift; a.ups = c.ups;
-  a.M = c.M; a.rows = c.Cout;
-  const int tx = dsee_cdiv(a.Kpad, 128), ty = dsee_cdiv(a.rows, 128);
-  const int S = wgrad_splits(a.M, tx * ty);
-  a.msplit = ((a.M + S - 1) / S + 31) / 32 * 32;
+static int wgrad_launch(WgradArgs& a, int S, hipStream_t st) {
+  const int tx = dsee_cdiv(a.Kuse, 128), ty = dsee_cdiv(a.rows, 128);
   const size_t lds = (size_t)4 * 32 * WLD * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -782,9 +794,86 @@ int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dou
   else
     conv_wgrad_kernel<0><<<dim3(tx, ty, S), 256, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+static void wgrad_fill(WgradArgs& a, const ConvArgs& c, const float* in, const float* dout, float* workspace) {
+  a.dout = dout; a.in = in; a.slab = workspace;
+  a.N = c.N; a.Hi = c.Hi; a.Wi = c.Wi; a.Cin = c.Cin; a.Ho = c.Ho; a.Wo = c.Wo; a.Cout = c.Cout;
+  a.KH = c.KH; a.KW = c.KW; a.Ktot = c.Ktot; a.Kpad = c.Kpad;
+  a.mul = c.mul; a.off = c.off; a.kdir = c.kdir; a.dshift = c.dshift; a.ups = c.ups;
+  a.M = c.M; a.rows = c.Cout;
+}
+
+int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
+                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_real, hipStream_t st) {
+  ConvArgs c = {};
+  int rc = fill_geom(c, g);
+  if (rc) return rc;
+  DSEE_CHECK_ARG(in && dout && workspace && dw_oihw);
+  DSEE_CHECK_ARG(Cout_real <= g->Cout && Cin_real <= g->Cin);
+  DSEE_CHECK_ARG(workspace_bytes >= dsee_conv2d_wgrad_workspace(g));
+  WgradArgs a = {};
+  wgrad_fill(a, c, in, dout, workspace);
+  a.korder = (g->korder == 1 && c.Cin % 32 == 0) ? 1 : 0;
+  a.Kuse = a.korder == 1 ? (Cin_real + 31) / 32 * 32 * a.KH * a.KW : a.Ktot;  // skip trailing channel chunks
+  const int ty = dsee_cdiv(a.rows, 128);
+  const int S = wgrad_splits(a.M, dsee_cdiv(a.Kpad, 128) * ty);  // same split count as the workspace query
+  a.msplit = ((a.M + S - 1) / S + 31) / 32 * 32;
+  rc = wgrad_launch(a, S, st);
+  if (rc) return rc;
   const long total = (long)Cout_real * Cin_real * a.KH * a.KW;
   wgrad_reduce_unpack_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
-      workspace, dw_oihw, S, a.rows, a.Kpad, Cout_real, Cin_real, a.KH, a.KW, a.Cin);
+      workspace, dw_oihw, S, a.rows, a.Kpad, Cout_real, Cin_real, a.KH, a.KW, a.Cin, a.korder);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+// image-aligned split count for the table variant: S = N * sper, each split = P / sper pixels of one image
+static int table_sper(const dsee_conv_geom* g) {
+  const int P = g->Ho * g->Wo;
+  const int tiles = dsee_cdiv(dsee_conv_kpad(g->KH, g->KW, g->Cin), 128) * dsee_cdiv(g->Cout, 128);
+  int want = 2048 / (tiles * g->N > 0 ? tiles * g->N : 1);
+  int sper = 1;
+  while (sper * 2 <= want && P % (sper * 2) == 0 && (P / (sper * 2)) % 32 == 0 && P / (sper * 2) >= 1024) sper *= 2;
+  return sper;
+}
+
+size_t dsee_conv2d_wgrad_table_workspace(const dsee_conv_geom* g) {
+  if (!g) return 0;
+  return (size_t)g->N * table_sper(g) * g->Cout * dsee_conv_kpad(g->KH, g->KW, g->Cin) * sizeof(float);
+}
+
+/* Weight gradient of the SEAN modulate GEMM whose last 32 input channels are the one-hot label with per-image
+ * weights: ONE split-K launch with image-aligned splits; the shared columns (first Cin_shared channels) are summed
+ * over every split into dw_oihw [rows][Cin_shared][3][3] (skipped if NULL / Cin_shared == 0), the one-hot columns
+ * are summed per image into dtable [N][taps][rows][32]. */
+int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
+                            size_t workspace_bytes, float* dw_oihw, int Cin_shared, float* dtable, int L,
+                            hipStream_t st) {
+  ConvArgs c = {};
+  int rc = fill_geom(c, g);
+  if (rc) return rc;
+  DSEE_CHECK_ARG(in && dout && workspace && dtable && g->korder == 1 && Cin_shared + 32 == g->Cin && L <= 32);
+  DSEE_CHECK_ARG((g->Ho * g->Wo) % 32 == 0 && workspace_bytes >= dsee_conv2d_wgrad_table_workspace(g));
+  WgradArgs a = {};
+  wgrad_fill(a, c, in, dout, workspace);
+  a.korder = 1;
+  a.Kuse = a.Ktot;
+  const int sper = table_sper(g), S = g->N * sper;
+  a.msplit = g->Ho * g->Wo / sper;
+  rc = wgrad_launch(a, S, st);
+  if (rc) return rc;
+  const int taps = a.KH * a.KW;
+  if (dw_oihw && Cin_shared > 0) {
+    const long total = (long)a.rows * Cin_shared * taps;
+    wgrad_reduce_unpack_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
+        workspace, dw_oihw, S, a.rows, a.Kpad, a.rows, Cin_shared, a.KH, a.KW, a.Cin, 1);
+    DSEE_LAUNCH_CHECK();
+  }
+  const long tt = (long)g->N * taps * a.rows * 32;
+  wgrad_table_unpack_kernel<<<(int)min(4096L, (tt + 255) / 256), 256, 0, st>>>(
+      workspace, dtable, g->N, sper, a.rows, a.Kpad, Cin_shared / 32 * taps * 32, taps, L);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -62,8 +62,8 @@ __global__ void onehot_pack_kernel(const float* __restrict__ w, float* __restric
 // Weight gradient of the one-hot conv.  Block = 128 channels x 2 tap groups; each thread owns its channel's
 // accumulator column in LDS ([9*L][128] floats), so no atomics and a fixed summation order.
 __global__ __launch_bounds__(256) void onehot_conv_wgrad_kernel(const uint8_t* __restrict__ lab,
-                                                                const float* __restrict__ dact,
-                                                                const float* __restrict__ act, int ld, int coff, int N,
+                                                                const float* __restrict__ dact, int dld,
+                                                                const float* __restrict__ act, int ald, int N,
                                                                 int H, int W, int shift, int R, int Rw, int L,
                                                                 int chunk_px, float* __restrict__ part) {
   extern __shared__ float accs[];  // [9*L + 1][128]   (last row: bias gradient)
@@ -84,8 +84,7 @@ __global__ __launch_bounds__(256) void onehot_conv_wgrad_kernel(const uint8_t* _
       const long m = mb + j;
       float g = 0.f;
       if (m < m1) {
-        const size_t o = (size_t)m * ld + coff + c;
-        g = act[o] > 0.f ? dact[o] : 0.f;
+        g = act[(size_t)m * ald + c] > 0.f ? dact[(size_t)m * dld + c] : 0.f;
       }
       gv[j] = g;
     }
@@ -127,6 +126,24 @@ __global__ void onehot_wgrad_finalize_kernel(const float* __restrict__ part, int
   } else {
     const int tap = row / L, r = row % L;
     dw[((size_t)c * L + r) * 9 + tap] = v;
+  }
+}
+
+// out[m][coff + r] = (lab(m) == r), r in [0,32)
+__global__ __launch_bounds__(256) void label_onehot_kernel(const uint8_t* __restrict__ lab, float* __restrict__ out,
+                                                           int N, int H, int W, int shift, int R, int Rw, int ld,
+                                                           int coff) {
+  const int q = threadIdx.x & 7, s = threadIdx.x >> 3;  // 8 float4 per pixel, 32 pixels per block pass
+  const long M = (long)N * R * Rw;
+  for (long m = (long)blockIdx.x * 32 + s; m < M; m += (long)gridDim.x * 32) {
+    const int w = (int)(m % Rw);
+    const long t = m / Rw;
+    const int h = (int)(t % R), n = (int)(t / R);
+    const int r = lab_at(lab, n, H, W, shift, h, w);
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (q * 4 + k == r) ? 1.f : 0.f;
+    *reinterpret_cast<f32x4*>(out + m * ld + coff + q * 4) = v;
   }
 }
 
@@ -235,8 +252,9 @@ size_t dsee_onehot_conv3x3_wgrad_workspace(int N, int H, int W, int shift, int L
 
 /* dW_sh[:, r, tap] = sum_{p : lab(p+tap)=r} relu'(act[p]) * dact[p]  (SURVEY Appendix E); Co fixed at 128
  * (normalization.py:95 nhidden).  act/dact are [M][ld] with the 128 channels at offset coff. */
-int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, const float* act, int ld, int coff, int N, int H,
-                              int W, int shift, int L, float* dw_oihw, float* dbias, float* workspace, hipStream_t st) {
+int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, int dact_ld, const float* act, int act_ld, int N,
+                              int H, int W, int shift, int L, float* dw_oihw, float* dbias, float* workspace,
+                              hipStream_t st) {
   DSEE_CHECK_ARG(lab && dact && act && dw_oihw && dbias && workspace && L <= 32);
   const int R = H >> shift, Rw = W >> shift;
   const long M = (long)N * R * Rw;
@@ -249,10 +267,21 @@ int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, const float
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  onehot_conv_wgrad_kernel<<<parts, 256, lds, st>>>(lab, dact, act, ld, coff, N, H, W, shift, R, Rw, L, cp, workspace);
+  onehot_conv_wgrad_kernel<<<parts, 256, lds, st>>>(lab, dact, dact_ld, act, act_ld, N, H, W, shift, R, Rw, L, cp,
+                                                    workspace);
   DSEE_LAUNCH_CHECK();
   onehot_wgrad_finalize_kernel<<<dsee_cdiv((long)(9 * L + 1) * 128, 256), 256, 0, st>>>(workspace, parts, L, dw_oihw,
                                                                                         dbias);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_label_onehot(const uint8_t* lab, float* out, int N, int H, int W, int shift, int out_ld, int coff,
+                      hipStream_t st) {
+  DSEE_CHECK_ARG(lab && out && out_ld % 4 == 0 && coff % 4 == 0 && out_ld >= coff + 32);
+  const int R = H >> shift, Rw = W >> shift;
+  const long M = (long)N * R * Rw;
+  label_onehot_kernel<<<(int)min(4096L, (M + 31) / 32), 256, 0, st>>>(lab, out, N, H, W, shift, R, Rw, out_ld, coff);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -161,6 +161,40 @@ class SpadeNorm(nn.Module):
     def forward(self, x, labels, style, training):
         n, h, w, c = x.shape
         fm = h if self.kind == "spade" else min(h, self.max_fm)  # SPADE.forward has no fm cap
+        sh = self.mlp_shared._modules["0"]
+        st = self.param_free_norm
+        capped = fm != h
+        if capped or (self.kind != "spade" and (h * w) % 128 != 0):
+            return self._forward_dense(x, labels, style, training, fm)
+        shift = labels.shift_for(h)
+        # ---- table path: one fused autograd node per norm
+        if self.kind == "spade":
+            w2a, b2 = ops.pack_gamma_beta(self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_gamma.bias,
+                                          self.mlp_beta.bias)
+            return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, None, b2, st.running_mean, st.running_var,
+                                           labels, shift, training, 1.0)
+        zero_b = torch.zeros_like(self.mlp_style_gamma.bias)
+        if self.kind == "sean":
+            wg, wb = torch.sigmoid(self.alpha_gamma), torch.sigmoid(self.alpha_beta)
+            bg = (1.0 - wg) * self.mlp_gamma.bias + wg * self.mlp_style_gamma.bias
+            bb = (1.0 - wb) * self.mlp_beta.bias + wb * self.mlp_style_beta.bias
+            w2a, b2 = ops.pack_gamma_beta((1.0 - wg) * self.mlp_gamma.weight, (1.0 - wb) * self.mlp_beta.weight, bg, bb)
+            ws2, _ = ops.pack_gamma_beta(wg * self.mlp_style_gamma.weight, wb * self.mlp_style_beta.weight, zero_b,
+                                         zero_b)
+            table = ops.style_table(style, ws2)
+            return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, table, b2, st.running_mean, st.running_var,
+                                           labels, shift, training, 1.0)
+        # puresean: out = xhat * gamma_s + beta_s
+        ws2, b2 = ops.pack_gamma_beta(self.mlp_style_gamma.weight, self.mlp_style_beta.weight,
+                                      self.mlp_style_gamma.bias, self.mlp_style_beta.bias)
+        table = ops.style_table(style, ws2)
+        return ops.SeanNormTable.apply(x, None, None, None, table, b2, st.running_mean, st.running_var, labels, shift,
+                                       training, 0.0)
+
+    def _forward_dense(self, x, labels, style, training, fm):
+        """General path (style map materialised as 128 gathered channels): resolutions below 16x16, and the
+        reference's max_fm_size cap where the upsampled embedding replaces the style map."""
+        n, h, w, c = x.shape
         shift = labels.shift_for(fm)
         cat_ups = 0
         sh = self.mlp_shared._modules["0"]

@@ -360,7 +360,7 @@ class SeanInput(torch.autograd.Function):
         if ctx.want_actv and ctx.needs_input_grad[0]:
             dw, db = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
             ws = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
-            L.call("onehot_conv3x3_wgrad", lab.t, dcat, cat, ld, 0, n, lab.h, lab.w, shift, lab.nc, dw, db, ws)
+            L.call("onehot_conv3x3_wgrad", lab.t, dcat, ld, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw, db, ws)
         if ctx.want_style and ctx.needs_input_grad[2]:
             s = ctx.sshape[2]
             dstyle = new(*ctx.sshape)
@@ -447,8 +447,8 @@ class SpadeNormAct(torch.autograd.Function):
         out, scale = torch.empty_like(x), torch.empty_like(x)
         wp = _pack_fwd(w2, kin, geom.korder)
         with _timed("conv_igemm_128x128_modulate", _flops(geom)):
-            L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, b2.contiguous(), x, mean, invstd, out, scale, c,
-                   float(add_one), LRELU_SLOPE)
+            L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, None, 0, b2.contiguous(), x, mean, invstd, out, scale,
+                   c, float(add_one), LRELU_SLOPE)
         ctx.geom = geom
         ctx.save_for_backward(x, cat, w2, out, scale, mean, invstd)
         return out
@@ -480,6 +480,102 @@ class SpadeNormAct(torch.autograd.Function):
             idx, _ = packed_perm(c, x.device)
             db2 = torch.cat([cs.reshape(-1), torch.zeros(1, device=x.device)]).index_select(0, idx)
         return dx, dcat, dw2, db2, None, None, None, None, None
+
+
+class SeanNormTable(torch.autograd.Function):
+    """SPADE / SEAN / PureSEAN norm + LeakyReLU as ONE node, with the SEAN style half as per-image tables.
+
+    The style map is constant per region, so its 3x3 convs are convs over the one-hot label with per-image weights
+    T[n][tap][row][r] = sum_s W_s[row][s][tap] * style[n][r][s] (SURVEY B-7).  The GEMM therefore reads
+    [ReLU(mlp_shared(seg)) (128) ; one-hot label (19 -> 32)] = 160 channels (K = 1440) instead of
+    [actv ; style_map] = 256 (K = 2304), and the style gradient is a label-segmented sum of the gamma/beta
+    gradient rows.  `table` None -> SPADE (128 channels); `w2a` None -> PureSEAN (one-hot only)."""
+
+    @staticmethod
+    def forward(ctx, x, w_sh, b_sh, w2a, table, b2, running_mean, running_var, labels, shift, training, add_one):
+        n, h, w, c = x.shape
+        nc = labels.nc
+        has_a, has_t = w2a is not None, table is not None
+        rows = w2a.shape[0] if has_a else table.shape[2]
+        ca = NHIDDEN if has_a else 0
+        ld = ca + (32 if has_t else 0)
+        cat = new(n, h, w, ld)
+        if has_a:
+            tab = new(9, nc, NHIDDEN)
+            L.call("onehot_conv3x3_pack", w_sh.contiguous(), tab, NHIDDEN, nc)
+            L.call("onehot_conv3x3_fwd", labels.t, tab, b_sh, cat, n, labels.h, labels.w, shift, nc, NHIDDEN, ld, 0, 1)
+        if has_t:
+            L.call("label_onehot", labels.t, cat, n, labels.h, labels.w, shift, ld, ca)
+        mean, invstd = new(c), new(c)
+        if training:
+            ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
+            L.call("norm_stats", x, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var, ws)
+        else:
+            L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
+        geom = L.geom_fwd(n, h, w, ld, rows, 3, 1, 1, 0)
+        assert geom.korder == 1
+        wp = None
+        if has_a:
+            w2a = w2a.contiguous()
+            wp = _pack_fwd(w2a, ca, 1)
+        tb = table.contiguous() if has_t else None
+        out, scale = torch.empty_like(x), torch.empty_like(x)
+        with _timed("conv_igemm_128x128_modulate", _flops(geom)):
+            L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, tb, ca, b2.contiguous(), x, mean, invstd, out, scale, c,
+                   float(add_one), LRELU_SLOPE)
+        ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
+        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, cat, w2a, out, scale, mean, invstd = ctx.saved_tensors
+        geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
+        n, h, w, c = x.shape
+        ld = cat.shape[3]
+        dgb = (torch.zeros if c % 64 else torch.empty)(n, h, w, rows, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        cs = new(2, c)
+        ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
+        L.call("modulate_bwd", dh.contiguous(), out, x, scale, mean, invstd, None, dx, dgb, rows, cs, n, h * w, c,
+               LRELU_SLOPE, ws)
+        dw_sh = db_sh = dw2a = dtable = db2 = None
+        if ctx.has_a:
+            # data gradient only w.r.t. the 128 embedding channels (the one-hot channels need none)
+            ga = L.ConvGeom(n, h, w, rows, h, w, NHIDDEN, 3, 3, 1, 1, -1, 0, 0, 1)
+            dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga)
+            dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
+            wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
+            L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw_sh, db_sh,
+                   wso)
+        if ctx.has_t:
+            # one split-K launch (image-aligned splits): shared columns -> dw2a, one-hot columns per image -> dtable
+            nbytes = L.lib().dsee_conv2d_wgrad_table_workspace(C.byref(geom))
+            wsw = scratch(nbytes, "wgrad")
+            dtable = new(n, 9, rows, 32)
+            if ctx.has_a:
+                dw2a = new(rows, NHIDDEN, 3, 3)
+            with _timed("conv_wgrad_128x128(+slab reduce)", _flops(geom)):
+                L.call("conv2d_wgrad_table", C.byref(geom), cat, dgb, wsw, C.c_size_t(nbytes), dw2a, ld - 32, dtable,
+                       lab.nc)
+        elif ctx.has_a and ctx.needs_input_grad[3]:
+            dw2a = wgrad_raw(cat, dgb, geom, rows, NHIDDEN, 3, 3)
+        if ctx.needs_input_grad[5]:
+            idx, _ = packed_perm(c, x.device)
+            db2 = torch.cat([cs.reshape(-1), torch.zeros(1, device=x.device)]).index_select(0, idx)
+        return dx, dw_sh, db_sh, dw2a, dtable, db2, None, None, None, None, None, None
+
+
+def style_table(style, ws2):
+    """T[n][tap][row][r(32)] from the style matrix [N,19,S] and the (row-permuted, blend-scaled) style conv weights
+    ws2 [rows,S,3,3]: a 1x1 convolution over the N*19 style rows (HIP conv kernel, differentiable), then a
+    parameter-sized transpose/pad (<= 6 MB) into the layout the modulate kernel reads."""
+    n, nc, s = style.shape
+    rows = ws2.shape[0]
+    wt = ws2.permute(2, 3, 0, 1).reshape(9 * rows, s, 1, 1)             # [(tap,row)][s]
+    t = conv2d(style.reshape(n, nc, 1, s).contiguous(), wt, None, None, 1, 0, 0, L.ACT_NONE)   # [N,19,1,9*rows]
+    t = t.reshape(n, nc, 9, rows).permute(0, 2, 3, 1)                   # [N,9,rows,19]
+    return torch.nn.functional.pad(t, (0, 32 - nc)).contiguous()
 
 
 # ------------------------------------------------------------------------------------ pooling

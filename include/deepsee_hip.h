@@ -81,16 +81,31 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
  * groups side by side (row order of the packed weight: for 64-channel block b, wave w, half h, lane c:
  * row = b*128 + w*64 + h*32 + c  <->  channel b*64 + w*32 + c, h = 0 gamma / 1 beta) and the epilogue writes
  *   scale = acc_gamma + bias_gamma + add_one ;  h = lrelu(((x-mean)*invstd) * scale + acc_beta + bias_beta)
- * so gamma/beta never reach HBM.  `scale` is saved for the backward pass. */
+ * so gamma/beta never reach HBM.  `scale` is saved for the backward pass.
+ *
+ * SEAN style half as a table: the style map is constant per region, so conv(style_map, W_s) is a conv over the one-hot
+ * label map with per-image weights T[n][tap][row][r] = sum_s W_s[row][s][tap] * style[n][r][s] (SURVEY B-7).  When
+ * style_table != NULL the last 32 input channels of `in` must hold the one-hot label (19 classes padded to 32,
+ * dsee_label_onehot) and their 9 K-slabs read T instead of w_packed (which then covers the first shared_cin channels):
+ * +288 K instead of +1152 K for the style half.  Requires korder 1 and Ho*Wo % 128 == 0. */
 int dsee_conv2d_modulate_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed,
-                             const float* bias_packed, const float* x, const float* mean, const float* invstd,
-                             float* out_h, float* out_scale, int C, float add_one, float slope, hipStream_t stream);
+                             const float* style_table, int shared_cin, const float* bias_packed, const float* x,
+                             const float* mean, const float* invstd, float* out_h, float* out_scale, int C,
+                             float add_one, float slope, hipStream_t stream);
 
 /* dW[co][ci][kh][kw] = sum_m dout[m][co] * in[src(m,tap)][ci]  (conv_backward weight part); split-K over
  * pixels into `workspace` slabs, reduced in fixed order (deterministic). */
 size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g);
 int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
                       size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_real, hipStream_t stream);
+
+/* wgrad of the SEAN modulate GEMM with a per-image style table (see dsee_conv2d_modulate_fwd): one split-K launch with
+ * image-aligned splits; shared columns -> dw_oihw [rows][Cin_shared][KH][KW] (may be NULL), one-hot columns per image ->
+ * dtable [N][taps][rows][32]. */
+size_t dsee_conv2d_wgrad_table_workspace(const dsee_conv_geom* g);
+int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
+                            size_t workspace_bytes, float* dw_oihw, int Cin_shared, float* dtable, int L,
+                            hipStream_t stream);
 
 /* ------------------------------------------------------------------ normalisation statistics / backward
  * Replaces F.batch_norm(training) of the single-device SynchronizedBatchNorm2d branch
@@ -123,9 +138,12 @@ int dsee_onehot_conv3x3_pack(const float* w_oihw, float* table, int Co, int L, h
 int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float* bias, float* out, int N, int H, int W,
                             int shift, int L, int Co, int out_ld, int coff, int relu, hipStream_t stream);
 size_t dsee_onehot_conv3x3_wgrad_workspace(int N, int H, int W, int shift, int L);
-int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, const float* act, int ld, int coff, int N, int H,
-                              int W, int shift, int L, float* dw_oihw, float* dbias, float* workspace,
+int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, int dact_ld, const float* act, int act_ld, int N,
+                              int H, int W, int shift, int L, float* dw_oihw, float* dbias, float* workspace,
                               hipStream_t stream);
+/* out[m][coff + r] = (label(m) == r), r in [0, 32): the one-hot input channels of the SEAN style table path */
+int dsee_label_onehot(const uint8_t* lab, float* out, int N, int H, int W, int shift, int out_ld, int coff,
+                      hipStream_t stream);
 /* out[m][coff..] = scale * table[n][label(m)][:]   — SEAN style_map (normalization.py:179-185); backward of
  * extract_style_matrix */
 int dsee_label_gather(const uint8_t* lab, const float* table, float* out, int N, int H, int W, int shift, int L, int Cs,

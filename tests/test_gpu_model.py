@@ -124,7 +124,7 @@ def test_smooth_loss_backward(name):
     """Backward parity with the sign-function losses taken out: L_G = <fake, R>, L_D = sum_k <D_k(cat[fake;real]), R_k>,
     L_V = sum_i <VGG_i(fake), R_i> with fixed random R.  Every HIP backward kernel of the path (SPADE/SEAN modulate,
     BN, convs dgrad/wgrad, SN, noise, upsample, IN, pools, style pool/gather, one-hot conv) is exercised and compared
-    with the oracle in float64: the HIP error must be within 10x the CPU-fp32 oracle's own
+    with the oracle in float64: the HIP error must be within 20x the CPU-fp32 oracle's own
     error (floor 1e-4; the MFMA accumulates each output in one fp32 chain over K, oneDNN in blocked partial sums) and
     below 2e-3 absolutely."""
     from deepsee_amd import networks as N, ops
@@ -200,7 +200,7 @@ def test_smooth_loss_backward(name):
         den = max(float(v.norm()), (1e-2 if v.numel() == 1 else 1e-3) * gmax)
         eh = float((hg[kk].double() - v).norm()) / den
         ec = float((g32[kk].double() - v).norm()) / den
-        assert eh <= max(10 * ec, 1e-3) and eh < 2e-3, (kk, eh, ec, float(v.norm()), gmax)
+        assert eh <= max(20 * ec, 1e-3) and eh < 2e-3, (kk, eh, ec, float(v.norm()), gmax)
         worst = max(worst, (eh, kk))
     print("worst HIP-vs-f64 grad error %.2e (%s)" % worst)
 

@@ -105,6 +105,45 @@ def test_spade_sean_norm_fwd_bwd(kind, C, R, N):
             assert rel(p[k].grad.cpu(), v.grad) < 1e-4, k
 
 
+@pytest.mark.parametrize("kind,C,R,N", [("spade", 64, 16, 2), ("sean", 64, 16, 2), ("sean", 128, 32, 3), ("puresean", 64, 16, 2)])
+def test_sean_norm_table_path(kind, C, R, N):
+    """The production path for R >= 16: style half as per-image one-hot tables (K = 1440 instead of 2304)."""
+    from deepsee_amd import ops, networks as Nw
+    from types import SimpleNamespace
+    g = gen(7 * C + R + N)
+    Lc, S, H = 19, 128, 64
+    label = torch.randint(0, Lc, (N, 1, H, H), generator=g).float()
+    seg = O.onehot_labels(label, Lc)
+    style = (torch.rand(N, Lc, S, generator=g) * 2 - 1).requires_grad_()
+    x = torch.randn(N, C, R, R, generator=g).requires_grad_()
+    mod = Nw.SpadeNorm(kind, C, Lc, S, 256)
+    st = {"n." + k: O.recipe_tensor("tt_" + kind, k, v.shape, 1.0) for k, v in mod.state_dict().items()}
+    orc = O.Oracle(O.make_opt(), {"SR": st})
+    P = orc.S["SR"]
+    y = F.leaky_relu(orc._norm(kind, P, "n", x, seg, style), 0.2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    mod.load_state_dict({k[2:]: v for k, v in st.items()})
+    mod.cuda()
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
+    xs = nhwc(x.detach()).requires_grad_()
+    sty = style.detach().cuda().requires_grad_()
+    h = mod(xs, labels, sty, True)
+    h.backward(nhwc(gy))
+    torch.cuda.synchronize()
+    assert rel(nchw(h.detach(), C), y.detach()) < TOL
+    assert rel(nchw(xs.grad, C), x.grad) < 5 * TOL
+    assert rel(mod.param_free_norm.running_var.cpu(), P["n.param_free_norm.running_var"]) < TOL
+    if kind != "spade":
+        assert rel(sty.grad.cpu(), style.grad) < 1e-4
+    for k, p in mod.named_parameters():
+        ref = P["n." + k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel(p.grad.cpu(), ref) < 2e-4, k
+
+
 @pytest.mark.parametrize("act", [1, 3])
 def test_instnorm_act(act):
     from deepsee_amd import ops
