@@ -50,9 +50,58 @@ struct ConvArgs {
 
 constexpr int BK = 32;
 constexpr int LDK = 36;  // padded LDS row (floats)
-constexpr int FLUSH = 4; // K-slabs per partial-accumulator chain (power of two)
+constexpr int FLUSH = 8; // K-slabs per partial-accumulator chain (power of two): 256-deep MFMA chains
 
 enum { EPI_PLAIN = 0, EPI_MODULATE = 1 };
+
+// Shared epilogue: `row_of(i, r)` maps accumulator element r of M-subtile i to the output pixel index (or -1).
+template <int MT, int NT, int BN, int EPI, typename RowOf>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int bn, int wn, int lane,
+                                              RowOf row_of) {
+  if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
+      if (col >= a.Cout) continue;
+      const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long row = row_of(i, r);
+          if (row >= 0) {
+            float v = acc[i][j][r] + b;
+            if (a.res) v += a.res[(size_t)row * a.Cout + col];
+            a.out[(size_t)row * a.Cout + col] = dsee_act(v, a.act, a.slope);
+          }
+        }
+    }
+  } else {
+    static_assert(EPI != EPI_MODULATE || NT == 2, "modulate pairs gamma/beta tiles");
+    // tile j=0 holds (scale-ish) gamma, j=1 holds beta of channel c for the same rows.
+    const int c = bn * (BN / 2) + wn * 32 + (lane & 31);
+    if (c < a.C) {
+      const int pcol = bn * BN + wn * 64 + (lane & 31);
+      const float bg = a.bias ? a.bias[pcol] : 0.f;
+      const float bb = a.bias ? a.bias[pcol + 32] : 0.f;
+      const float mu = a.mean[c], is = a.invstd[c];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long row = row_of(i, r);
+          if (row >= 0) {
+            const size_t o = (size_t)row * a.C + c;
+            const float xh = (a.mx[o] - mu) * is;
+            const float sc = acc[i][0][r] + bg + a.add_one;
+            const float v = xh * sc + (acc[i][1][r] + bb);
+            a.scale_out[o] = sc;
+            a.out[o] = v > 0.f ? v : v * a.slope;
+          }
+        }
+    }
+  }
+}
 
 // GEO = 1: source pixel is an affine function of the output pixel (dshift == 0, ups == 0) and Cin % 32 == 0, so the
 //          per-slab address work is a handful of selects; GEO = 0: general geometry (strided dgrads, fused upsample,
@@ -60,7 +109,7 @@ enum { EPI_PLAIN = 0, EPI_MODULATE = 1 };
 //          arithmetic and the global loads of slab kt+1 interleave with the MFMAs of slab kt (the matrix pipe takes a
 //          new MFMA only every 64 cycles per wave; everything else issues in its shadow).
 template <int MT, int NT, int WM, int WN, int EPI, int GEO>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
   constexpr int NTHR = WM * WN * 64, RPP = NTHR / 8;  // threads, LDS rows filled per pass
   constexpr int A_CH = BM * 8 / NTHR, B_CH = BN * 8 / NTHR;
@@ -157,13 +206,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_ige
         ra[j] = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_voff[j] : 0xFFFFFFFFu, soff, 0));
       }
-      const bool sty = a.wt != nullptr && kt >= a.nk_shared;  // block-uniform
-      const unsigned soff_b = (unsigned)__builtin_amdgcn_readfirstlane(
-          sty ? ((n_img * (nk - a.nk_shared) + (kt - a.nk_shared)) * a.wt_rows) * (BK * 4) : kt * (BK * 4));
+      if constexpr (EPI == EPI_MODULATE) {
+        // per-image style table for the K tail (block-uniform switch; one load instruction either way)
+        const bool sty = a.wt != nullptr && kt >= a.nk_shared;
+        const unsigned soff_b = (unsigned)__builtin_amdgcn_readfirstlane(
+            sty ? ((n_img * (nk - a.nk_shared) + (kt - a.nk_shared)) * a.wt_rows) * (BK * 4) : kt * (BK * 4));
+        const __amdgpu_buffer_rsrc_t rs = sty ? rsrc_t : rsrc_b;
 #pragma unroll
-      for (int j = 0; j < B_CH; ++j)
-        rb[j] = __builtin_bit_cast(f32x4, sty ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, t_voff[j], soff_b, 0)
-                                              : __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], soff_b, 0));
+        for (int j = 0; j < B_CH; ++j)
+          rb[j] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, sty ? t_voff[j] : b_voff[j], soff_b, 0));
+      } else {
+        const unsigned soff_b = (unsigned)__builtin_amdgcn_readfirstlane(kt * (BK * 4));
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j)
+          rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], soff_b, 0));
+      }
       // advance to the next slab (scalar selects only): next tap, then next channel chunk
       g_tap += 1;
       g_kw += 1;
@@ -285,49 +343,194 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 4 : 2)) void conv_ige
 
   // ---- epilogue.  C/D map of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const int rbase = bm * BM + wm * MT * 32 + 4 * (lane >> 5);
-  if constexpr (EPI == EPI_PLAIN) {
+  conv_epilogue<MT, NT, BN, EPI>(a, acc, bn, wn, lane, [&](int i, int r) {
+    const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+    return row < a.M ? (long)row : -1L;
+  });
+}
+
+// ---------------------------------------------------------------- 3x3 stride-1 "same" conv with an LDS-staged halo
+// The hot layers (512->512 resblock convs, gamma/beta GEMM, their data gradients, VGG) are 3x3 / stride 1 / same
+// size.  An M tile is an 8x16 pixel patch; for every 32-channel chunk its 10x18 halo is staged in LDS ONCE and the 9
+// taps read their A fragments from it at fixed offsets, so the A operand costs 23 KB of L2->LDS traffic per 9 K-slabs
+// instead of 144 KB and no per-slab address arithmetic at all; only the weight slab (16 KB) is fetched per tap.
+// Measured motivation (tools/bench_conv_one.py ablations): with either operand's global traffic removed the same
+// loop runs at 95 % of the fp32 MFMA peak, with both present at 84 %.
+// WM = 2: 8x16 patch, 4 waves, 2 blocks/CU (shipped).  WM = 4 (16x16 patch, 8 waves, 1 block/CU, half the weight
+// traffic) measured the same 86 % of peak, so the extra instantiation is not built.
+constexpr int HALO_W = 18;
+
+template <int EPI, int WM>
+__global__ __launch_bounds__(WM * 128, 2) void conv_halo_kernel(ConvArgs a) {
+  constexpr int MT = 2, NT = 2, BN = 128, NTHR = WM * 128, B_CH = BN * 8 / NTHR, RPP = NTHR / 8;
+  constexpr int PH = WM * 4, HALO_PX = HALO_W * (PH + 2), HALO_CH = (HALO_PX * 8 + NTHR - 1) / NTHR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ah = smem;                    // [180][LDK]
+  float* Bs = smem + HALO_PX * LDK;    // [2][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;  // wm in [0, WM)
+  int bm, bn;
+  {
+    const int nbn = gridDim.y, total = gridDim.x * nbn;
+    const int b = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bn = l % nbn;
+    bm = l / nbn;
+  }
+  const int txn = a.Wo / 16, tyn = a.Ho / PH;
+  const int tx = bm % txn, ty = (bm / txn) % tyn, n_img = bm / (txn * tyn);
+  const int chunk = tid & 7, lrow = tid >> 3;
+  const int ntaps = 9, ncc = a.Cin / 32, nk = ncc * ntaps;
+
+  // halo element e = tid + 256*j -> pixel e>>3, 16-B chunk e&7; fixed byte offset (or the out-of-range sentinel)
+  unsigned h_voff[HALO_CH];
+  int h_lds[HALO_CH];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
-      if (col >= a.Cout) continue;
-      const float b = a.bias ? a.bias[col] : 0.f;
+  for (int j = 0; j < HALO_CH; ++j) {
+    const int e = tid + NTHR * j, hp = e >> 3, hc = e & 7;
+    const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+    const int y = ty * PH + hy - 1, x = tx * 16 + hx - 1;
+    const bool ok = e < HALO_PX * 8 && y >= 0 && y < a.Hi && x >= 0 && x < a.Wi;
+    h_voff[j] = ok ? (unsigned)((((size_t)(n_img * a.Hi + y) * a.Wi + x) * a.Cin + hc * 4) * 4) : 0xFFFFFFFFu;
+    h_lds[j] = e < HALO_PX * 8 ? hp * LDK + hc * 4 : -1;
+  }
+  unsigned b_voff[B_CH], t_voff[B_CH];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < B_CH; ++j) {
+    b_voff[j] = (unsigned)(((size_t)(lrow + RPP * j) * a.wstride + chunk * 4) * 4);
+    t_voff[j] = (unsigned)(((lrow + RPP * j) * BK + chunk * 4) * 4);
+  }
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0xFFFFFFFE, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.w + (size_t)bn * BN * a.wstride), 0, 0xFFFFFFFE, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((a.wt ? a.wt : a.w) + (size_t)bn * BN * BK), 0, 0xFFFFFFFE, 0x00020000);
+
+  f32x4 hreg[HALO_CH], rb[B_CH];
+  auto load_halo = [&](int cc, bool live) {
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(cc * (BK * 4));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (row < a.M) {
-            float v = acc[i][j][r] + b;
-            if (a.res) v += a.res[(size_t)row * a.Cout + col];
-            a.out[(size_t)row * a.Cout + col] = dsee_act(v, a.act, a.slope);
-          }
-        }
+    for (int j = 0; j < HALO_CH; ++j)
+      hreg[j] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, live ? h_voff[j] : 0xFFFFFFFFu, so, 0));
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int j = 0; j < HALO_CH; ++j)
+      if (h_lds[j] >= 0) *reinterpret_cast<f32x4*>(Ah + h_lds[j]) = hreg[j];
+  };
+  auto load_b = [&](int kt) {
+    if constexpr (EPI == EPI_MODULATE) {
+      const bool sty = a.wt != nullptr && kt >= a.nk_shared;
+      const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(
+          sty ? ((n_img * (nk - a.nk_shared) + (kt - a.nk_shared)) * a.wt_rows) * (BK * 4) : kt * (BK * 4));
+      const __amdgpu_buffer_rsrc_t rs = sty ? rsrc_t : rsrc_b;
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j)
+        rb[j] = __builtin_bit_cast(f32x4,
+                                   __builtin_amdgcn_raw_buffer_load_b128(rs, sty ? t_voff[j] : b_voff[j], so, 0));
+    } else {
+      const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(kt * (BK * 4));
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j)
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], so, 0));
     }
-  } else {
-    static_assert(EPI != EPI_MODULATE || NT == 2, "modulate pairs gamma/beta tiles");
-    // tile j=0 holds (scale-ish) gamma, j=1 holds beta of channel c for the same rows.
-    const int c = bn * (BN / 2) + wn * 32 + (lane & 31);
-    if (c < a.C) {
-      const int pcol = bn * BN + wn * 64 + (lane & 31);
-      const float bg = a.bias ? a.bias[pcol] : 0.f;
-      const float bb = a.bias ? a.bias[pcol + 32] : 0.f;
-      const float mu = a.mean[c], is = a.invstd[c];
+  };
+  auto store_b = [&](int buf) {
+    float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) *reinterpret_cast<f32x4*>(Bb + (lrow + RPP * j) * LDK + chunk * 4) = rb[j];
+  };
+
+  f32x16 acc[MT][NT], part[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  int a_frag[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a_frag[i] = ((wm * 4 + i * 2 + (frow >> 4)) * HALO_W + (frow & 15)) * LDK + fk;
+  const int b_frag = (wn * NT * 32 + frow) * LDK + fk;
+  // halo offset of tap (kh,kw): rows/cols 1 + off + k*kdir in {0,1,2}
+  auto tap_off = [&](int tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    return ((1 + a.off + kh * a.kdir) * HALO_W + (1 + a.off + kw * a.kdir)) * LDK;
+  };
+  f32x4 af[2][MT], bf[2][NT];
+  auto read_frags = [&](int toff, int buf, int kk, int set) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[set][i] = *reinterpret_cast<const f32x4*>(Ah + a_frag[i] + toff + kk * 8);
+    const float* Bc = Bs + buf * BN * LDK + b_frag + kk * 8;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[set][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDK);
+  };
+  auto mma_group = [&](int set) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (row < a.M) {
-            const size_t o = (size_t)row * a.C + c;
-            const float xh = (a.mx[o] - mu) * is;
-            const float sc = acc[i][0][r] + bg + a.add_one;
-            const float v = xh * sc + (acc[i][1][r] + bb);
-            a.scale_out[o] = sc;
-            a.out[o] = v > 0.f ? v : v * a.slope;
-          }
-        }
+        for (int j = 0; j < NT; ++j)
+          part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][q], bf[set][j][q], part[i][j], 0, 0, 0);
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] += part[i][j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+      }
+  };
+
+  load_halo(0, true);
+  load_b(0);
+  int cur = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+    __syncthreads();  // nobody reads the previous chunk's halo / weight slabs any more
+    store_halo();
+    store_b(cur);
+    __syncthreads();
+    load_halo(min(cc + 1, ncc - 1), cc + 1 < ncc);  // next chunk's halo: 9 slabs of MFMAs cover it
+    load_b(min(cc * ntaps + 1, nk - 1));
+    read_frags(tap_off(0), cur, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kt = cc * ntaps + tap;
+      const int toff = tap_off(tap);
+      read_frags(toff, cur, 1, 1);
+      mma_group(0);
+      read_frags(toff, cur, 2, 0);
+      mma_group(1);
+      read_frags(toff, cur, 3, 1);
+      mma_group(0);
+      if (tap < 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(cur ^ 1);
+        __syncthreads();
+        read_frags(tap_off(tap + 1), cur ^ 1, 0, 0);
+        load_b(min(kt + 2, nk - 1));
+        mma_group(1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+      } else {
+        mma_group(1);
+      }
+      if ((kt & (FLUSH - 1)) == FLUSH - 1) flush();
     }
   }
+  flush();
+
+  conv_epilogue<MT, NT, BN, EPI>(a, acc, bn, wn, lane, [&](int i, int r) {
+    const int local = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    return (long)(n_img * a.Ho + ty * PH + (local >> 4)) * a.Wo + tx * 16 + (local & 15);
+  });
 }
 
 // ---------------------------------------------------------------- weight gradient (split-K)
@@ -640,8 +843,32 @@ int launch_conv_geo(const ConvArgs& a, hipStream_t st) {
   return DSEE_OK;
 }
 
+template <int EPI, int WM>
+int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)(HALO_W * (WM * 4 + 2) + 2 * 128) * LDK * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI, WM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid(a.M / (WM * 64), EPI == EPI_MODULATE ? dsee_cdiv(a.C, 64) : dsee_cdiv(a.Cout, 128));
+  conv_halo_kernel<EPI, WM><<<grid, WM * 128, lds, st>>>(a);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+static bool halo_ok(const ConvArgs& a) {
+  static int disable = -1;
+  if (disable < 0) disable = getenv("DSEE_NO_HALO") ? 1 : 0;
+  return !disable && a.korder == 1 && a.KH == 3 && a.KW == 3 && a.mul == 1 && a.Hi == a.Ho && a.Wi == a.Wo &&
+         a.Ho % 8 == 0 && a.Wo % 16 == 0 && a.off == -a.kdir && (a.kdir == 1 || a.kdir == -1) &&
+         (long)a.N * a.Hi * a.Wi * a.Cin * 4 + 65536 < 0xFFFFFFFEL;
+}
+
 template <int MT, int NT, int WM, int WN, int EPI>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
+  if (MT == 2 && NT == 2 && WM == 2 && WN == 2 && halo_ok(a)) return launch_conv_halo<EPI, 2>(a, st);
   ConvArgs b = a;
   bool fast = a.korder == 1;
   if (fast) {
