@@ -25,7 +25,8 @@ struct ConvArgs {
   const float* in;
   const float* w;      // packed [wrows][Kpad], k = (kh*KW+kw)*Cin + c
   const float* bias;   // [Cout] or null (packed order for the modulate epilogue)
-  const float* res;    // residual [M][Cout] or null
+  const float* res;    // residual [M][res_ld] or null (act == DSEE_ACT_MASK: ReLU mask source instead of addend)
+  int res_ld;
   float* out;          // [M][Cout]
   // modulate epilogue (SPADE / SEAN / PureSEAN)
   const float* mx;     // [M][C] tensor being normalised
@@ -71,7 +72,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
           const long row = row_of(i, r);
           if (row >= 0) {
             float v = acc[i][j][r] + b;
-            if (a.res) v += a.res[(size_t)row * a.Cout + col];
+            if (a.act == DSEE_ACT_MASK) {
+              v = a.res[(size_t)row * a.res_ld + col] > 0.f ? v : 0.f;  // backward of a ReLU whose output is `res`
+            } else if (a.res) {
+              v += a.res[(size_t)row * a.res_ld + col];
+            }
             a.out[(size_t)row * a.Cout + col] = dsee_act(v, a.act, a.slope);
           }
         }
@@ -543,6 +548,7 @@ struct WgradArgs {
   int mul, off, kdir, dshift, ups;
   int M, msplit, rows;
   int korder, Kuse;  // slab column order; number of slab columns actually computed (<= Ktot)
+  int Kstart;        // first slab column computed (multiple of 128)
   int margin;  // WGEO 1: bytes the `in` buffer base is moved down (most negative tap shift)
 };
 
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   // B' column (k') owned by this thread is fixed for the whole kernel
   // (korder 1: chunk-major k' = (ci/32)*(taps*32) + tap*32 + ci%32, so that "only the first Kuse columns" means
   //  "only the first Kuse/(taps*32) channel chunks" — the one-hot tail of the SEAN input needs no shared gradient)
-  const int kq = kx * 128 + chunk * 4;
+  const int kq = a.Kstart + kx * 128 + chunk * 4;
   const bool kok = kq < a.Kuse;
   int tap = 0, cch = 0;
   if (kok) {
@@ -690,18 +696,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 
   const int nk = (m1 - m0 + 31) / 32;
   const int fcol = lane & 31, fk = lane >> 5;
-  auto mma_steps = [&](int buf, int k0, int k1) {
-    const float* Ac = As + buf * 32 * WLD + wm * 64 + fcol;
-    const float* Bc = Bs + buf * 32 * WLD + wn * 64 + fcol;
+  // fragments double-buffered in registers: 4 k-steps (16 MFMAs) per group, the next group's 16 ds_read_b32 are in
+  // flight while the current group's MFMAs issue, and the last group of a slab runs across the barrier (as in the
+  // forward kernel) so the matrix pipe is not left empty for barrier + LDS latency.
+  float fa[2][8], fb[2][8];
+  auto read_frags = [&](int buf, int g, int set) {
+    const float* Ac = As + buf * 32 * WLD + wm * 64 + fcol + (g * 8 + fk) * WLD;
+    const float* Bc = Bs + buf * 32 * WLD + wn * 64 + fcol + (g * 8 + fk) * WLD;
 #pragma unroll
-    for (int kk = k0; kk < k1; ++kk) {
-      const int k = kk * 2 + fk;
-      const float a0 = Ac[k * WLD], a1 = Ac[k * WLD + 32];
-      const float b0 = Bc[k * WLD], b1 = Bc[k * WLD + 32];
-      part[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, part[0][0], 0, 0, 0);
-      part[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, part[0][1], 0, 0, 0);
-      part[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, part[1][0], 0, 0, 0);
-      part[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, part[1][1], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      fa[set][2 * q] = Ac[q * 2 * WLD];
+      fa[set][2 * q + 1] = Ac[q * 2 * WLD + 32];
+      fb[set][2 * q] = Bc[q * 2 * WLD];
+      fb[set][2 * q + 1] = Bc[q * 2 * WLD + 32];
+    }
+  };
+  auto mma_group = [&](int set) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      part[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][2 * q], fb[set][2 * q], part[0][0], 0, 0, 0);
+      part[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][2 * q], fb[set][2 * q + 1], part[0][1], 0, 0, 0);
+      part[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][2 * q + 1], fb[set][2 * q], part[1][0], 0, 0, 0);
+      part[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][2 * q + 1], fb[set][2 * q + 1], part[1][1], 0, 0, 0);
     }
   };
   if (nk > 0) {
@@ -709,15 +725,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     store_tile(0);
   }
   __syncthreads();
-  if (nk > 0) load_tile(min(1, nk - 1), nk > 1);
+  if (nk > 0) {
+    load_tile(min(1, nk - 1), nk > 1);
+    read_frags(0, 0, 0);
+  }
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    mma_steps(cur, 0, 12);
+    read_frags(cur, 1, 1);
+    mma_group(0);
+    read_frags(cur, 2, 0);
+    mma_group(1);
+    read_frags(cur, 3, 1);
+    mma_group(0);
     __builtin_amdgcn_sched_barrier(0);  // slab kt+1 was requested a full slab ago; its first use stays below
-    mma_steps(cur, 12, 16);
     store_tile(cur ^ 1);
     __syncthreads();
+    read_frags(cur ^ 1, 0, 0);                    // next slab's first fragments under this slab's last MFMA group
     load_tile(min(kt + 2, nk - 1), kt + 2 < nk);  // next prefetch right after the barrier (branch-free)
+    mma_group(1);
+    __builtin_amdgcn_sched_barrier(0);
     if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -733,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   float* slab = a.slab + (size_t)z * a.rows * a.Kpad;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int col = kx * 128 + wn * 64 + j * 32 + (lane & 31);
+    const int col = a.Kstart + kx * 128 + wn * 64 + j * 32 + (lane & 31);
     if (col >= a.Kuse) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -793,13 +819,14 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
 }
 
 __global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int rows,
-                                           int Kpad, int Cout, int Cin, int KH, int KW, int Cin_s, int korder) {
-  // dw[co][ci][kh][kw] = sum_s slab[s][co][k'(tap, ci)]   (fixed order => deterministic)
+                                           int Kpad, int Cout, int Cin, int KH, int KW, int Cin_s, int korder,
+                                           int ci0) {
+  // dw[co][ci][kh][kw] = sum_s slab[s][co][k'(tap, ci0 + ci)]   (fixed order => deterministic)
   const long total = (long)Cout * Cin * KH * KW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int tap = (int)(i % (KH * KW));
     const long t = i / (KH * KW);
-    const int ci = (int)(t % Cin), co = (int)(t / Cin);
+    const int ci = ci0 + (int)(t % Cin), co = (int)(t / Cin);
     const size_t kcol = korder == 0 ? (size_t)tap * Cin_s + ci
                                     : (size_t)(ci >> 5) * (KH * KW * 32) + (size_t)tap * 32 + (ci & 31);
     const size_t o = (size_t)co * Kpad + kcol;
@@ -937,12 +964,14 @@ int dsee_pack_weight_dgrad(const float* w_oihw, const float* scale_num, const fl
 }
 
 int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
-                    const float* residual, float* out, int act, float slope, hipStream_t st) {
+                    const float* residual, int residual_ld, float* out, int act, float slope, hipStream_t st) {
   ConvArgs a = {};
   int rc = fill_geom(a, g);
   if (rc) return rc;
   DSEE_CHECK_ARG(in && w_packed && out);
+  DSEE_CHECK_ARG(act != DSEE_ACT_MASK || residual != nullptr);
   a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out; a.act = act; a.slope = slope;
+  a.res_ld = residual_ld > 0 ? residual_ld : a.Cout;
   if (a.Cout > 64) return launch_conv<2, 2, 2, 2, EPI_PLAIN>(a, st);
   if (a.Cout > 32) return launch_conv<2, 2, 4, 1, EPI_PLAIN>(a, st);
   return launch_conv<1, 1, 4, 1, EPI_PLAIN>(a, st);
@@ -995,7 +1024,7 @@ size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g) {
 }
 
 static int wgrad_launch(WgradArgs& a, int S, hipStream_t st) {
-  const int tx = dsee_cdiv(a.Kuse, 128), ty = dsee_cdiv(a.rows, 128);
+  const int tx = dsee_cdiv(a.Kuse - a.Kstart, 128), ty = dsee_cdiv(a.rows, 128);
   const size_t lds = (size_t)4 * 32 * WLD * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1033,17 +1062,21 @@ static void wgrad_fill(WgradArgs& a, const ConvArgs& c, const float* in, const f
 }
 
 int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
-                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_real, hipStream_t st) {
+                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
+                      hipStream_t st) {
   ConvArgs c = {};
   int rc = fill_geom(c, g);
   if (rc) return rc;
   DSEE_CHECK_ARG(in && dout && workspace && dw_oihw);
-  DSEE_CHECK_ARG(Cout_real <= g->Cout && Cin_real <= g->Cin);
+  DSEE_CHECK_ARG(Cout_real <= g->Cout && Cin_first >= 0 && Cin_first + Cin_real <= g->Cin);
+  DSEE_CHECK_ARG(Cin_first == 0 || (g->korder == 1 && Cin_first % 32 == 0));
   DSEE_CHECK_ARG(workspace_bytes >= dsee_conv2d_wgrad_workspace(g));
   WgradArgs a = {};
   wgrad_fill(a, c, in, dout, workspace);
   a.korder = (g->korder == 1 && c.Cin % 32 == 0) ? 1 : 0;
-  a.Kuse = a.korder == 1 ? (Cin_real + 31) / 32 * 32 * a.KH * a.KW : a.Ktot;  // skip trailing channel chunks
+  // chunk-major slabs: only the channel chunks [Cin_first/32, ceil((Cin_first+Cin_real)/32)) are computed
+  a.Kuse = a.korder == 1 ? (Cin_first + Cin_real + 31) / 32 * 32 * a.KH * a.KW : a.Ktot;
+  a.Kstart = a.korder == 1 ? Cin_first / 32 * 32 * a.KH * a.KW / 128 * 128 : 0;
   const int ty = dsee_cdiv(a.rows, 128);
   const int S = wgrad_splits(a.M, dsee_cdiv(a.Kpad, 128) * ty);  // same split count as the workspace query
   a.msplit = ((a.M + S - 1) / S + 31) / 32 * 32;
@@ -1051,7 +1084,7 @@ int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dou
   if (rc) return rc;
   const long total = (long)Cout_real * Cin_real * a.KH * a.KW;
   wgrad_reduce_unpack_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
-      workspace, dw_oihw, S, a.rows, a.Kpad, Cout_real, Cin_real, a.KH, a.KW, a.Cin, a.korder);
+      workspace, dw_oihw, S, a.rows, a.Kpad, Cout_real, Cin_real, a.KH, a.KW, a.Cin, a.korder, Cin_first);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1087,6 +1120,7 @@ int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const floa
   wgrad_fill(a, c, in, dout, workspace);
   a.korder = 1;
   a.Kuse = a.Ktot;
+  a.Kstart = 0;
   const int sper = table_sper(g), S = g->N * sper;
   a.msplit = g->Ho * g->Wo / sper;
   rc = wgrad_launch(a, S, st);
@@ -1095,7 +1129,7 @@ int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const floa
   if (dw_oihw && Cin_shared > 0) {
     const long total = (long)a.rows * Cin_shared * taps;
     wgrad_reduce_unpack_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
-        workspace, dw_oihw, S, a.rows, a.Kpad, a.rows, Cin_shared, a.KH, a.KW, a.Cin, 1);
+        workspace, dw_oihw, S, a.rows, a.Kpad, a.rows, Cin_shared, a.KH, a.KW, a.Cin, 1, 0);
     DSEE_LAUNCH_CHECK();
   }
   const long tt = (long)g->N * taps * a.rows * 32;

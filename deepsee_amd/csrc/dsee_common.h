@@ -34,7 +34,7 @@ __device__ __forceinline__ float dsee_act(float v, int act, float slope) {
   if (act == DSEE_ACT_LRELU) return v > 0.f ? v : v * slope;
   if (act == DSEE_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == DSEE_ACT_TANH) return tanhf(v);
-  return v;
+  return v;  // DSEE_ACT_NONE, DSEE_ACT_MASK (handled by the conv epilogue)
 }
 
 // d(act)/d(pre) expressed through the saved OUTPUT y (valid for lrelu/relu/tanh).

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSEE_LIB") or os.path.join(_HERE, "libdeepsee_hip.so")  # DSEE_LIB: kernel experiments only
 
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_MASK = 0, 1, 2, 3, 4
 
 
 class ConvGeom(C.Structure):

@@ -24,8 +24,15 @@ _scratch = {}
 PROFILE = None
 
 
-def _variant(geom):
-    return "conv_igemm_128x128" if geom.Cout > 64 else ("conv_igemm_256x64" if geom.Cout > 32 else "conv_igemm_128x32")
+def _variant(geom, modulate=False):
+    """Name of the kernel the C dispatcher (conv_mfma.hip: launch_conv / halo_ok) picks for this geometry."""
+    halo = (geom.korder == 1 and geom.KH == 3 and geom.KW == 3 and geom.mul == 1 and geom.Hi == geom.Ho
+            and geom.Wi == geom.Wo and geom.Ho % 8 == 0 and geom.Wo % 16 == 0 and geom.off == -geom.kdir)
+    if modulate:
+        return "conv_halo_128x128_modulate" if halo else "conv_igemm_128x128_modulate"
+    if geom.Cout > 64:
+        return "conv_halo_128x128" if halo else "conv_igemm_128x128"
+    return "conv_igemm_256x64" if geom.Cout > 32 else "conv_igemm_128x32"
 
 
 def _flops(geom):
@@ -153,19 +160,20 @@ def _pack_dgrad(w, cout_s, korder):
     return wp
 
 
-def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE):
+def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
     with _timed(_variant(geom), _flops(geom)):
-        L.call("conv2d_fwd", C.byref(geom), x, wp, bias, res, out, act, float(slope))
+        L.call("conv2d_fwd", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope))
     return out
 
 
-def wgrad_raw(x, dout, geom, cout, cin, kh, kw):
+def wgrad_raw(x, dout, geom, cout, cin, kh, kw, cin_first=0):
     nbytes = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
     ws = scratch(nbytes, "wgrad")
     dw = new(cout, cin, kh, kw)
-    with _timed("conv_wgrad_128x128(+slab reduce)", _flops(geom)):
-        L.call("conv2d_wgrad", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin)
+    flops = _flops(geom) * ((cin + 31) // 32 * 32 if geom.korder else geom.Cin) / geom.Cin
+    with _timed("conv_wgrad_128x128(+slab reduce)", flops):
+        L.call("conv2d_wgrad", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin_first, cin)
     return dw
 
 
@@ -446,7 +454,7 @@ class SpadeNormAct(torch.autograd.Function):
         w2 = w2.contiguous()
         out, scale = torch.empty_like(x), torch.empty_like(x)
         wp = _pack_fwd(w2, kin, geom.korder)
-        with _timed("conv_igemm_128x128_modulate", _flops(geom)):
+        with _timed(_variant(geom, True), _flops(geom)):
             L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, None, 0, b2.contiguous(), x, mean, invstd, out, scale,
                    c, float(add_one), LRELU_SLOPE)
         ctx.geom = geom
@@ -520,7 +528,7 @@ class SeanNormTable(torch.autograd.Function):
             wp = _pack_fwd(w2a, ca, 1)
         tb = table.contiguous() if has_t else None
         out, scale = torch.empty_like(x), torch.empty_like(x)
-        with _timed("conv_igemm_128x128_modulate", _flops(geom)):
+        with _timed(_variant(geom, True), _flops(geom)):
             L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, tb, ca, b2.contiguous(), x, mean, invstd, out, scale, c,
                    float(add_one), LRELU_SLOPE)
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
@@ -543,11 +551,19 @@ class SeanNormTable(torch.autograd.Function):
         if ctx.has_a:
             # data gradient only w.r.t. the 128 embedding channels (the one-hot channels need none)
             ga = L.ConvGeom(n, h, w, rows, h, w, NHIDDEN, 3, 3, 1, 1, -1, 0, 0, 1)
-            dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga)
-            dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
-            wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
-            L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw_sh, db_sh,
-                   wso)
+            if ctx.has_t:
+                # ReLU backward fused into the dgrad epilogue; the gradient of mlp_shared (a conv over the one-hot
+                # label) is then the weight gradient w.r.t. the one-hot channels already sitting in `cat` (MFMA)
+                dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga, None, cat, L.ACT_MASK, res_ld=ld)
+                gs = L.geom_fwd(n, h, w, ld, NHIDDEN, 3, 1, 1, 0)
+                dw_sh = wgrad_raw(cat, dactv, gs, NHIDDEN, lab.nc, 3, 3, cin_first=NHIDDEN)
+                db_sh = channel_dot(dactv, None, NHIDDEN).clone()
+            else:
+                dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga)
+                dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
+                wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
+                L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw_sh,
+                       db_sh, wso)
         if ctx.has_t:
             # one split-K launch (image-aligned splits): shared columns -> dw2a, one-hot columns per image -> dtable
             nbytes = L.lib().dsee_conv2d_wgrad_table_workspace(C.byref(geom))

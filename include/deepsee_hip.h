@@ -38,6 +38,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define DSEE_ACT_LRELU 1
 #define DSEE_ACT_RELU 2
 #define DSEE_ACT_TANH 3
+#define DSEE_ACT_MASK 4 /* conv epilogue only: out = residual > 0 ? v : 0 (ReLU backward fused into a dgrad) */
 
 int dsee_version(void);
 const char* dsee_last_error(void);
@@ -74,7 +75,7 @@ int dsee_pack_weight_dgrad(const float* w_oihw, const float* scale_num, const fl
  * discriminator.py:78-96; encoder.py:83-99,142-158; architecture.py:151-181 (VGG19).
  * With the dgrad geometry + dsee_pack_weight_dgrad it is the data gradient of the same convs. */
 int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
-                    const float* residual, float* out, int act, float slope, hipStream_t stream);
+                    const float* residual, int residual_ld, float* out, int act, float slope, hipStream_t stream);
 
 /* Fused SPADE / SEAN / PureSEAN normalisation (normalization.py:107-120, 167-213, 258-286) + the
  * LeakyReLU of architecture.py:92,114:  the implicit GEMM produces (gamma-ish, beta-ish) for 32-channel
@@ -94,10 +95,12 @@ int dsee_conv2d_modulate_fwd(const dsee_conv_geom* g, const float* in, const flo
                              float add_one, float slope, hipStream_t stream);
 
 /* dW[co][ci][kh][kw] = sum_m dout[m][co] * in[src(m,tap)][ci]  (conv_backward weight part); split-K over
- * pixels into `workspace` slabs, reduced in fixed order (deterministic). */
+ * pixels into `workspace` slabs, reduced in fixed order (deterministic).  Only input channels
+ * [Cin_first, Cin_first + Cin_real) are produced (Cin_first > 0 needs korder 1 and a multiple of 32). */
 size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g);
 int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
-                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_real, hipStream_t stream);
+                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
+                      hipStream_t stream);
 
 /* wgrad of the SEAN modulate GEMM with a per-image style table (see dsee_conv2d_modulate_fwd): one split-K launch with
  * image-aligned splits; shared columns -> dw_oihw [rows][Cin_shared][KH][KW] (may be NULL), one-hot columns per image ->

@@ -33,7 +33,7 @@ def test_capi_library_loads_and_exports_header_symbols():
     assert so.dsee_conv_wrows(3) == 128 and so.dsee_conv_wrows(512) == 512
     # argument validation returns an error code + message instead of launching
     so.dsee_last_error.restype = ctypes.c_char_p
-    rc = so.dsee_conv2d_fwd(None, None, None, None, None, None, 0, ctypes.c_float(0.2), None)
+    rc = so.dsee_conv2d_fwd(None, None, None, None, None, 0, None, 0, ctypes.c_float(0.2), None)
     assert rc == -1 and b"argument check failed" in so.dsee_last_error()
 
 

@@ -78,7 +78,7 @@ def test_conv_fwd_dgrad_wgrad(case):
         b_d[:cout] = b.to(dev)
     r_d = nhwc(res).to(dev) if use_res else None
     out = torch.empty(n, geom.Ho, geom.Wo, cout_s, device=dev)
-    L.call("conv2d_fwd", C.byref(geom), x_d, wp, b_d, r_d, out, act, 0.2)
+    L.call("conv2d_fwd", C.byref(geom), x_d, wp, b_d, r_d, 0, out, act, 0.2)
     torch.cuda.synchronize()
     assert geom.Ho == y.shape[2]
     assert rel(nchw(out.cpu(), cout), y.detach()) < 2e-5
@@ -91,7 +91,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     L.call("pack_weight_dgrad", w_d, None, None, wd, cout, cin, k, k, cout_s, gd.korder)
     gy_d = nhwc(gy).to(dev)
     dx = torch.empty(n, gd.Ho, gd.Wo, cin_s, device=dev)
-    L.call("conv2d_fwd", C.byref(gd), gy_d, wd, None, None, dx, 0, 0.0)
+    L.call("conv2d_fwd", C.byref(gd), gy_d, wd, None, None, 0, dx, 0, 0.0)
     torch.cuda.synchronize()
     dx_ref = xr.grad
     dx_c = nchw(dx.cpu(), cin)
@@ -103,6 +103,6 @@ def test_conv_fwd_dgrad_wgrad(case):
     ws_bytes = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
     ws = torch.empty(ws_bytes // 4, device=dev)
     dw = torch.empty(cout, cin, k, k, device=dev)
-    L.call("conv2d_wgrad", C.byref(geom), x_d, gy_d, ws, C.c_size_t(ws_bytes), dw, cout, cin)
+    L.call("conv2d_wgrad", C.byref(geom), x_d, gy_d, ws, C.c_size_t(ws_bytes), dw, cout, 0, cin)
     torch.cuda.synchronize()
     assert rel(dw.cpu(), wr.grad) < 2e-5

@@ -23,14 +23,14 @@ def main():
         x = torch.randn(n, r, r, cin, device=dev)
         wp = torch.randn(L.wrows(cout), L.kpad(3, 3, cin), device=dev) * 0.02
         out = torch.empty(n, r, r, cout, device=dev)
-        ms = timeit(lambda: L.call("conv2d_fwd", C.byref(geom), x, wp, None, None, out, 0, 0.2))
+        ms = timeit(lambda: L.call("conv2d_fwd", C.byref(geom), x, wp, None, None, 0, out, 0, 0.2))
         fl = 2.0 * n * r * r * cin * 9 * cout
         print("fwd   N=%d R=%d %d->%d: %.3f ms  %.1f TF/s (%.0f%% of 157.3)" % (n, r, cin, cout, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
         gy = torch.randn(n, r, r, cout, device=dev)
         wsb = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
         ws = torch.empty(wsb // 4, device=dev)
         dw = torch.empty(cout, cin, 3, 3, device=dev)
-        ms = timeit(lambda: L.call("conv2d_wgrad", C.byref(geom), x, gy, ws, C.c_size_t(wsb), dw, cout, cin))
+        ms = timeit(lambda: L.call("conv2d_wgrad", C.byref(geom), x, gy, ws, C.c_size_t(wsb), dw, cout, 0, cin))
         print("wgrad N=%d R=%d %d->%d: %.3f ms  %.1f TF/s (%.0f%%)  ws=%.0f MB" % (n, r, cin, cout, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100, wsb / 1e6))
 
 

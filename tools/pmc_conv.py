@@ -8,6 +8,6 @@ x = torch.randn(n, r, r, cin, device="cuda"); wp = torch.randn(L.wrows(cout), L.
 out = torch.empty(n, r, r, cout, device="cuda"); gy = torch.randn(n, r, r, cout, device="cuda")
 wsb = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom)); ws = torch.empty(wsb // 4, device="cuda"); dw = torch.empty(cout, cin, 3, 3, device="cuda")
 for _ in range(3):
-    L.call("conv2d_fwd", C.byref(geom), x, wp, None, None, out, 0, 0.2)
-    L.call("conv2d_wgrad", C.byref(geom), x, gy, ws, C.c_size_t(wsb), dw, cout, cin)
+    L.call("conv2d_fwd", C.byref(geom), x, wp, None, None, 0, out, 0, 0.2)
+    L.call("conv2d_wgrad", C.byref(geom), x, gy, ws, C.c_size_t(wsb), dw, cout, 0, cin)
 torch.cuda.synchronize()
