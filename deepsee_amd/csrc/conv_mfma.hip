@@ -44,6 +44,7 @@ struct ConvArgs {
   const float* wt;
   int nk_shared, wt_rows;
   int wstride;  // row length (floats) of the shared packed weight (== Kpad unless a table supplies the K tail)
+  long wgroup_stride;  // grouped GEMM: image n of the input uses the weight matrix at w + n*wgroup_stride (0: shared)
   int act;
   float slope;
   int M;
@@ -184,15 +185,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(ConvArgs a)
   }
   __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(a.in) - a.margin), 0, 0xFFFFFFFE, 0x00020000);
+  const int n_img = (bm * BM) / (a.Ho * a.Wo);  // used by the per-image table / grouped-GEMM modes only
   __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.w + (size_t)bn * BN * a.wstride), 0, 0xFFFFFFFE, 0x00020000);
+      (void*)(a.w + (size_t)bn * BN * a.wstride + (size_t)n_img * a.wgroup_stride), 0, 0xFFFFFFFE, 0x00020000);
   // per-image table rows are 32 floats long; this block's rows start at bn*BN
   __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((a.wt ? a.wt : a.w) + (size_t)bn * BN * BK), 0, 0xFFFFFFFE, 0x00020000);
   unsigned t_voff[B_CH];
 #pragma unroll
   for (int j = 0; j < B_CH; ++j) t_voff[j] = (unsigned)(((lrow + RPP * j) * BK + chunk * 4) * 4);
-  const int n_img = (bm * BM) / (a.Ho * a.Wo);  // only meaningful (and only used) when a.wt != nullptr
   const int nk = a.Kpad / BK;
 
   // Loads are unconditional (masked rows read element 0 of the tensor); the zero fill is applied when the slab
@@ -924,7 +925,7 @@ int fill_geom(ConvArgs& a, const dsee_conv_geom* g) {
   a.N = g->N; a.Hi = g->Hi; a.Wi = g->Wi; a.Cin = g->Cin; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
   a.KH = g->KH; a.KW = g->KW; a.Ktot = g->KH * g->KW * g->Cin; a.Kpad = (a.Ktot + 31) / 32 * 32;
   a.mul = g->mul; a.off = g->off; a.kdir = g->kdir; a.dshift = g->dshift; a.ups = g->ups; a.korder = g->korder;
-  a.wstride = a.Kpad; a.wt = nullptr; a.nk_shared = 0; a.wt_rows = 0;
+  a.wstride = a.Kpad; a.wt = nullptr; a.nk_shared = 0; a.wt_rows = 0; a.wgroup_stride = 0;
   DSEE_CHECK_ARG(g->korder == 0 || (g->korder == 1 && g->dshift == 0 && g->ups == 0 && g->Cin % 32 == 0 && g->KH * g->KW <= 32));
   long M = (long)g->N * g->Ho * g->Wo;
   DSEE_CHECK_ARG(M < (1L << 31) && (long)g->N * g->Hi * g->Wi * g->Cin < (1L << 40));
@@ -975,6 +976,20 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
   if (a.Cout > 64) return launch_conv<2, 2, 2, 2, EPI_PLAIN>(a, st);
   if (a.Cout > 32) return launch_conv<2, 2, 4, 1, EPI_PLAIN>(a, st);
   return launch_conv<1, 1, 4, 1, EPI_PLAIN>(a, st);
+}
+
+/* Grouped GEMM on the implicit-GEMM kernel: a 1x1 "convolution" whose image n multiplies the weight matrix
+ * w_packed + n * group_stride (floats).  Used for the 36 Winograd-domain GEMMs (image = transform position). */
+int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
+                            float* out, hipStream_t st) {
+  ConvArgs a = {};
+  int rc = fill_geom(a, g);
+  if (rc) return rc;
+  DSEE_CHECK_ARG(in && w_packed && out && g->KH == 1 && g->KW == 1 && g->korder == 1 && g->mul == 1);
+  DSEE_CHECK_ARG((g->Ho * g->Wo) % 128 == 0 && g->Cout > 64);  // a 128-row tile never straddles two groups
+  a.in = in; a.w = w_packed; a.out = out; a.act = DSEE_ACT_NONE; a.res_ld = a.Cout;
+  a.wgroup_stride = group_stride;
+  return launch_conv<2, 2, 2, 2, EPI_PLAIN>(a, st);
 }
 
 int dsee_conv2d_modulate_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed,

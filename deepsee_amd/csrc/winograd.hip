@@ -1,0 +1,192 @@
+// Winograd F(4x4, 3x3) transforms for the 3x3 / stride-1 / pad-1 convolutions (Lavin & Gray 2016, interpolation
+// points 0, +-1, +-2, inf).  Y = A^T [ (G g G^T) (.) (B^T d B) ] A  per 4x4 output tile and (cin, cout) pair: the
+// element-wise product summed over cin is 36 independent GEMMs  M[xi][tile][cout] = V[xi][tile][cin] * U[xi][cin][cout]
+// (2.25 M*Cin*Cout MACs instead of 9), run on the fp32 MFMA implicit-GEMM kernel as a grouped 1x1 convolution
+// (dsee_conv2d_fwd_grouped).  The two transforms here are streaming kernels (16 B per lane along C):
+//   input  : x [N][H][W][C]            -> V [36][T][C],  T = N*(H/4)*(W/4) tiles, zero padding at the image border
+//   output : M [36][T][Cout] (+bias, +residual, activation) -> y [N][H][W][Cout]
+//   weights: w OIHW [Cout][Cin][3][3]  -> U [36][rows(Cout)][Cin]   (forward)   or, with `transpose_flip`,
+//                                         U'[36][rows(Cin)][Cout] of the 180-degree-rotated kernel (data gradient)
+// Replaces the same ATen convolutions as conv_mfma.hip (architecture.py:98,122 and their backward).
+#include "dsee_common.h"
+
+namespace {
+
+// one column / row of B^T d : 6 -> 6
+__device__ __forceinline__ void bt6(const f32x4 (&d)[6], f32x4 (&o)[6]) {
+  o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+  o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+  o[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+// A^T m : 6 -> 4
+__device__ __forceinline__ void at4(const f32x4 (&m)[6], f32x4 (&o)[4]) {
+  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34;
+  o[1] = d12 + 2.f * d34;
+  o[2] = s12 + 4.f * s34;
+  o[3] = d12 + 8.f * d34 + m[5];
+}
+
+__global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N,
+                                                           int H, int W, int C) {
+  const int C4 = C / 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = T * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    f32x4 tmp[6][6];  // tmp[row][col] = (B^T d)[row][col]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int xx = tx * 4 - 1 + j;
+      f32x4 col[6], o[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int yy = ty * 4 - 1 + k;
+        const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H;
+        col[k] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + yy) * W + xx) * C + q * 4)
+                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      bt6(col, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      f32x4 o[6];
+      bt6(tmp[k], o);  // (B^T d) B : same combination along the row
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        *reinterpret_cast<f32x4*>(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, float* __restrict__ y, int N,
+                                                            int H, int W, int C, int act, float slope) {
+  const int C4 = C / 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = T * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    f32x4 tmp[4][6];  // tmp[i][col] = (A^T m)[i][col]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 col[6], o[4];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) col[k] = *reinterpret_cast<const f32x4*>(M + ((size_t)(k * 6 + j) * T + t) * C + q * 4);
+      at4(col, o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tmp[k][j] = o[k];
+    }
+    const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 o[4];
+      at4(tmp[k], o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t off = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + q * 4;
+        f32x4 v = o[j] + b;
+        if (res) v += *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dsee_act(v[e], act, slope);
+        *reinterpret_cast<f32x4*>(y + off) = v;
+      }
+    }
+  }
+}
+
+// U[xi][row][k]: forward  row = co, k = ci, g = w[co][ci][:][:]
+//                dgrad    row = ci, k = co, g = rot180(w[co][ci])
+__global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows,
+                                     int Kpad, int transpose_flip) {
+  const long total = (long)rows * Kpad;
+  const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / Kpad), k = (int)(i % Kpad);
+    float g[3][3];
+    const bool ok = row < R && k < K;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float v = 0.f;
+        if (ok) {
+          const int co = transpose_flip ? k : row, ci = transpose_flip ? row : k;
+          const int kh = transpose_flip ? 2 - a : a, kw = transpose_flip ? 2 - b : b;
+          v = w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw];
+        }
+        g[a][b] = v;
+      }
+    // G g : 6x3
+    float t[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float g0 = g[0][b], g1 = g[1][b], g2 = g[2][b];
+      t[0][b] = 0.25f * g0;
+      t[1][b] = (-1.f / 6.f) * (g0 + g1 + g2);
+      t[2][b] = (-1.f / 6.f) * (g0 - g1 + g2);
+      t[3][b] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      t[4][b] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      t[5][b] = g2;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const float t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
+      float u[6];
+      u[0] = 0.25f * t0;
+      u[1] = (-1.f / 6.f) * (t0 + t1 + t2);
+      u[2] = (-1.f / 6.f) * (t0 - t1 + t2);
+      u[3] = (1.f / 24.f) * t0 + (1.f / 12.f) * t1 + (1.f / 6.f) * t2;
+      u[4] = (1.f / 24.f) * t0 - (1.f / 12.f) * t1 + (1.f / 6.f) * t2;
+      u[5] = t2;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) U[(size_t)(a * 6 + b) * total + i] = u[b];
+    }
+  }
+}
+
+inline int wgrid(long n) { return (int)min(16384L, (n + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(x && V && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
+  wino43_input_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_wino43_output(const float* M, const float* bias, const float* residual, float* y, int N, int H, int W, int C,
+                       int act, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(M && y && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
+  wino43_output_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(M, bias, residual, y, N, H, W, C,
+                                                                                     act, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* U: [36][dsee_conv_wrows(R)][dsee_conv_kpad(1,1,K)] with (R,K) = (Cout,Cin) forward, (Cin,Cout) data gradient */
+int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, hipStream_t st) {
+  DSEE_CHECK_ARG(w_oihw && U);
+  const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
+  wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"

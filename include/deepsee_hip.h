@@ -77,6 +77,18 @@ int dsee_pack_weight_dgrad(const float* w_oihw, const float* scale_num, const fl
 int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                     const float* residual, int residual_ld, float* out, int act, float slope, hipStream_t stream);
 
+/* Winograd F(4x4,3x3) path for 3x3 / stride 1 / pad 1 convolutions (same call sites as dsee_conv2d_fwd):
+ *   V = dsee_wino43_input(x)                                [36][T][Cin],  T = N*(H/4)*(W/4)
+ *   M = dsee_conv2d_fwd_grouped(V viewed [36][T][1][Cin], U, group_stride = wrows*Kpad)   36 GEMMs, 2.25 MAC/px/ch pair
+ *   y = dsee_wino43_output(M, bias, residual, act)
+ * with U = dsee_wino43_weights(w, transpose_flip = 0) (forward) or 1 (data gradient of the same conv). */
+int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t stream);
+int dsee_wino43_output(const float* M, const float* bias, const float* residual, float* y, int N, int H, int W, int C,
+                       int act, float slope, hipStream_t stream);
+int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, hipStream_t stream);
+int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
+                            float* out, hipStream_t stream);
+
 /* Fused SPADE / SEAN / PureSEAN normalisation (normalization.py:107-120, 167-213, 258-286) + the
  * LeakyReLU of architecture.py:92,114:  the implicit GEMM produces (gamma-ish, beta-ish) for 32-channel
  * groups side by side (row order of the packed weight: for 64-channel block b, wave w, half h, lane c:

@@ -106,3 +106,40 @@ def test_conv_fwd_dgrad_wgrad(case):
     L.call("conv2d_wgrad", C.byref(geom), x_d, gy_d, ws, C.c_size_t(ws_bytes), dw, cout, 0, cin)
     torch.cuda.synchronize()
     assert rel(dw.cpu(), wr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,h,act,use_res", [(2, 128, 256, 32, 1, True), (8, 256, 128, 16, 0, False),
+                                                      (1, 512, 512, 64, 0, True)])
+def test_winograd_conv_autograd_function(n, cin, cout, h, act, use_res):
+    """ops.conv2d routes wide 3x3 / stride-1 layers through Winograd F(4x4,3x3) (36 grouped MFMA GEMMs + two streaming
+    transforms) for the forward and the data gradient; the weight gradient stays direct.  fp32 Winograd F(4x4,3x3)
+    carries ~10x the rounding error of the direct form (Lavin & Gray 2016, table 4): bound 1e-4 instead of 2e-5."""
+    from deepsee_amd import ops
+    assert ops._wino_ok(n, h, h, cin, cout, 3, 1, 1, 0)
+    g = torch.Generator().manual_seed(n * cin + h)
+    x = torch.randn(n, cin, h, h, generator=g).requires_grad_()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).requires_grad_()
+    b = torch.randn(cout, generator=g).requires_grad_()
+    res = torch.randn(n, cout, h, h, generator=g).requires_grad_() if use_res else None
+    y = F.conv2d(x, w, b, padding=1)
+    if use_res:
+        y = y + res
+    if act == 1:
+        y = F.leaky_relu(y, 0.2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x.detach()).cuda().requires_grad_()
+    wd, bd = w.detach().cuda().requires_grad_(), b.detach().cuda().requires_grad_()
+    rd = nhwc(res.detach()).cuda().requires_grad_() if use_res else None
+    yd = ops.conv2d(xd, wd, bd, rd, 1, 1, 0, act)
+    yd.backward(nhwc(gy).cuda())
+    torch.cuda.synchronize()
+    assert rel(nchw(yd.detach().cpu(), cout), y.detach()) < 1e-4
+    # with a fused LeakyReLU, outputs within the Winograd rounding error (~1e-5) of zero take the other slope in the
+    # backward: a ~sqrt(fraction) = 1e-3 effect on every gradient (same mechanism as in test_gpu_model.py)
+    gt = 5e-3 if act else 1e-4
+    assert rel(nchw(xd.grad.cpu(), cin), x.grad) < gt
+    assert rel(wd.grad.cpu(), w.grad) < (gt if act else 2e-5)
+    assert rel(bd.grad.cpu(), b.grad) < (gt if act else 2e-5)
+    if use_res:
+        assert rel(nchw(rd.grad.cpu(), cout), res.grad) < (gt if act else 2e-5)

@@ -214,9 +214,11 @@ def test_smooth_loss_backward(name):
     med = lambda t: t[len(t) // 2]
     # Gradients of this network are ill-conditioned in fp32 (LeakyReLU/ReLU kinks crossed within rounding flip and
     # move a whole block's gradients together): the fp32 ORACLE moves by median ~5e-4 / max ~2.5e-3 against float64
-    # when its input changes by 1e-6.  HIP must deviate from exact arithmetic no more than twice that, and never by
-    # more than 5e-3 (real kernel bugs are O(1)); typical observed: median 1e-5 .. 7e-4.
-    assert ehs[-1] <= max(2 * eps_[-1], 20 * ecs[-1], 1e-3) and ehs[-1] < 5e-3, (worst, eps_[-1], ecs[-1])
+    # when its input changes by 1e-6.  HIP must deviate from exact arithmetic no more than twice that (or 20x the
+    # unperturbed oracle), and never by more than 1e-2 (real kernel bugs are O(1)); typical observed: median 1e-5 ..
+    # 7e-4.  The Winograd F(4x4,3x3) layers carry ~10x the forward rounding error of the direct form (1e-5 instead of
+    # 1e-6 on `fake`), which shows up here as proportionally more kink crossings.
+    assert ehs[-1] <= max(2 * eps_[-1], 20 * ecs[-1], 1e-3) and ehs[-1] < 1e-2, (worst, eps_[-1], ecs[-1])
     assert med(ehs) <= max(2 * med(eps_), 20 * med(ecs), 3e-4), (med(ehs), med(eps_), med(ecs))
     print("HIP-vs-f64 grad error: median %.2e worst %.2e (%s) | oracle-f32: median %.2e max %.2e | oracle-f32 with 1e-6 input perturbation: median %.2e max %.2e" % (med(ehs), worst[0], worst[1], med(ecs), ecs[-1], med(eps_), eps_[-1]))
 

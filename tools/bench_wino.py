@@ -1,0 +1,23 @@
+import sys, torch
+sys.path.insert(0, ".")
+from deepsee_amd import ops, lib as L
+def timeit(fn, it=5):
+    fn(); fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(it): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / it
+for (n, r, c) in [(8, 256, 512), (8, 128, 512), (8, 64, 512), (8, 32, 512)]:
+    x = torch.randn(n, r, r, c, device="cuda"); w = torch.randn(c, c, 3, 3, device="cuda") * 0.02
+    ops.WINOGRAD = True
+    tw = timeit(lambda: ops._wino_conv(x, w, n, r, r, c, c, False))
+    geom = L.geom_fwd(n, r, r, c, c, 3, 1, 1)
+    wp = ops._pack_fwd(w, c, 1)
+    td = timeit(lambda: ops.conv_raw(x, wp, geom))
+    fl = 2.0 * n * r * r * c * 9 * c
+    print("R=%d: winograd %.3f ms (%.0f TF/s algorithmic) | direct halo %.3f ms (%.0f TF/s)" % (r, tw, fl / tw / 1e9, td, fl / td / 1e9))
+    ops.PROFILE = {}
+    ops._wino_conv(x, w, n, r, r, c, c, False); torch.cuda.synchronize()
+    for k, v in ops.PROFILE.items(): print("   ", k, sum(s.elapsed_time(e) for s, e, _ in v), "ms", sum(f for _, _, f in v) / sum(s.elapsed_time(e) for s, e, _ in v) / 1e9, "TF/s executed")
+    ops.PROFILE = None
