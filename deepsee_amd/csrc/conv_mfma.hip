@@ -855,6 +855,41 @@ __global__ void wgrad_table_unpack_kernel(const float* __restrict__ slab, float*
   }
 }
 
+
+// Winograd F(4x4,3x3) weight gradient, last stage: dU[xi][co][ci] = sum_j slab[xi*sper + j][co][ci], then
+// dg = G^T dU G  -> dw OIHW [Cout][Cin][3][3]
+__global__ void wino43_wgrad_finalize_kernel(const float* __restrict__ slab, float* __restrict__ dw, int sper,
+                                             int rows, int Kpad, int Cout, int Cin) {
+  const long total = (long)Cout * Cin;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i / Cin), ci = (int)(i % Cin);
+    float t[3][6];  // G^T dU
+    {
+      float u[6][6];
+#pragma unroll
+      for (int xi = 0; xi < 36; ++xi) {
+        float v = 0.f;
+        for (int j = 0; j < sper; ++j) v += slab[((size_t)(xi * sper + j) * rows + co) * Kpad + ci];
+        u[xi / 6][xi % 6] = v;
+      }
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const float s12 = u[1][b] + u[2][b], d12 = u[1][b] - u[2][b], s34 = u[3][b] + u[4][b], d34 = u[3][b] - u[4][b];
+        t[0][b] = 0.25f * u[0][b] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        t[1][b] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+        t[2][b] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + u[5][b];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float s12 = t[a][1] + t[a][2], d12 = t[a][1] - t[a][2], s34 = t[a][3] + t[a][4], d34 = t[a][3] - t[a][4];
+      dw[i * 9 + a * 3 + 0] = 0.25f * t[a][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+      dw[i * 9 + a * 3 + 1] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+      dw[i * 9 + a * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[a][5];
+    }
+  }
+}
+
 template <int MT, int NT, int WM, int WN, int EPI, int GEO>
 int launch_conv_geo(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
@@ -1150,6 +1185,45 @@ int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const floa
   const long tt = (long)g->N * taps * a.rows * 32;
   wgrad_table_unpack_kernel<<<(int)min(4096L, (tt + 255) / 256), 256, 0, st>>>(
       workspace, dtable, g->N, sper, a.rows, a.Kpad, Cin_shared / 32 * taps * 32, taps, L);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+// split count per transform position for the Winograd weight gradient (36 * sper splits in all)
+static int wino_sper(long T, int Cin_s, int Cout_s) {
+  const int tiles = dsee_cdiv(dsee_conv_kpad(1, 1, Cin_s), 128) * dsee_cdiv(Cout_s, 128);
+  const int want = 3072 / (36 * tiles) > 1 ? 3072 / (36 * tiles) : 1;
+  int sper = 1;
+  while (sper * 2 <= want && T % (sper * 2) == 0 && (T / (sper * 2)) % 32 == 0 && T / (sper * 2) >= 512) sper *= 2;
+  return sper;
+}
+
+size_t dsee_wino43_wgrad_workspace(long T, int Cin_s, int Cout_s) {
+  return (size_t)36 * wino_sper(T, Cin_s, Cout_s) * Cout_s * dsee_conv_kpad(1, 1, Cin_s) * sizeof(float);
+}
+
+/* Weight gradient of a 3x3 / stride-1 / pad-1 convolution in the Winograd F(4x4,3x3) domain:
+ *   dU[xi] = dM[xi]^T V[xi]  (36 reductions over the T tiles, one split-K MFMA launch),  dw = G^T dU G.
+ * V  [36][T][Cin_s]  = dsee_wino43_input(x),  dM [36][T][Cout_s] = dsee_wino43_dout(dy);  T % 32 == 0. */
+int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw, long T,
+                      int Cin_s, int Cout_s, int Cout, int Cin, hipStream_t st) {
+  DSEE_CHECK_ARG(V && dM && workspace && dw_oihw && T % 32 == 0 && Cin_s % 4 == 0 && Cout_s % 4 == 0);
+  DSEE_CHECK_ARG(Cout <= Cout_s && Cin <= Cin_s && 36 * T < (1L << 31));
+  DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_workspace(T, Cin_s, Cout_s));
+  WgradArgs a = {};
+  a.dout = dM; a.in = V; a.slab = workspace;
+  a.N = 1; a.Hi = a.Ho = (int)(36 * T / 32); a.Wi = a.Wo = 32; a.Cin = Cin_s; a.Cout = Cout_s;
+  a.KH = a.KW = 1; a.Ktot = Cin_s; a.Kpad = dsee_conv_kpad(1, 1, Cin_s);
+  a.mul = 1; a.off = 0; a.kdir = 1; a.dshift = 0; a.ups = 0;
+  a.M = (int)(36 * T); a.rows = Cout_s;
+  a.korder = 0; a.Kuse = a.Ktot; a.Kstart = 0;
+  const int sper = wino_sper(T, Cin_s, Cout_s);
+  a.msplit = (int)(T / sper);
+  int rc = wgrad_launch(a, 36 * sper, st);
+  if (rc) return rc;
+  const long total = (long)Cout * Cin;
+  wino43_wgrad_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(workspace, dw_oihw, sper, a.rows,
+                                                                                     a.Kpad, Cout, Cin);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

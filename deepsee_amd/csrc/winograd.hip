@@ -68,6 +68,50 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
   }
 }
 
+// A d : 4 -> 6   (adjoint of at4)
+__device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
+  const f32x4 s02 = d[0] + d[2], s13 = d[1] + d[3], t02 = d[0] + 4.f * d[2], t13 = 2.f * d[1] + 8.f * d[3];
+  o[0] = d[0];
+  o[1] = s02 + s13;
+  o[2] = s02 - s13;
+  o[3] = t02 + t13;
+  o[4] = t02 - t13;
+  o[5] = d[3];
+}
+
+// dM[xi][t][c] = (A dY A^T)[xi] per 4x4 tile of the output gradient (adjoint of the output transform)
+__global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N,
+                                                          int H, int W, int C) {
+  const int C4 = C / 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = T * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    f32x4 tmp[6][4];  // tmp[row][col] = (A dY)[row][col]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 col[4], o[6];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        col[k] = *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + q * 4);
+      a6(col, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      f32x4 o[6];
+      a6(tmp[k], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             const float* __restrict__ res, float* __restrict__ y, int N,
                                                             int H, int W, int C, int act, float slope) {
@@ -166,6 +210,13 @@ extern "C" {
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(x && V && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   wino43_input_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dM && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
+  wino43_dout_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

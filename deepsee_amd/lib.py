@@ -39,7 +39,8 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.dsee_last_error.restype = C.c_char_p
         for fn in ("conv2d_wgrad_workspace", "conv2d_wgrad_table_workspace", "norm_workspace", "channel_dot_workspace",
-                   "onehot_conv3x3_wgrad_workspace", "label_segsum_workspace", "loss_workspace"):
+                   "onehot_conv3x3_wgrad_workspace", "label_segsum_workspace", "loss_workspace",
+                   "wino43_wgrad_workspace"):
             getattr(_lib, "dsee_" + fn).restype = C.c_size_t
     return _lib
 

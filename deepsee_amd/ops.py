@@ -189,6 +189,7 @@ def channel_dot(a, b, c):
 
 # ---- Winograd F(4x4,3x3) for the wide 3x3 / stride-1 layers (4x fewer fp32 MACs than the direct form)
 WINOGRAD = True
+WINOGRAD_WGRAD = True
 
 
 def _wino_ok(n, h, w, cin_s, cout_s, k, stride, pad, ups):
@@ -214,6 +215,21 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     y = new(n, h, wd, r_s)
     L.call("wino43_output", m, bias, res, y, n, h, wd, r_s, act, LRELU_SLOPE)
     return y
+
+
+def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci):
+    """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain."""
+    t = n * (h // 4) * (wd // 4)
+    v = new(36, t, cin_s)
+    L.call("wino43_input", x, v, n, h, wd, cin_s)
+    dm = new(36, t, cout_s)
+    L.call("wino43_dout", g, dm, n, h, wd, cout_s)
+    nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(t), cin_s, cout_s)
+    ws = scratch(nbytes, "wgrad")
+    dw = new(co, ci, 3, 3)
+    with _timed("winograd_wgrad_128x128(36 groups)", 2.0 * 36 * t * cin_s * cout_s):
+        L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci)
+    return dw
 
 
 class Conv2d(torch.autograd.Function):
@@ -258,7 +274,9 @@ class Conv2d(torch.autograd.Function):
                 L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
             else:
                 dx = dxl
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
+            dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci)
+        elif ctx.needs_input_grad[1]:
             dw = wgrad_raw(x, g, geom, co, ci, kh, kw)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = channel_dot(g, None, co).clone()

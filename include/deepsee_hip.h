@@ -88,6 +88,14 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, hipStream_t stream);
 int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
                             float* out, hipStream_t stream);
+/* Weight gradient of the same convs in the Winograd domain (backward of architecture.py:98,122):
+ *   dM = dsee_wino43_dout(dy) = A dY A^T  [36][T][Cout_s];  V = dsee_wino43_input(x);
+ *   dsee_wino43_wgrad: dU[xi] = dM[xi]^T V[xi] (one split-K MFMA launch over 36 groups), dw = G^T dU G  (OIHW).
+ * T % 32 == 0; workspace from dsee_wino43_wgrad_workspace. */
+int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hipStream_t stream);
+size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
+int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
+                      long T, int Cin_stored, int Cout_stored, int Cout, int Cin, hipStream_t stream);
 
 /* Fused SPADE / SEAN / PureSEAN normalisation (normalization.py:107-120, 167-213, 258-286) + the
  * LeakyReLU of architecture.py:92,114:  the implicit GEMM produces (gamma-ish, beta-ish) for 32-channel

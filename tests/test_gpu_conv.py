@@ -112,7 +112,7 @@ def test_conv_fwd_dgrad_wgrad(case):
                                                       (1, 512, 512, 64, 0, True)])
 def test_winograd_conv_autograd_function(n, cin, cout, h, act, use_res):
     """ops.conv2d routes wide 3x3 / stride-1 layers through Winograd F(4x4,3x3) (36 grouped MFMA GEMMs + two streaming
-    transforms) for the forward and the data gradient; the weight gradient stays direct.  fp32 Winograd F(4x4,3x3)
+    transforms) for the forward, the data gradient and (split-K over tiles, dw = G^T dU G) the weight gradient.  fp32 F(4x4,3x3)
     carries ~10x the rounding error of the direct form (Lavin & Gray 2016, table 4): bound 1e-4 instead of 2e-5."""
     from deepsee_amd import ops
     assert ops._wino_ok(n, h, h, cin, cout, 3, 1, 1, 0)
@@ -139,7 +139,7 @@ def test_winograd_conv_autograd_function(n, cin, cout, h, act, use_res):
     # backward: a ~sqrt(fraction) = 1e-3 effect on every gradient (same mechanism as in test_gpu_model.py)
     gt = 5e-3 if act else 1e-4
     assert rel(nchw(xd.grad.cpu(), cin), x.grad) < gt
-    assert rel(wd.grad.cpu(), w.grad) < (gt if act else 2e-5)
+    assert rel(wd.grad.cpu(), w.grad) < gt
     assert rel(bd.grad.cpu(), b.grad) < (gt if act else 2e-5)
     if use_res:
         assert rel(nchw(rd.grad.cpu(), cout), res.grad) < (gt if act else 2e-5)

@@ -21,3 +21,9 @@ for (n, r, c) in [(8, 256, 512), (8, 128, 512), (8, 64, 512), (8, 32, 512)]:
     ops._wino_conv(x, w, n, r, r, c, c, False); torch.cuda.synchronize()
     for k, v in ops.PROFILE.items(): print("   ", k, sum(s.elapsed_time(e) for s, e, _ in v), "ms", sum(f for _, _, f in v) / sum(s.elapsed_time(e) for s, e, _ in v) / 1e9, "TF/s executed")
     ops.PROFILE = None
+
+    g = torch.randn(n, r, r, c, device="cuda")
+    tw = timeit(lambda: ops._wino_wgrad(x, g, n, r, r, c, c, c, c))
+    td = timeit(lambda: ops.wgrad_raw(x, g, geom, c, c, 3, 3))
+    a, b = ops._wino_wgrad(x, g, n, r, r, c, c, c, c), ops.wgrad_raw(x, g, geom, c, c, 3, 3)
+    print("R=%d wgrad: winograd %.3f ms (%.0f TF/s algorithmic) | direct %.3f ms (%.0f TF/s) | rel diff %.2e" % (r, tw, fl / tw / 1e9, td, fl / td / 1e9, ((a - b).norm() / b.norm()).item()))
