@@ -890,6 +890,55 @@ __global__ void wino43_wgrad_finalize_kernel(const float* __restrict__ slab, flo
   }
 }
 
+// Same for the SEAN gamma/beta GEMM with per-image groups (slab index ((xi*N + n)*sper + j)): shared columns k < ca are
+// summed over images into dw2a [rows][ca][3][3]; one-hot columns per image into dtable [N][9][rows][32].
+__global__ void wino43_wgrad_table_finalize_kernel(const float* __restrict__ slab, float* __restrict__ dw2a,
+                                                   float* __restrict__ dtable, int N, int sper, int rows, int Kpad,
+                                                   int ca, int L) {
+  const long total = (long)rows * (ca + 32);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / (ca + 32)), k = (int)(i % (ca + 32));
+    const bool shared = k < ca;
+    float acc[36];
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] = 0.f;
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+      for (int xi = 0; xi < 36; ++xi) {
+        float v = 0.f;
+        for (int j = 0; j < sper; ++j) v += slab[((size_t)((xi * N + n) * sper + j) * rows + row) * Kpad + k];
+        acc[xi] = shared ? acc[xi] + v : v;
+      }
+      if (shared && n + 1 < N) continue;
+      float t[3][6], dg[9];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const float u0 = acc[b], u1 = acc[6 + b], u2 = acc[12 + b], u3 = acc[18 + b], u4 = acc[24 + b], u5 = acc[30 + b];
+        const float s12 = u1 + u2, d12 = u1 - u2, s34 = u3 + u4, d34 = u3 - u4;
+        t[0][b] = 0.25f * u0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        t[1][b] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+        t[2][b] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + u5;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float s12 = t[a][1] + t[a][2], d12 = t[a][1] - t[a][2], s34 = t[a][3] + t[a][4], d34 = t[a][3] - t[a][4];
+        dg[a * 3 + 0] = 0.25f * t[a][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        dg[a * 3 + 1] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+        dg[a * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[a][5];
+      }
+      if (shared) {
+        if (dw2a)
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) dw2a[((size_t)row * ca + k) * 9 + tap] = dg[tap];
+      } else {
+        const int r = k - ca;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) dtable[(((size_t)n * 9 + tap) * rows + row) * 32 + r] = r < L ? dg[tap] : 0.f;
+      }
+    }
+  }
+}
+
 template <int MT, int NT, int WM, int WN, int EPI, int GEO>
 int launch_conv_geo(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
@@ -1224,6 +1273,37 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
   const long total = (long)Cout * Cin;
   wino43_wgrad_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(workspace, dw_oihw, sper, a.rows,
                                                                                      a.Kpad, Cout, Cin);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows) {
+  return (size_t)36 * N * wino_sper(T / N, ca + 32, rows) * rows * dsee_conv_kpad(1, 1, ca + 32) * sizeof(float);
+}
+
+/* Weight gradient of the SEAN gamma/beta GEMM in the Winograd domain (per-image groups, see dsee_wino43_weights_table):
+ * V [36][T][ca+32] = dsee_wino43_input(cat), dM [36][T][rows] = dsee_wino43_dout(dgb), tiles image-major (T/N each,
+ * multiple of 32).  Writes dw2a [rows][ca][3][3] (NULL / ca == 0: skipped) and dtable [N][9][rows][32]. */
+int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
+                            float* dtable, long T, int N, int ca, int rows, int L, hipStream_t st) {
+  DSEE_CHECK_ARG(V && dM && workspace && dtable && N > 0 && T % N == 0 && (T / N) % 32 == 0 && ca % 32 == 0);
+  DSEE_CHECK_ARG(rows % 4 == 0 && L <= 32 && 36 * T < (1L << 31));
+  DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_table_workspace(T, N, ca, rows));
+  const int ld = ca + 32;
+  WgradArgs a = {};
+  a.dout = dM; a.in = V; a.slab = workspace;
+  a.N = 1; a.Hi = a.Ho = (int)(36 * T / 32); a.Wi = a.Wo = 32; a.Cin = ld; a.Cout = rows;
+  a.KH = a.KW = 1; a.Ktot = ld; a.Kpad = dsee_conv_kpad(1, 1, ld);
+  a.mul = 1; a.off = 0; a.kdir = 1; a.dshift = 0; a.ups = 0;
+  a.M = (int)(36 * T); a.rows = rows;
+  a.korder = 0; a.Kuse = a.Ktot; a.Kstart = 0;
+  const int sper = wino_sper(T / N, ld, rows);
+  a.msplit = (int)(T / N / sper);
+  int rc = wgrad_launch(a, 36 * N * sper, st);
+  if (rc) return rc;
+  const long total = (long)rows * ld;
+  wino43_wgrad_table_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
+      workspace, ca > 0 ? dw2a : nullptr, dtable, N, sper, rows, a.Kpad, ca, L);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-                                                            const float* __restrict__ res, float* __restrict__ y, int N,
-                                                            int H, int W, int C, int act, float slope) {
+                                                            const float* __restrict__ res, int res_ld,
+                                                            float* __restrict__ y, int N, int H, int W, int C, int act,
+                                                            float slope) {
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -140,14 +141,125 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
       at4(tmp[k], o);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const size_t off = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + q * 4;
+        const size_t px = ((size_t)n * H + ty * 4 + k) * W + tx * 4 + j, off = px * C + q * 4;
         f32x4 v = o[j] + b;
-        if (res) v += *reinterpret_cast<const f32x4*>(res + off);
+        if (act == DSEE_ACT_MASK) {  // backward of a ReLU whose output is `res`
+          const f32x4 m = *reinterpret_cast<const f32x4*>(res + px * res_ld + q * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = dsee_act(v[e], act, slope);
+          for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+        } else {
+          if (res) v += *reinterpret_cast<const f32x4*>(res + px * res_ld + q * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = dsee_act(v[e], act, slope);
+        }
         *reinterpret_cast<f32x4*>(y + off) = v;
       }
     }
+  }
+}
+
+// 4x4 output tile of one channel quad: y[k][j] = (A^T m A)[k][j], m[xi] read at column `col` of M [36][T][ld]
+__device__ __forceinline__ void out_tile(const float* __restrict__ M, long T, long t, int ld, int col,
+                                         f32x4 (&y)[4][4]) {
+  f32x4 tmp[4][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    f32x4 c6[6], o[4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = *reinterpret_cast<const f32x4*>(M + ((size_t)(k * 6 + j) * T + t) * ld + col);
+    at4(c6, o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tmp[k][j] = o[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) at4(tmp[k], y[k]);
+}
+
+// Output transform of the gamma/beta GEMM fused with the SPADE/SEAN modulate + LeakyReLU (same arithmetic as the
+// EPI_MODULATE epilogue of conv_mfma.hip; packed column of channel c: (c/64)*128 + ((c%64)/32)*64 + c%32, beta +32)
+__global__ __launch_bounds__(256) void wino43_output_modulate_kernel(
+    const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ out,
+    float* __restrict__ scale, int N, int H, int W, int C, int rows, float add_one, float slope) {
+  const int C4 = C / 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = T * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4), c = q * 4;
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    const int pg = (c >> 6) * 128 + ((c & 63) >> 5) * 64 + (c & 31);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bg = bias ? *reinterpret_cast<const f32x4*>(bias + pg) : z4;
+    const f32x4 bb = bias ? *reinterpret_cast<const f32x4*>(bias + pg + 32) : z4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    f32x4 yg[4][4], yb[4][4];
+    out_tile(M, T, t, rows, pg, yg);
+    out_tile(M, T, t, rows, pg + 32, yb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t off = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + c;
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + off) - mu) * is;
+        const f32x4 sc = yg[k][j] + bg + add_one;
+        f32x4 v = xh * sc + (yb[k][j] + bb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        *reinterpret_cast<f32x4*>(scale + off) = sc;
+        *reinterpret_cast<f32x4*>(out + off) = v;
+      }
+  }
+}
+
+// G g G^T of one 3x3 filter -> u[36]
+__device__ __forceinline__ void ggt(const float (&g)[3][3], float (&u)[36]) {
+  float t[6][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const float g0 = g[0][b], g1 = g[1][b], g2 = g[2][b];
+    t[0][b] = 0.25f * g0;
+    t[1][b] = (-1.f / 6.f) * (g0 + g1 + g2);
+    t[2][b] = (-1.f / 6.f) * (g0 - g1 + g2);
+    t[3][b] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    t[4][b] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    t[5][b] = g2;
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const float t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
+    u[a * 6 + 0] = 0.25f * t0;
+    u[a * 6 + 1] = (-1.f / 6.f) * (t0 + t1 + t2);
+    u[a * 6 + 2] = (-1.f / 6.f) * (t0 - t1 + t2);
+    u[a * 6 + 3] = (1.f / 24.f) * t0 + (1.f / 12.f) * t1 + (1.f / 6.f) * t2;
+    u[a * 6 + 4] = (1.f / 24.f) * t0 - (1.f / 12.f) * t1 + (1.f / 6.f) * t2;
+    u[a * 6 + 5] = t2;
+  }
+}
+
+// per-image weights of the SEAN gamma/beta GEMM in the Winograd domain:
+// U[xi][n][row][k] = G g G^T,  g = w2a[row][k][:][:] (k < ca, shared)  |  table[n][tap][row][k - ca] (one-hot chunk)
+__global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const float* __restrict__ table,
+                                           float* __restrict__ U, int N, int rows, int ca, int Kpad) {
+  const long per = (long)rows * Kpad, total = (long)N * per;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kpad);
+    const long rr = i / Kpad;
+    const int row = (int)(rr % rows), n = (int)(rr / rows);
+    float g[3][3], u[36];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      float v = 0.f;
+      if (k < ca)
+        v = w2a[((size_t)row * ca + k) * 9 + tap];
+      else if (k < ca + 32)
+        v = table[(((size_t)n * 9 + tap) * rows + row) * 32 + (k - ca)];
+      g[tap / 3][tap % 3] = v;
+    }
+    ggt(g, u);
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) U[(size_t)xi * total + i] = u[xi];
   }
 }
 
@@ -221,11 +333,13 @@ int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hip
   return DSEE_OK;
 }
 
-int dsee_wino43_output(const float* M, const float* bias, const float* residual, float* y, int N, int H, int W, int C,
-                       int act, float slope, hipStream_t st) {
+int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
+                       int H, int W, int C, int act, float slope, hipStream_t st) {
   DSEE_CHECK_ARG(M && y && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_output_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(M, bias, residual, y, N, H, W, C,
-                                                                                     act, slope);
+  DSEE_CHECK_ARG(act != DSEE_ACT_MASK || residual);
+  DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
+  wino43_output_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(M, bias, residual, residual_ld, y, N,
+                                                                                     H, W, C, act, slope);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -236,6 +350,26 @@ int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int tr
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
   wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const float* x, const float* mean,
+                                const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
+                                int rows, float add_one, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(M && x && mean && invstd && out_h && out_scale && C % 64 == 0 && rows == 2 * C);
+  DSEE_CHECK_ARG(H % 4 == 0 && W % 4 == 0);
+  wino43_output_modulate_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+      M, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W, C, rows, add_one, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* U: [36][N][rows][Kpad(ca + 32)], rows % 128 == 0; w2a [rows][ca][3][3] (NULL if ca == 0), table [N][9][rows][32] */
+int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, hipStream_t st) {
+  DSEE_CHECK_ARG(table && U && (ca == 0 || w2a) && ca % 32 == 0 && rows % 128 == 0);
+  const int Kpad = dsee_conv_kpad(1, 1, ca + 32);
+  wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

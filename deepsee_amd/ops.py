@@ -190,46 +190,77 @@ def channel_dot(a, b, c):
 # ---- Winograd F(4x4,3x3) for the wide 3x3 / stride-1 layers (4x fewer fp32 MACs than the direct form)
 WINOGRAD = True
 WINOGRAD_WGRAD = True
+WINOGRAD_MOD = True
+
+
+def _wino_chunk(n, h, w, cmax, per_image=False):
+    """Images per Winograd pass: the transformed tensors [36][T][C] are addressed with 32-bit byte offsets, and a
+    128-row GEMM tile must not straddle two groups (transform positions; with per_image also images)."""
+    if h % 4 or w % 4:
+        return None
+    tpi = (h // 4) * (w // 4)
+    for nb in range(n, 0, -1):
+        if n % nb == 0 and 36 * nb * tpi * cmax * 4 < 0xF0000000 and ((tpi if per_image else nb * tpi) % 128 == 0):
+            return nb
+    return None
+
+
+def _wino_mod_chunk(n, h, w, c, rows, per_image):
+    """Images per pass of the Winograd gamma/beta GEMM (None: use the direct kernel)."""
+    if not (WINOGRAD and WINOGRAD_MOD and c % 64 == 0 and rows == 2 * c and rows % 128 == 0):
+        return None
+    return _wino_chunk(n, h, w, rows, per_image)
 
 
 def _wino_ok(n, h, w, cin_s, cout_s, k, stride, pad, ups):
     return (WINOGRAD and k == 3 and stride == 1 and pad == 1 and ups == 0 and cin_s % 32 == 0 and cout_s % 128 == 0
-            and cin_s >= 128 and h % 4 == 0 and w % 4 == 0 and (n * h * w) % 2048 == 0
-            and 36 * (n * h * w // 16) * max(cin_s, cout_s) * 4 < 0xF0000000)
+            and cin_s >= 128 and _wino_chunk(n, h, w, max(cin_s, cout_s)) is not None)
 
 
-def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE):
+def _wino_gemm(v, u, groups, t_g, k_s, r_s, gstride):
+    m = new(groups, t_g, r_s)
+    g = L.ConvGeom(groups, t_g, 1, k_s, t_g, 1, r_s, 1, 1, 1, 0, 1, 0, 0, 1)
+    with _timed("winograd_gemm_128x128(igemm,36 groups)", 2.0 * groups * t_g * k_s * r_s):
+        L.call("conv2d_fwd_grouped", C.byref(g), v, u, C.c_long(gstride), m)
+    return m
+
+
+def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0):
     """y = conv3x3(x, w) (transpose_flip: data gradient of that conv) through 36 Winograd-domain GEMMs."""
     co, ci = w.shape[0], w.shape[1]
     r_s, k_s = (cin_s, cout_s) if transpose_flip else (cout_s, cin_s)   # GEMM output / reduction channels
-    t = n * (h // 4) * (wd // 4)
     rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
     u = new(36, rows, kp)
     L.call("wino43_weights", w, u, co, ci, int(transpose_flip))
-    v = new(36, t, k_s)
-    L.call("wino43_input", x, v, n, h, wd, k_s)
-    m = new(36, t, r_s)
-    g = L.ConvGeom(36, t, 1, k_s, t, 1, r_s, 1, 1, 1, 0, 1, 0, 0, 1)
-    with _timed("winograd_gemm_128x128(igemm,36 groups)", 2.0 * 36 * t * k_s * r_s):
-        L.call("conv2d_fwd_grouped", C.byref(g), v, u, C.c_long(rows * kp), m)
     y = new(n, h, wd, r_s)
-    L.call("wino43_output", m, bias, res, y, n, h, wd, r_s, act, LRELU_SLOPE)
+    nb = _wino_chunk(n, h, wd, max(r_s, k_s))
+    t = nb * (h // 4) * (wd // 4)
+    for n0 in range(0, n, nb):
+        v = new(36, t, k_s)
+        L.call("wino43_input", x[n0:n0 + nb], v, nb, h, wd, k_s)
+        m = _wino_gemm(v, u, 36, t, k_s, r_s, rows * kp)
+        L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
+               r_s, act, LRELU_SLOPE)
     return y
 
 
 def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci):
     """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain."""
-    t = n * (h // 4) * (wd // 4)
-    v = new(36, t, cin_s)
-    L.call("wino43_input", x, v, n, h, wd, cin_s)
-    dm = new(36, t, cout_s)
-    L.call("wino43_dout", g, dm, n, h, wd, cout_s)
+    nb = _wino_chunk(n, h, wd, max(cin_s, cout_s))
+    t = nb * (h // 4) * (wd // 4)
     nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(t), cin_s, cout_s)
     ws = scratch(nbytes, "wgrad")
-    dw = new(co, ci, 3, 3)
-    with _timed("winograd_wgrad_128x128(36 groups)", 2.0 * 36 * t * cin_s * cout_s):
-        L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci)
-    return dw
+    total = None
+    for n0 in range(0, n, nb):
+        v = new(36, t, cin_s)
+        L.call("wino43_input", x[n0:n0 + nb], v, nb, h, wd, cin_s)
+        dm = new(36, t, cout_s)
+        L.call("wino43_dout", g[n0:n0 + nb], dm, nb, h, wd, cout_s)
+        dw = new(co, ci, 3, 3)
+        with _timed("winograd_wgrad_128x128(36 groups)", 2.0 * 36 * t * cin_s * cout_s):
+            L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci)
+        total = dw if total is None else total.add_(dw)
+    return total
 
 
 class Conv2d(torch.autograd.Function):
@@ -575,15 +606,33 @@ class SeanNormTable(torch.autograd.Function):
             L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
         geom = L.geom_fwd(n, h, w, ld, rows, 3, 1, 1, 0)
         assert geom.korder == 1
-        wp = None
         if has_a:
             w2a = w2a.contiguous()
-            wp = _pack_fwd(w2a, ca, 1)
         tb = table.contiguous() if has_t else None
         out, scale = torch.empty_like(x), torch.empty_like(x)
-        with _timed(_variant(geom, True), _flops(geom)):
-            L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, tb, ca, b2.contiguous(), x, mean, invstd, out, scale, c,
-                   float(add_one), LRELU_SLOPE)
+        nb = ctx.wino_nb = _wino_mod_chunk(n, h, w, c, rows, has_t)
+        if nb:
+            tpi = (h // 4) * (w // 4)
+            kp = L.kpad(1, 1, ld)
+            b2c = b2.contiguous()
+            for n0 in range(0, n, nb):
+                v = new(36, nb * tpi, ld)
+                L.call("wino43_input", cat[n0:n0 + nb], v, nb, h, w, ld)
+                if has_t:
+                    u = new(36, nb, rows, kp)
+                    L.call("wino43_weights_table", w2a if has_a else None, tb[n0:n0 + nb], u, nb, rows, ca)
+                    m = _wino_gemm(v, u, 36 * nb, tpi, ld, rows, rows * kp)
+                else:
+                    u = new(36, rows, kp)
+                    L.call("wino43_weights", w2a, u, rows, ca, 0)
+                    m = _wino_gemm(v, u, 36, nb * tpi, ld, rows, rows * kp)
+                L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
+                       scale[n0:n0 + nb], nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
+        else:
+            wp = _pack_fwd(w2a, ca, 1) if has_a else None
+            with _timed(_variant(geom, True), _flops(geom)):
+                L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, tb, ca, b2.contiguous(), x, mean, invstd, out,
+                       scale, c, float(add_one), LRELU_SLOPE)
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
         ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd)
         return out
@@ -604,20 +653,50 @@ class SeanNormTable(torch.autograd.Function):
         if ctx.has_a:
             # data gradient only w.r.t. the 128 embedding channels (the one-hot channels need none)
             ga = L.ConvGeom(n, h, w, rows, h, w, NHIDDEN, 3, 3, 1, 1, -1, 0, 0, 1)
+            wino_d = ctx.wino_nb and _wino_chunk(n, h, w, rows) is not None
             if ctx.has_t:
                 # ReLU backward fused into the dgrad epilogue; the gradient of mlp_shared (a conv over the one-hot
                 # label) is then the weight gradient w.r.t. the one-hot channels already sitting in `cat` (MFMA)
-                dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga, None, cat, L.ACT_MASK, res_ld=ld)
+                if wino_d:
+                    dactv = _wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True, None, cat, L.ACT_MASK, res_ld=ld)
+                else:
+                    dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga, None, cat, L.ACT_MASK, res_ld=ld)
                 gs = L.geom_fwd(n, h, w, ld, NHIDDEN, 3, 1, 1, 0)
                 dw_sh = wgrad_raw(cat, dactv, gs, NHIDDEN, lab.nc, 3, 3, cin_first=NHIDDEN)
                 db_sh = channel_dot(dactv, None, NHIDDEN).clone()
             else:
-                dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga)
+                dactv = (_wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True) if wino_d
+                         else conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga))
                 dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
                 wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
                 L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw_sh,
                        db_sh, wso)
-        if ctx.has_t:
+        nb = ctx.wino_nb
+        if nb and (ctx.has_t or ctx.needs_input_grad[3]):
+            # weight gradient in the Winograd domain: groups (xi, image), shared columns summed over images
+            tpi, ca = (h // 4) * (w // 4), (NHIDDEN if ctx.has_a else 0)
+            if ctx.has_t:
+                nbytes = L.lib().dsee_wino43_wgrad_table_workspace(C.c_long(nb * tpi), nb, ca, rows)
+                dtable = new(n, 9, rows, 32)
+            else:
+                nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(nb * tpi), ld, rows)
+            wsw = scratch(nbytes, "wgrad")
+            for n0 in range(0, n, nb):
+                v = new(36, nb * tpi, ld)
+                L.call("wino43_input", cat[n0:n0 + nb], v, nb, h, w, ld)
+                dm = new(36, nb * tpi, rows)
+                L.call("wino43_dout", dgb[n0:n0 + nb], dm, nb, h, w, rows)
+                dwc = new(rows, NHIDDEN, 3, 3) if ctx.has_a else None
+                with _timed("winograd_wgrad_128x128(36 groups)", 2.0 * 36 * nb * tpi * ld * rows):
+                    if ctx.has_t:
+                        L.call("wino43_wgrad_table", v, dm, wsw, C.c_size_t(nbytes), dwc, dtable[n0:n0 + nb],
+                               C.c_long(nb * tpi), nb, ca, rows, lab.nc)
+                    else:
+                        L.call("wino43_wgrad", v, dm, wsw, C.c_size_t(nbytes), dwc, C.c_long(nb * tpi), ld, rows, rows,
+                               NHIDDEN)
+                if dwc is not None:
+                    dw2a = dwc if dw2a is None else dw2a.add_(dwc)
+        elif ctx.has_t:
             # one split-K launch (image-aligned splits): shared columns -> dw2a, one-hot columns per image -> dtable
             nbytes = L.lib().dsee_conv2d_wgrad_table_workspace(C.byref(geom))
             wsw = scratch(nbytes, "wgrad")

@@ -83,8 +83,8 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
  *   y = dsee_wino43_output(M, bias, residual, act)
  * with U = dsee_wino43_weights(w, transpose_flip = 0) (forward) or 1 (data gradient of the same conv). */
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t stream);
-int dsee_wino43_output(const float* M, const float* bias, const float* residual, float* y, int N, int H, int W, int C,
-                       int act, float slope, hipStream_t stream);
+int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
+                       int H, int W, int C, int act, float slope, hipStream_t stream);
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, hipStream_t stream);
 int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
                             float* out, hipStream_t stream);
@@ -92,6 +92,19 @@ int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const floa
  *   dM = dsee_wino43_dout(dy) = A dY A^T  [36][T][Cout_s];  V = dsee_wino43_input(x);
  *   dsee_wino43_wgrad: dU[xi] = dM[xi]^T V[xi] (one split-K MFMA launch over 36 groups), dw = G^T dU G  (OIHW).
  * T % 32 == 0; workspace from dsee_wino43_wgrad_workspace. */
+/* SEAN / SPADE gamma-beta GEMM (normalization.py:107-120,167-213,258-286) in the Winograd domain:
+ *   U  = dsee_wino43_weights_table(w2a, table)   [36][N][rows][ca+32]  per-image weights (style tables)
+ *   M  = dsee_conv2d_fwd_grouped(V = wino43_input(cat), U)   with 36*N groups of T/N tiles
+ *   h, scale = dsee_wino43_output_modulate(M, ...)   output transform + BN-normalise + modulate + LeakyReLU
+ * backward: dsee_wino43_wgrad_table (dw2a, dtable) and the plain Winograd data gradient with a ReLU-mask epilogue. */
+int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const float* x, const float* mean,
+                                const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
+                                int rows, float add_one, float slope, hipStream_t stream);
+int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca,
+                              hipStream_t stream);
+size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
+int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
+                            float* dtable, long T, int N, int ca, int rows, int L, hipStream_t stream);
 int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hipStream_t stream);
 size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,

@@ -105,9 +105,13 @@ def test_spade_sean_norm_fwd_bwd(kind, C, R, N):
             assert rel(p[k].grad.cpu(), v.grad) < 1e-4, k
 
 
-@pytest.mark.parametrize("kind,C,R,N", [("spade", 64, 16, 2), ("sean", 64, 16, 2), ("sean", 128, 32, 3), ("puresean", 64, 16, 2)])
+@pytest.mark.parametrize("kind,C,R,N", [("spade", 64, 16, 2), ("sean", 64, 16, 2), ("sean", 128, 32, 3), ("puresean", 64, 16, 2),
+                                        ("spade", 64, 64, 2), ("sean", 64, 64, 2), ("sean", 128, 64, 3), ("puresean", 64, 64, 2)])
 def test_sean_norm_table_path(kind, C, R, N):
-    """The production path for R >= 16: style half as per-image one-hot tables (K = 1440 instead of 2304)."""
+    """The production path for R >= 16: style half as per-image one-hot tables (K = 1440 instead of 2304).  From R = 64
+    the gamma/beta GEMM, its data gradient and its weight/table gradient run in the Winograd F(4x4,3x3) domain with
+    (transform position, image) groups: ~10x the fp32 rounding error of the direct form, and the ReLU / LeakyReLU
+    masks taken from values within that error of zero flip (a sqrt(fraction) effect on the gradients)."""
     from deepsee_amd import ops, networks as Nw
     from types import SimpleNamespace
     g = gen(7 * C + R + N)
@@ -128,20 +132,23 @@ def test_sean_norm_table_path(kind, C, R, N):
     labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
     xs = nhwc(x.detach()).requires_grad_()
     sty = style.detach().cuda().requires_grad_()
+    wino = ops._wino_mod_chunk(N, R, R, C, 2 * C, kind != "spade") is not None
+    assert wino == (R >= 64)
     h = mod(xs, labels, sty, True)
     h.backward(nhwc(gy))
     torch.cuda.synchronize()
-    assert rel(nchw(h.detach(), C), y.detach()) < TOL
-    assert rel(nchw(xs.grad, C), x.grad) < 5 * TOL
+    ft, gt = (1e-4, 5e-3) if wino else (TOL, 2e-4)
+    assert rel(nchw(h.detach(), C), y.detach()) < ft
+    assert rel(nchw(xs.grad, C), x.grad) < (gt if wino else 5 * TOL)
     assert rel(mod.param_free_norm.running_var.cpu(), P["n.param_free_norm.running_var"]) < TOL
     if kind != "spade":
-        assert rel(sty.grad.cpu(), style.grad) < 1e-4
+        assert rel(sty.grad.cpu(), style.grad) < (gt if wino else 1e-4)
     for k, p in mod.named_parameters():
         ref = P["n." + k].grad
         if ref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
         else:
-            assert rel(p.grad.cpu(), ref) < 2e-4, k
+            assert rel(p.grad.cpu(), ref) < gt, k
 
 
 @pytest.mark.parametrize("act", [1, 3])
