@@ -1241,7 +1241,7 @@ int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const floa
 // split count per transform position for the Winograd weight gradient (36 * sper splits in all)
 static int wino_sper(long T, int Cin_s, int Cout_s) {
   const int tiles = dsee_cdiv(dsee_conv_kpad(1, 1, Cin_s), 128) * dsee_cdiv(Cout_s, 128);
-  const int want = 3072 / (36 * tiles) > 1 ? 3072 / (36 * tiles) : 1;
+  const int want = 4608 / (36 * tiles) > 1 ? 4608 / (36 * tiles) : 1;
   int sper = 1;
   while (sper * 2 <= want && T % (sper * 2) == 0 && (T / (sper * 2)) % 32 == 0 && T / (sper * 2) >= 512) sper *= 2;
   return sper;
@@ -1255,10 +1255,22 @@ size_t dsee_wino43_wgrad_workspace(long T, int Cin_s, int Cout_s) {
  *   dU[xi] = dM[xi]^T V[xi]  (36 reductions over the T tiles, one split-K MFMA launch),  dw = G^T dU G.
  * V  [36][T][Cin_s]  = dsee_wino43_input(x),  dM [36][T][Cout_s] = dsee_wino43_dout(dy);  T % 32 == 0. */
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw, long T,
-                      int Cin_s, int Cout_s, int Cout, int Cin, hipStream_t st) {
+                      int Cin_s, int Cout_s, int Cout, int Cin, int split, hipStream_t st) {
   DSEE_CHECK_ARG(V && dM && workspace && dw_oihw && T % 32 == 0 && Cin_s % 4 == 0 && Cout_s % 4 == 0);
   DSEE_CHECK_ARG(Cout <= Cout_s && Cin <= Cin_s && 36 * T < (1L << 31));
   DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_workspace(T, Cin_s, Cout_s));
+  if (split) {
+    // operands are the transposed bf16x3 layouts of dsee_wino43_dout_split_t / dsee_wino43_input_split_t
+    DSEE_CHECK_ARG(Cout_s % 128 == 0 && Cin_s % 32 == 0);
+    const int sper = wino_sper(T, Cin_s, Cout_s), Kpad = dsee_conv_kpad(1, 1, Cin_s);
+    int rc = dsee_gemm_bf16x3_tn(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st);
+    if (rc) return rc;
+    const long total = (long)Cout * Cin;
+    wino43_wgrad_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(workspace, dw_oihw, sper,
+                                                                                       Cout_s, Kpad, Cout, Cin);
+    DSEE_LAUNCH_CHECK();
+    return DSEE_OK;
+  }
   WgradArgs a = {};
   a.dout = dM; a.in = V; a.slab = workspace;
   a.N = 1; a.Hi = a.Ho = (int)(36 * T / 32); a.Wi = a.Wo = 32; a.Cin = Cin_s; a.Cout = Cout_s;
@@ -1285,11 +1297,22 @@ size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows) {
  * V [36][T][ca+32] = dsee_wino43_input(cat), dM [36][T][rows] = dsee_wino43_dout(dgb), tiles image-major (T/N each,
  * multiple of 32).  Writes dw2a [rows][ca][3][3] (NULL / ca == 0: skipped) and dtable [N][9][rows][32]. */
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
-                            float* dtable, long T, int N, int ca, int rows, int L, hipStream_t st) {
+                            float* dtable, long T, int N, int ca, int rows, int L, int split, hipStream_t st) {
   DSEE_CHECK_ARG(V && dM && workspace && dtable && N > 0 && T % N == 0 && (T / N) % 32 == 0 && ca % 32 == 0);
   DSEE_CHECK_ARG(rows % 4 == 0 && L <= 32 && 36 * T < (1L << 31));
   DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_table_workspace(T, N, ca, rows));
   const int ld = ca + 32;
+  if (split) {
+    DSEE_CHECK_ARG(rows % 128 == 0);
+    const int sper = wino_sper(T / N, ld, rows), Kpad = dsee_conv_kpad(1, 1, ld);
+    int rc = dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
+    if (rc) return rc;
+    const long total = (long)rows * ld;
+    wino43_wgrad_table_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
+        workspace, ca > 0 ? dw2a : nullptr, dtable, N, sper, rows, Kpad, ca, L);
+    DSEE_LAUNCH_CHECK();
+    return DSEE_OK;
+  }
   WgradArgs a = {};
   a.dout = dM; a.in = V; a.slab = workspace;
   a.N = 1; a.Hi = a.Ho = (int)(36 * T / 32); a.Wi = a.Wo = 32; a.Cin = ld; a.Cout = rows;

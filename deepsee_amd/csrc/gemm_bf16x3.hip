@@ -1,0 +1,248 @@
+// fp32 GEMM on the bf16 matrix cores by operand splitting ("bf16x3"): every fp32 operand is written by its producer
+// as three bf16 terms  x = x0 + x1 + x2  (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); 3 x 8 significand
+// bits + signs cover the 24-bit fp32 significand, so the split is EXACT), and the product is accumulated in fp32 from
+// the six partial products whose weight is above 2^-26:
+//     a*b ~= a2*b0 + a1*b1 + a0*b2 + a1*b0 + a0*b1 + a0*b0        (dropped: a1*b2 + a2*b1 + a2*b2 <= 2^-26 |a||b|)
+// Every bf16 x bf16 product is exact in fp32, so the result carries LESS rounding error than a chain of fp32 FMAs
+// (measured against float64 in tests/test_gpu_conv.py), while v_mfma_f32_32x32x16_bf16 runs at 16x the rate of
+// v_mfma_f32_32x32x2_f32 on gfx950: 6 bf16 MFMAs per 16 k's instead of 8 fp32 MFMAs per 16 k's at 1/16 the rate
+// = 2.67x the fp32-MFMA peak (2516 / 6 = 419 TFLOP/s fp32-equivalent).
+//
+// Used for the Winograd-domain GEMMs (winograd.hip produces the split operands directly):
+//   C[m][n] = sum_k A[m][k] * B[group(m)][n][k],   C: [M][N] fp32, group(m) = m / rows_per_group,
+//   A3: [K/16][M][3][16] bf16,  B3: [groups][K/16][rowsB][3][16] bf16   ("slab-major": the 16-k slab of a row tile is
+//   ONE contiguous block of rows x 96 B, so every cache line fetched is used whole, once).
+// Kernel: BK = 16 slabs, two LDS stages of [(BM+BN) rows][3 terms][16 k] (+16 B pad: 112 B rows, conflict-free
+// ds_read_b128 fragments), register-staged buffer loads (per-thread offsets fixed, buffer base advanced per slab),
+// operands swapped in the MFMA so that a lane ends up with 4 consecutive n per row m -> 16-byte stores.
+#include <stdlib.h>
+
+#include "dsee_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Gemm3Args {
+  const unsigned char* A;
+  const unsigned char* B;
+  float* C;
+  long M;      // rows of A (per z)
+  int N, K;    // valid columns (= rows of B), reduction length per z (multiple of 16)
+  int ldc;     // row stride of C
+  long rows_per_group;               // grouped mode: rows m / rows_per_group select the B matrix
+  long b_group_bytes;
+  long a_slab_bytes, b_slab_bytes;   // distance between consecutive 16-k slabs
+  long a_z_bytes, b_z_bytes, c_z_elems;  // blockIdx.y (batch / split-K index) offsets
+  int abl;
+};
+
+constexpr int ROWB = 112;  // LDS bytes per row per stage: 3 terms x 16 k x 2 B + 16 B pad
+
+// FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `part`, which is then folded into `acc`
+// (long reductions of the weight gradients: keeps the fp32 accumulation error at the blocked-sum level).
+template <int WM, int WN, int MT, int NT, int FL>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_kernel(Gemm3Args a) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64;
+  constexpr int ACH = BM * 6 / NTHR, BCH = BN * 6 / NTHR;  // 16-byte chunks per thread per slab
+  static_assert(BM * 6 % NTHR == 0 && BN * 6 % NTHR == 0, "uniform A/B chunk split");
+  constexpr int STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  // XCD-aware tile order (speed only): hardware puts workgroup b on XCD b % 8; give each XCD a contiguous range of
+  // logical tiles, N tiles of one M tile adjacent, so blocks sharing A rows meet in one L2.
+  long bm;
+  int bn;
+  {
+    const int nbn = (a.N + BN - 1) / BN;
+    const long total = gridDim.x, b = blockIdx.x;
+    const long q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+    const long l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bn = (int)(l % nbn);
+    bm = l / nbn;
+  }
+  const long group = (bm * BM) / a.rows_per_group;
+  // slab kt of this tile: A rows [bm*BM, +BM) at a.A + (kt*M + bm*BM)*96; B rows at a.B + group + (kt*b_rows + bn*BN)*96
+  const long z = blockIdx.y;
+  const unsigned char* pa = a.A + z * a.a_z_bytes + bm * BM * 96;
+  const unsigned char* pb = a.B + z * a.b_z_bytes + group * a.b_group_bytes + (long)bn * BN * 96;
+  const long sa = a.a_slab_bytes, sb_ = a.b_slab_bytes;
+  const int bvalid = min(BN, a.N - bn * BN) * 96;  // rows of B past N read as zeros (buffer range check)
+
+  unsigned voff[ACH + BCH], loff[ACH + BCH];
+#pragma unroll
+  for (int j = 0; j < ACH + BCH; ++j) {
+    const int q = tid + NTHR * (j < ACH ? j : j - ACH);
+    const int row = q / 6, c = q % 6;
+    voff[j] = (unsigned)(q * 16);
+    loff[j] = (unsigned)(((j < ACH ? 0 : BM) + row) * ROWB + c * 16);
+  }
+  const int nk = a.K / 16;
+  u32x4 st[ACH + BCH];
+  auto gload = [&](int kt) {
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + kt * sa), 0, BM * 96, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + kt * sb_), 0, bvalid, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff[j], 0, 0);
+#pragma unroll
+    for (int j = ACH; j < ACH + BCH; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff[j], 0, 0);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < ACH + BCH; ++j) *reinterpret_cast<u32x4*>(smem + buf * STAGE + loff[j]) = st[j];
+  };
+
+  f32x16 acc[MT][NT], tot[FL > 0 ? MT : 1][FL > 0 ? NT : 1];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (FL > 0) tot[i][j][r] = 0.f;
+      }
+
+  // fragment addresses: lane (row = lane & 31, k-half = lane >> 5) reads the 8 k's of its half for each term
+  const unsigned fa = (unsigned)((wm * MT * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16);
+  const unsigned fb = (unsigned)((BM + wn * NT * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16);
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  gload(min(1, nk - 1));
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* sb = smem + ((a.abl & 16) ? 0 : cur * STAGE);
+    bf16x8 af[MT][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + fa + i * 32 * ROWB + p * 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * 32 * ROWB + p * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        // smallest terms first; B fragment is the MFMA "A" operand so that acc rows run along n
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[2], af[i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][0], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(a.abl & 2)) lstore(cur ^ 1);  // slab kt+1 (requested one slab ago)
+    if (!(a.abl & 32)) __syncthreads();
+    if (!(a.abl & 1)) gload(min(kt + 2, nk - 1));  // branch-free: past the end the last slab is fetched again
+    cur ^= 1;
+    if constexpr (FL > 0) {
+      if ((kt & (FL - 1)) == FL - 1 || kt + 1 == nk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            tot[i][j] += acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+      }
+    }
+  }
+  if constexpr (FL > 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = tot[i][j];
+  }
+
+  if (a.abl & 8) {
+    if (acc[0][0][0] == 12345.678f) a.C[0] = 1.f;
+    return;
+  }
+  // epilogue: D[n][m] layout -> lane holds, for each 8-row group g, n = 8g + 4*(lane>>5) + 0..3 of column m = lane&31
+  float* cz = a.C + z * a.c_z_elems;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const long m = bm * BM + wm * MT * 32 + i * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n0 = bn * BN + wn * NT * 32 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (n0 + 8 * g < a.N) *reinterpret_cast<f32x4*>(cz + m * a.ldc + n0 + 8 * g) = v;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int MT, int NT, int FL>
+int launch_gemm3(const Gemm3Args& a, int nz, hipStream_t st) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  const size_t lds = (size_t)2 * (BM + BN) * ROWB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<WM, WN, MT, NT, FL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const long tiles = (a.M / BM) * ((a.N + BN - 1) / BN);
+  gemm3_kernel<WM, WN, MT, NT, FL><<<dim3((unsigned)tiles, (unsigned)nz), WM * WN * 64, lds, st>>>(a);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* C[m][n] = sum_k A[m][k] * B[m / rows_per_group][n][k]  in fp32 accuracy from bf16x3-split operands.
+ * A3 [K/16][M][3][16] bf16, B3 [groups][K/16][b_rows][3][16] bf16 (b_rows >= N rows per group), C [M][N] fp32.
+ * M, rows_per_group multiples of 128; N multiple of 128; K multiple of 16.
+ * tile: 0 = automatic, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves). */
+int dsee_gemm_bf16x3(const void* A3, const void* B3, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                     int tile, hipStream_t st) {
+  DSEE_CHECK_ARG(A3 && B3 && C && M > 0 && N > 0 && K > 0 && K % 16 == 0 && N % 128 == 0 && M % 128 == 0);
+  DSEE_CHECK_ARG(rows_per_group % 128 == 0 && M % rows_per_group == 0 && b_rows >= N);
+  Gemm3Args a = {};
+  { const char* e = getenv("DSEE_G3_ABL"); a.abl = e ? atoi(e) : 0; }
+  a.A = (const unsigned char*)A3; a.B = (const unsigned char*)B3; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.ldc = N; a.rows_per_group = rows_per_group;
+  a.b_group_bytes = (long)b_rows * K * 6; a.a_slab_bytes = M * 96; a.b_slab_bytes = (long)b_rows * 96;
+  const bool big_ok = rows_per_group % 256 == 0 && N % 256 == 0;
+  if (tile == 0) tile = (big_ok && (M / 256) * (N / 256) >= 512) ? 2 : 1;
+  if (tile == 2) {
+    DSEE_CHECK_ARG(big_ok);
+    return launch_gemm3<2, 4, 4, 2, 0>(a, 1, st);
+  }
+  return launch_gemm3<2, 2, 2, 2, 0>(a, 1, st);
+}
+
+/* Batched, split-K "TN" product for weight gradients: for z = (group g, split s), g < groups, s < splits,
+ *   C[z][i][j] = sum over the T/splits tiles t of split s of  P[g][t][i] * Q[g][t][j]
+ * P3t [groups][T/16][rows_p][3][16 t] bf16, Q3t [groups][T/16][rows_q][3][16 t] bf16 (the transposed split layout
+ * written by dsee_wino43_dout_split_t / dsee_wino43_input_split_t), C [groups*splits][rows_p][ldc] fp32.
+ * rows_p % 128 == 0, rows_q % 4 == 0, (T/16) % splits == 0. */
+int dsee_gemm_bf16x3_tn(const void* P3t, const void* Q3t, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                        int splits, hipStream_t st) {
+  DSEE_CHECK_ARG(P3t && Q3t && C && groups > 0 && T % 16 == 0 && rows_p % 128 == 0 && rows_q % 4 == 0);
+  DSEE_CHECK_ARG(splits > 0 && (T / 16) % splits == 0 && ldc >= rows_q);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)P3t; a.B = (const unsigned char*)Q3t; a.C = C;
+  const long nk = T / 16 / splits;
+  a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p; a.b_group_bytes = 0;
+  a.a_slab_bytes = (long)rows_p * 96; a.b_slab_bytes = (long)rows_q * 96;
+  a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
+  // 128x128 tiles (two blocks per CU, registers to spare for the second accumulator level)
+  return launch_gemm3<2, 2, 2, 2, 16>(a, groups * splits, st);
+}
+
+}  // extern "C"

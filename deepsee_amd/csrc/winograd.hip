@@ -12,6 +12,32 @@
 
 namespace {
 
+// bf16x3 split of fp32 values (gemm_bf16x3.hip): x = x0 + x1 + x2 exactly, each term a bf16
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float x, unsigned short (&h)[3]) {
+  const __bf16 b0 = (__bf16)x;
+  const float r1 = x - (float)b0;
+  const __bf16 b1 = (__bf16)r1;
+  const __bf16 b2 = (__bf16)(r1 - (float)b1);
+  h[0] = __builtin_bit_cast(unsigned short, b0);
+  h[1] = __builtin_bit_cast(unsigned short, b1);
+  h[2] = __builtin_bit_cast(unsigned short, b2);
+}
+// element (row, k) term p of a slab-major split matrix [K/16][rows][3][16]
+__device__ __forceinline__ size_t split_index(size_t row, int k, size_t rows, int p) {
+  return (((size_t)(k >> 4) * rows + row) * 3 + p) * 16 + (k & 15);
+}
+__device__ __forceinline__ void store_split4(unsigned short* base, size_t row, int k, size_t rows, const f32x4& v) {
+  unsigned short h[4][3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3(v[e], h[e]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const u16x4 w = {h[0][p], h[1][p], h[2][p], h[3][p]};
+    *reinterpret_cast<u16x4*>(base + split_index(row, k, rows, p)) = w;
+  }
+}
+
 // one column / row of B^T d : 6 -> 6
 __device__ __forceinline__ void bt6(const f32x4 (&d)[6], f32x4 (&o)[6]) {
   o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
@@ -31,13 +57,62 @@ __device__ __forceinline__ void at4(const f32x4 (&m)[6], f32x4 (&o)[4]) {
   o[3] = d12 + 8.f * d34 + m[5];
 }
 
+// Output modes of the transform kernels: fp32 rows | bf16x3 slab-major with k = channel (forward / data-gradient GEMM
+// operands) | bf16x3 slab-major with k = tile (weight-gradient operands, [xi][T/16][C][3][16 tiles])
+constexpr int OUT_F32 = 0, OUT_SPLIT = 1, OUT_SPLIT_T = 2;
+
+// split modes: a wave = 16 consecutive tiles x one 16-channel slab (T % 16 == 0, C % 16 == 0), lane = (tile l>>2,
+// channel quad l&3); its three term stores then fill 1536 contiguous bytes of either split layout
+__device__ __forceinline__ void wave_tile_quad(long i, int C4, int& q, long& t) {
+  const int C16 = C4 >> 2;
+  const long w = i >> 6;
+  const int l = (int)(i & 63);
+  q = (int)(w % C16) * 4 + (l & 3);
+  t = (w / C16) * 16 + (l >> 2);
+}
+
+// OUT_SPLIT_T: transpose the wave's 16 tiles x 16 channels through LDS so that lane (channel l>>2, tile quad l&3)
+// holds 4 consecutive tiles of one channel, then split and store 8 bytes per term
+__device__ __forceinline__ void emit_split_t(float* tb, unsigned short* base, int xi, long T, int C, long i,
+                                             const f32x4& o) {
+  const int l = (int)(i & 63), C16 = C >> 4;
+  const long w = i >> 6;
+  const int ch0 = (int)(w % C16) * 16;
+  const long tblk = w / C16;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) tb[(4 * (l & 3) + e) * 20 + (l >> 2)] = o[e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (l >> 2) * 20 + 4 * (l & 3));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  unsigned short h[4][3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3(v[e], h[e]);
+  const size_t row = ((size_t)xi * (T >> 4) + tblk) * C + ch0 + (l >> 2);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const u16x4 wv = {h[0][p], h[1][p], h[2][p], h[3][p]};
+    *reinterpret_cast<u16x4*>(base + (row * 3 + p) * 16 + 4 * (l & 3)) = wv;
+  }
+}
+
+template <int OUT>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N,
                                                            int H, int W, int C) {
+  __shared__ __attribute__((aligned(16))) float tbuf[OUT == OUT_SPLIT_T ? 4 : 1][16 * 20];
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    const long t = i / C4;
+    int q;
+    long t;
+    if constexpr (OUT != OUT_F32) {
+      wave_tile_quad(i, C4, q, t);
+    } else {
+      q = (int)(i % C4);
+      t = i / C4;
+    }
     const int tx = (int)(t % tw);
     const long r = t / tw;
     const int ty = (int)(r % th), n = (int)(r / th);
@@ -62,8 +137,14 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
       f32x4 o[6];
       bt6(tmp[k], o);  // (B^T d) B : same combination along the row
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
-        *reinterpret_cast<f32x4*>(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+      for (int j = 0; j < 6; ++j) {
+        if constexpr (OUT == OUT_SPLIT)
+          store_split4(reinterpret_cast<unsigned short*>(V), (size_t)(k * 6 + j) * T + t, q * 4, (size_t)36 * T, o[j]);
+        else if constexpr (OUT == OUT_SPLIT_T)
+          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(V), k * 6 + j, T, C, i, o[j]);
+        else
+          *reinterpret_cast<f32x4*>(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+      }
     }
   }
 }
@@ -80,13 +161,21 @@ __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
 }
 
 // dM[xi][t][c] = (A dY A^T)[xi] per 4x4 tile of the output gradient (adjoint of the output transform)
+template <int OUT>
 __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N,
                                                           int H, int W, int C) {
+  __shared__ __attribute__((aligned(16))) float tbuf[OUT == OUT_SPLIT_T ? 4 : 1][16 * 20];
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    const long t = i / C4;
+    int q;
+    long t;
+    if constexpr (OUT != OUT_F32) {
+      wave_tile_quad(i, C4, q, t);
+    } else {
+      q = (int)(i % C4);
+      t = i / C4;
+    }
     const int tx = (int)(t % tw);
     const long r = t / tw;
     const int ty = (int)(r % th), n = (int)(r / th);
@@ -106,8 +195,12 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
       f32x4 o[6];
       a6(tmp[k], o);
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
-        *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+      for (int j = 0; j < 6; ++j) {
+        if constexpr (OUT == OUT_SPLIT_T)
+          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, i, o[j]);
+        else
+          *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+      }
     }
   }
 }
@@ -241,7 +334,7 @@ __device__ __forceinline__ void ggt(const float (&g)[3][3], float (&u)[36]) {
 // per-image weights of the SEAN gamma/beta GEMM in the Winograd domain:
 // U[xi][n][row][k] = G g G^T,  g = w2a[row][k][:][:] (k < ca, shared)  |  table[n][tap][row][k - ca] (one-hot chunk)
 __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const float* __restrict__ table,
-                                           float* __restrict__ U, int N, int rows, int ca, int Kpad) {
+                                           float* __restrict__ U, int N, int rows, int ca, int Kpad, int split) {
   const long per = (long)rows * Kpad, total = (long)N * per;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % Kpad);
@@ -259,14 +352,24 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
     }
     ggt(g, u);
 #pragma unroll
-    for (int xi = 0; xi < 36; ++xi) U[(size_t)xi * total + i] = u[xi];
+    for (int xi = 0; xi < 36; ++xi) {
+      if (split) {
+        unsigned short h[3];
+        split3(u[xi], h);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          reinterpret_cast<unsigned short*>(U)[((size_t)xi * N + n) * per * 3 + split_index(row, k, rows, p)] = h[p];
+      } else {
+        U[(size_t)xi * total + i] = u[xi];
+      }
+    }
   }
 }
 
 // U[xi][row][k]: forward  row = co, k = ci, g = w[co][ci][:][:]
 //                dgrad    row = ci, k = co, g = rot180(w[co][ci])
 __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows,
-                                     int Kpad, int transpose_flip) {
+                                     int Kpad, int transpose_flip, int split) {
   const long total = (long)rows * Kpad;
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -308,7 +411,17 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
       u[4] = (1.f / 24.f) * t0 - (1.f / 12.f) * t1 + (1.f / 6.f) * t2;
       u[5] = t2;
 #pragma unroll
-      for (int b = 0; b < 6; ++b) U[(size_t)(a * 6 + b) * total + i] = u[b];
+      for (int b = 0; b < 6; ++b) {
+        if (split) {
+          unsigned short h[3];
+          split3(u[b], h);
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            reinterpret_cast<unsigned short*>(U)[(size_t)(a * 6 + b) * total * 3 + split_index(row, k, rows, p)] = h[p];
+        } else {
+          U[(size_t)(a * 6 + b) * total + i] = u[b];
+        }
+      }
     }
   }
 }
@@ -321,14 +434,40 @@ extern "C" {
 
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(x && V && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_input_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C);
+  wino43_input_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* same transform, output as bf16x3-split rows for dsee_gemm_bf16x3: V3 [C/16][36*T][3][16] bf16 (C % 16 == 0) */
+int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(x && V3 && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
+  wino43_input_kernel<OUT_SPLIT><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+      x, reinterpret_cast<float*>(V3), N, H, W, C);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
 int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dM && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_dout_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C);
+  wino43_dout_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* weight-gradient operands for dsee_gemm_bf16x3_tn: [36][T/16][C][3][16 tiles] bf16 (T % 16 == 0, C % 16 == 0) */
+int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(x && V3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
+  wino43_input_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+      x, reinterpret_cast<float*>(V3t), N, H, W, C);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dM3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
+  wino43_dout_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+      dy, reinterpret_cast<float*>(dM3t), N, H, W, C);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -345,11 +484,13 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
 }
 
 /* U: [36][dsee_conv_wrows(R)][dsee_conv_kpad(1,1,K)] with (R,K) = (Cout,Cin) forward, (Cin,Cout) data gradient */
-int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, hipStream_t st) {
+int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
+                        hipStream_t st) {
   DSEE_CHECK_ARG(w_oihw && U);
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
-  wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip);
+  wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip,
+                                                                 split);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -366,10 +507,11 @@ int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const 
 }
 
 /* U: [36][N][rows][Kpad(ca + 32)], rows % 128 == 0; w2a [rows][ca][3][3] (NULL if ca == 0), table [N][9][rows][32] */
-int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, hipStream_t st) {
+int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, int split,
+                              hipStream_t st) {
   DSEE_CHECK_ARG(table && U && (ca == 0 || w2a) && ca % 32 == 0 && rows % 128 == 0);
   const int Kpad = dsee_conv_kpad(1, 1, ca + 32);
-  wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad);
+  wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad, split);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -5,6 +5,7 @@ PyTorch supplies allocation, the stream and the autograd graph; every activation
 is a hand-written HIP kernel in libdeepsee_hip.so.  There is no CPU / ATen fallback: without the
 library these functions raise.
 """
+import os
 import ctypes as C
 
 import torch
@@ -191,6 +192,9 @@ def channel_dot(a, b, c):
 WINOGRAD = True
 WINOGRAD_WGRAD = True
 WINOGRAD_MOD = True
+# fp32 GEMMs of the Winograd domain on the bf16 matrix cores via exact 3-term operand splitting (gemm_bf16x3.hip);
+# DSEE_F32_MFMA=1 keeps them on v_mfma_f32_32x32x2_f32
+GEMM_SPLIT = os.environ.get("DSEE_F32_MFMA", "0") != "1"
 
 
 def _wino_chunk(n, h, w, cmax, per_image=False):
@@ -217,11 +221,38 @@ def _wino_ok(n, h, w, cin_s, cout_s, k, stride, pad, ups):
             and cin_s >= 128 and _wino_chunk(n, h, w, max(cin_s, cout_s)) is not None)
 
 
-def _wino_gemm(v, u, groups, t_g, k_s, r_s, gstride):
-    m = new(groups, t_g, r_s)
-    g = L.ConvGeom(groups, t_g, 1, k_s, t_g, 1, r_s, 1, 1, 1, 0, 1, 0, 0, 1)
-    with _timed("winograd_gemm_128x128(igemm,36 groups)", 2.0 * groups * t_g * k_s * r_s):
-        L.call("conv2d_fwd_grouped", C.byref(g), v, u, C.c_long(gstride), m)
+def _split_ok(k_s, r_s):
+    return GEMM_SPLIT and k_s % 32 == 0 and r_s % 128 == 0
+
+
+def _i16(n):
+    return torch.empty(n, dtype=torch.int16, device="cuda")
+
+
+def _wino_u(w, co, ci, transpose_flip, rows, kp, split):
+    """Winograd-domain weights U [36][rows][kp]: fp32, or bf16x3-split rows for the bf16 matrix cores."""
+    u = _i16(36 * rows * kp * 3) if split else new(36, rows, kp)
+    L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split))
+    return u
+
+
+def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split):
+    """M [36][t][r_s] = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs."""
+    tpi = (h // 4) * (wd // 4)
+    t = nb * tpi
+    groups, t_g = (36 * nb, tpi) if per_image else (36, t)
+    m = new(36, t, r_s)
+    if split:
+        v = _i16(36 * t * k_s * 3)
+        L.call("wino43_input_split", xc, v, nb, h, wd, k_s)
+        with _timed("winograd_gemm_bf16x3", 2.0 * 36 * t * k_s * r_s):
+            L.call("gemm_bf16x3", v, u, m, C.c_long(36 * t), r_s, k_s, C.c_long(t_g), rows, 0)
+    else:
+        v = new(36, t, k_s)
+        L.call("wino43_input", xc, v, nb, h, wd, k_s)
+        g = L.ConvGeom(groups, t_g, 1, k_s, t_g, 1, r_s, 1, 1, 1, 0, 1, 0, 0, 1)
+        with _timed("winograd_gemm_128x128(igemm,36 groups)", 2.0 * 36 * t * k_s * r_s):
+            L.call("conv2d_fwd_grouped", C.byref(g), v, u, C.c_long(rows * kp), m)
     return m
 
 
@@ -230,35 +261,45 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     co, ci = w.shape[0], w.shape[1]
     r_s, k_s = (cin_s, cout_s) if transpose_flip else (cout_s, cin_s)   # GEMM output / reduction channels
     rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
-    u = new(36, rows, kp)
-    L.call("wino43_weights", w, u, co, ci, int(transpose_flip))
+    split = _split_ok(k_s, r_s)
+    u = _wino_u(w, co, ci, transpose_flip, rows, kp, split)
     y = new(n, h, wd, r_s)
     nb = _wino_chunk(n, h, wd, max(r_s, k_s))
-    t = nb * (h // 4) * (wd // 4)
     for n0 in range(0, n, nb):
-        v = new(36, t, k_s)
-        L.call("wino43_input", x[n0:n0 + nb], v, nb, h, wd, k_s)
-        m = _wino_gemm(v, u, 36, t, k_s, r_s, rows * kp)
+        m = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split)
         L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
                r_s, act, LRELU_SLOPE)
     return y
+
+
+def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, split):
+    """(V, dM) of one image chunk for the Winograd-domain weight gradient (fp32 rows, or transposed bf16x3)."""
+    t = nb * (h // 4) * (wd // 4)
+    if split:
+        v, dm = _i16(36 * t * cin_s * 3), _i16(36 * t * cout_s * 3)
+        L.call("wino43_input_split_t", xc, v, nb, h, wd, cin_s)
+        L.call("wino43_dout_split_t", gc, dm, nb, h, wd, cout_s)
+    else:
+        v, dm = new(36, t, cin_s), new(36, t, cout_s)
+        L.call("wino43_input", xc, v, nb, h, wd, cin_s)
+        L.call("wino43_dout", gc, dm, nb, h, wd, cout_s)
+    return v, dm
 
 
 def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci):
     """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain."""
     nb = _wino_chunk(n, h, wd, max(cin_s, cout_s))
     t = nb * (h // 4) * (wd // 4)
+    split = GEMM_SPLIT and cout_s % 128 == 0 and cin_s % 32 == 0
     nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(t), cin_s, cout_s)
     ws = scratch(nbytes, "wgrad")
     total = None
     for n0 in range(0, n, nb):
-        v = new(36, t, cin_s)
-        L.call("wino43_input", x[n0:n0 + nb], v, nb, h, wd, cin_s)
-        dm = new(36, t, cout_s)
-        L.call("wino43_dout", g[n0:n0 + nb], dm, nb, h, wd, cout_s)
+        v, dm = _wino_wgrad_operands(x[n0:n0 + nb], g[n0:n0 + nb], nb, h, wd, cin_s, cout_s, split)
         dw = new(co, ci, 3, 3)
-        with _timed("winograd_wgrad_128x128(36 groups)", 2.0 * 36 * t * cin_s * cout_s):
-            L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci)
+        with _timed("winograd_wgrad_bf16x3" if split else "winograd_wgrad_128x128(36 groups)",
+                    2.0 * 36 * t * cin_s * cout_s):
+            L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci, int(split))
         total = dw if total is None else total.add_(dw)
     return total
 
@@ -615,17 +656,14 @@ class SeanNormTable(torch.autograd.Function):
             tpi = (h // 4) * (w // 4)
             kp = L.kpad(1, 1, ld)
             b2c = b2.contiguous()
+            split = _split_ok(ld, rows)
             for n0 in range(0, n, nb):
-                v = new(36, nb * tpi, ld)
-                L.call("wino43_input", cat[n0:n0 + nb], v, nb, h, w, ld)
                 if has_t:
-                    u = new(36, nb, rows, kp)
-                    L.call("wino43_weights_table", w2a if has_a else None, tb[n0:n0 + nb], u, nb, rows, ca)
-                    m = _wino_gemm(v, u, 36 * nb, tpi, ld, rows, rows * kp)
+                    u = _i16(36 * nb * rows * kp * 3) if split else new(36, nb, rows, kp)
+                    L.call("wino43_weights_table", w2a if has_a else None, tb[n0:n0 + nb], u, nb, rows, ca, int(split))
                 else:
-                    u = new(36, rows, kp)
-                    L.call("wino43_weights", w2a, u, rows, ca, 0)
-                    m = _wino_gemm(v, u, 36, nb * tpi, ld, rows, rows * kp)
+                    u = _wino_u(w2a, rows, ca, False, rows, kp, split)
+                m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split)
                 L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
                        scale[n0:n0 + nb], nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
         else:
@@ -681,19 +719,18 @@ class SeanNormTable(torch.autograd.Function):
             else:
                 nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(nb * tpi), ld, rows)
             wsw = scratch(nbytes, "wgrad")
+            split = GEMM_SPLIT and rows % 128 == 0 and ld % 32 == 0
             for n0 in range(0, n, nb):
-                v = new(36, nb * tpi, ld)
-                L.call("wino43_input", cat[n0:n0 + nb], v, nb, h, w, ld)
-                dm = new(36, nb * tpi, rows)
-                L.call("wino43_dout", dgb[n0:n0 + nb], dm, nb, h, w, rows)
+                v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], dgb[n0:n0 + nb], nb, h, w, ld, rows, split)
                 dwc = new(rows, NHIDDEN, 3, 3) if ctx.has_a else None
-                with _timed("winograd_wgrad_128x128(36 groups)", 2.0 * 36 * nb * tpi * ld * rows):
+                with _timed("winograd_wgrad_bf16x3" if split else "winograd_wgrad_128x128(36 groups)",
+                            2.0 * 36 * nb * tpi * ld * rows):
                     if ctx.has_t:
                         L.call("wino43_wgrad_table", v, dm, wsw, C.c_size_t(nbytes), dwc, dtable[n0:n0 + nb],
-                               C.c_long(nb * tpi), nb, ca, rows, lab.nc)
+                               C.c_long(nb * tpi), nb, ca, rows, lab.nc, int(split))
                     else:
                         L.call("wino43_wgrad", v, dm, wsw, C.c_size_t(nbytes), dwc, C.c_long(nb * tpi), ld, rows, rows,
-                               NHIDDEN)
+                               NHIDDEN, int(split))
                 if dwc is not None:
                     dw2a = dwc if dw2a is None else dw2a.add_(dwc)
         elif ctx.has_t:

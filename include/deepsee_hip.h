@@ -85,7 +85,15 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t stream);
 int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
                        int H, int W, int C, int act, float slope, hipStream_t stream);
-int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, hipStream_t stream);
+int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
+                        hipStream_t stream);
+/* fp32-accurate GEMM on the bf16 matrix cores (operands split into three bf16 terms by their producers, six MFMA
+ * products accumulated in fp32; see deepsee_amd/csrc/gemm_bf16x3.hip).  With `split` the producers write slab-major
+ * [K/16][rows][3][16] bf16 (1.5x the fp32 bytes) instead of fp32 rows:
+ *   C[m][n] = sum_k A[m][k] * B[m / rows_per_group][n][k],  A3 [K/16][M][3][16], B3 [groups][K/16][b_rows][3][16]. */
+int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C, hipStream_t stream);
+int dsee_gemm_bf16x3(const void* A3, const void* B3, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                     int tile, hipStream_t stream);
 int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
                             float* out, hipStream_t stream);
 /* Weight gradient of the same convs in the Winograd domain (backward of architecture.py:98,122):
@@ -100,15 +108,21 @@ int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const floa
 int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const float* x, const float* mean,
                                 const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
                                 int rows, float add_one, float slope, hipStream_t stream);
-int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca,
+int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, int split,
                               hipStream_t stream);
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
-                            float* dtable, long T, int N, int ca, int rows, int L, hipStream_t stream);
+                            float* dtable, long T, int N, int ca, int rows, int L, int split, hipStream_t stream);
 int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hipStream_t stream);
 size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
-                      long T, int Cin_stored, int Cout_stored, int Cout, int Cin, hipStream_t stream);
+                      long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, hipStream_t stream);
+/* split = 1: V / dM are the transposed bf16x3 operands [36][T/16][C][3][16 tiles] written by the two producers below
+ * and the reduction over tiles runs on the bf16 matrix cores (dsee_gemm_bf16x3_tn, fp32-accurate). */
+int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, int C, hipStream_t stream);
+int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, int C, hipStream_t stream);
+int dsee_gemm_bf16x3_tn(const void* P3t, const void* Q3t, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                        int splits, hipStream_t stream);
 
 /* Fused SPADE / SEAN / PureSEAN normalisation (normalization.py:107-120, 167-213, 258-286) + the
  * LeakyReLU of architecture.py:92,114:  the implicit GEMM produces (gamma-ish, beta-ish) for 32-channel

@@ -143,3 +143,40 @@ def test_winograd_conv_autograd_function(n, cin, cout, h, act, use_res):
     assert rel(bd.grad.cpu(), b.grad) < (gt if act else 2e-5)
     if use_res:
         assert rel(nchw(rd.grad.cpu(), cout), res.grad) < (gt if act else 2e-5)
+
+
+def _split_rows(x):
+    """fp32 [rows][K] -> slab-major bf16x3 [K/16][rows][3][16] (int16 view), the layout dsee_gemm_bf16x3 reads."""
+    x0 = x.bfloat16()
+    r = x - x0.float()
+    x1 = r.bfloat16()
+    x2 = (r - x1.float()).bfloat16()
+    assert torch.equal(x0.float() + x1.float() + x2.float(), x)       # the split is exact
+    rows, k = x.shape
+    return torch.stack([x0, x1, x2], 0).view(3, rows, k // 16, 16).permute(2, 1, 0, 3).contiguous().view(torch.int16)
+
+
+@pytest.mark.parametrize("groups,tg,n,k,tile", [(3, 256, 256, 160, 1), (2, 512, 256, 512, 2), (36, 128, 128, 32, 1),
+                                                (1, 1024, 512, 1024, 0)])
+def test_gemm_bf16x3_is_fp32_accurate(groups, tg, n, k, tile):
+    """The split-operand GEMM on the bf16 matrix cores against float64: its error must be that of fp32 arithmetic --
+    the six-product scheme drops only terms below 2^-26 |a||b| and every kept product is exact, so what remains is
+    the rounding of the fp32 accumulator (one chain of 6*K/16 MFMA accumulations; a blocked CPU sgemm on the same
+    data is the yardstick, bound: 2x its error and < 5e-7 relative)."""
+    from deepsee_amd import lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(groups * 1000 + k)
+    a = torch.randn(groups * tg, k, generator=g) * torch.rand(groups * tg, 1, generator=g).exp()
+    b = torch.randn(groups, n, k, generator=g)
+    ref = torch.einsum("gtk,gnk->gtn", a.view(groups, tg, k).double(), b.double()).reshape(groups * tg, n)
+    f32 = torch.einsum("gtk,gnk->gtn", a.view(groups, tg, k), b).reshape(groups * tg, n)
+    a3 = _split_rows(a).cuda()
+    b3 = torch.stack([_split_rows(b[i]) for i in range(groups)]).cuda()
+    c = torch.full((groups * tg, n), float("nan"), device="cuda")
+    L.call("gemm_bf16x3", a3, b3, c, C.c_long(groups * tg), n, k, C.c_long(tg), n, tile)
+    torch.cuda.synchronize()
+    e_split = ((c.cpu().double() - ref).norm() / ref.norm()).item()
+    e_f32 = ((f32.double() - ref).norm() / ref.norm()).item()
+    print("bf16x3 vs f64: %.2e | cpu sgemm vs f64: %.2e" % (e_split, e_f32))
+    assert e_split < 5e-7 and e_split <= 2 * e_f32, (e_split, e_f32)
+    assert ((c.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
