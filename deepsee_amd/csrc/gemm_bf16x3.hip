@@ -34,14 +34,28 @@ struct Gemm3Args {
   long rows_per_group;               // grouped mode: rows m / rows_per_group select the B matrix
   long b_group_bytes;
   long a_slab_bytes, b_slab_bytes;   // distance between consecutive 16-k slabs
-  long a_z_bytes, b_z_bytes, c_z_elems;  // blockIdx.y (batch / split-K index) offsets
-  int abl;
+  long a_z_bytes, b_z_bytes, c_z_elems;  // batch / split-K index offsets
+  int nz;
+  int abl;  // debug ablations (DSEE_G3_ABL): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no C stores
 };
+
+// force a value the compiler cannot prove wave-uniform into SGPRs (buffer resources / M0 must be scalar; without this
+// the loads are wrapped in waterfall loops)
+__device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
+}
 
 constexpr int ROWB = 112;  // LDS bytes per row per stage: 3 terms x 16 k x 2 B + 16 B pad
 
-// FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `part`, which is then folded into `acc`
+// FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `acc`, which is then folded into `tot`
 // (long reductions of the weight gradients: keeps the fp32 accumulation error at the blocked-sum level).
+//
+// Persistent: gridDim.x blocks walk the (z, M tile, N tile) list with stride gridDim.x, and the slab stream never
+// drains at a tile boundary -- the loads run two slabs ahead of the MFMAs straight into the next tile's first slabs,
+// and a finished tile's stores are issued behind the already-started loads, so neither the prologue latency nor the
+// epilogue is paid per tile (K = 160 .. 512 means only 10 .. 32 slabs per tile).
 template <int WM, int WN, int MT, int NT, int FL>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_kernel(Gemm3Args a) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64;
@@ -52,25 +66,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_ker
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  // XCD-aware tile order (speed only): hardware puts workgroup b on XCD b % 8; give each XCD a contiguous range of
-  // logical tiles, N tiles of one M tile adjacent, so blocks sharing A rows meet in one L2.
-  long bm;
-  int bn;
-  {
-    const int nbn = (a.N + BN - 1) / BN;
-    const long total = gridDim.x, b = blockIdx.x;
-    const long q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+  const int nbn = (a.N + BN - 1) / BN;
+  const long tiles_z = (a.M / BM) * nbn, ntile = tiles_z * a.nz;
+  const long G = gridDim.x;
+  // XCD-aware tile order (speed only): hardware puts workgroup b on XCD b % 8 (gridDim.x is a multiple of 8 or covers
+  // every tile); give each XCD a contiguous range of logical tiles, N tiles of one M tile adjacent, so blocks sharing
+  // A rows meet in one L2.
+  auto decode = [&](long v, long& z, long& bm, int& bn) {
+    const long q = ntile >> 3, r = ntile & 7, xcd = v & 7, idx = v >> 3;
     const long l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    bn = (int)(l % nbn);
-    bm = l / nbn;
-  }
-  const long group = (bm * BM) / a.rows_per_group;
-  // slab kt of this tile: A rows [bm*BM, +BM) at a.A + (kt*M + bm*BM)*96; B rows at a.B + group + (kt*b_rows + bn*BN)*96
-  const long z = blockIdx.y;
-  const unsigned char* pa = a.A + z * a.a_z_bytes + bm * BM * 96;
-  const unsigned char* pb = a.B + z * a.b_z_bytes + group * a.b_group_bytes + (long)bn * BN * 96;
-  const long sa = a.a_slab_bytes, sb_ = a.b_slab_bytes;
-  const int bvalid = min(BN, a.N - bn * BN) * 96;  // rows of B past N read as zeros (buffer range check)
+    z = l / tiles_z;
+    const long t = l - z * tiles_z;
+    bn = (int)(t % nbn);
+    bm = t / nbn;
+  };
 
   unsigned voff[ACH + BCH], loff[ACH + BCH];
 #pragma unroll
@@ -81,14 +90,35 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_ker
     loff[j] = (unsigned)(((j < ACH ? 0 : BM) + row) * ROWB + c * 16);
   }
   const int nk = a.K / 16;
+  const long sa = a.a_slab_bytes, sb_ = a.b_slab_bytes;
+
+  // ---- loader state: tile lt, slab lk (runs two slabs ahead of the compute state)
+  long lt = blockIdx.x;
+  int lk = 0, bvalid = 0;
+  const unsigned char *pa = a.A, *pb = a.B;
+  auto load_base = [&]() {
+    long z, bm;
+    int bn;
+    decode(lt < ntile ? lt : (long)blockIdx.x, z, bm, bn);  // past the end: harmless re-fetch of the first tile
+    const long group = (bm * BM) / a.rows_per_group;
+    // slab k of a tile: A rows [bm*BM, +BM) at A + z*a_z + k*a_slab + bm*BM*96; B likewise (+ group matrix)
+    pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 96);
+    pb = uniform_ptr(a.B + z * a.b_z_bytes + group * a.b_group_bytes + (long)bn * BN * 96);
+    bvalid = __builtin_amdgcn_readfirstlane(min(BN, a.N - bn * BN) * 96);  // rows of B past N read as zeros
+  };
   u32x4 st[ACH + BCH];
-  auto gload = [&](int kt) {
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + kt * sa), 0, BM * 96, 0x00020000);
-    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + kt * sb_), 0, bvalid, 0x00020000);
+  auto gload = [&]() {
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lk * sa), 0, BM * 96, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * sb_), 0, bvalid, 0x00020000);
 #pragma unroll
     for (int j = 0; j < ACH; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff[j], 0, 0);
 #pragma unroll
     for (int j = ACH; j < ACH + BCH; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff[j], 0, 0);
+    if (++lk == nk) {
+      lk = 0;
+      lt += G;
+      load_base();
+    }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -110,13 +140,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_ker
   const unsigned fa = (unsigned)((wm * MT * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16);
   const unsigned fb = (unsigned)((BM + wn * NT * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16);
 
-  gload(0);
+  load_base();
+  gload();
   lstore(0);
   __syncthreads();
-  gload(min(1, nk - 1));
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* sb = smem + ((a.abl & 16) ? 0 : cur * STAGE);
+  gload();
+  int cur = 0, ck = 0;
+  long ct = blockIdx.x;
+  for (;;) {
+    const unsigned char* sb = smem + cur * STAGE;
     bf16x8 af[MT][3];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -127,6 +159,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_ker
       bf16x8 bf[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * 32 * ROWB + p * 32);
+      if (a.abl & 4) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][j][0] += (float)bf[0][0] * (float)af[i][2][1] + (float)bf[1][2] * (float)af[i][1][3] + (float)bf[2][4] * (float)af[i][0][5];
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         // smallest terms first; B fragment is the MFMA "A" operand so that acc rows run along n
@@ -139,12 +176,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_ker
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!(a.abl & 2)) lstore(cur ^ 1);  // slab kt+1 (requested one slab ago)
-    if (!(a.abl & 32)) __syncthreads();
-    if (!(a.abl & 1)) gload(min(kt + 2, nk - 1));  // branch-free: past the end the last slab is fetched again
+    if (!(a.abl & 2)) lstore(cur ^ 1);  // next slab of the stream (requested one slab ago)
+    __syncthreads();
+    if (!(a.abl & 1)) gload();          // two slabs ahead; crosses into the next tile of this block without draining
     cur ^= 1;
+    ++ck;
     if constexpr (FL > 0) {
-      if ((kt & (FL - 1)) == FL - 1 || kt + 1 == nk) {
+      if ((ck & (FL - 1)) == 0 || ck == nk) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -155,47 +193,253 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_ker
           }
       }
     }
-  }
-  if constexpr (FL > 0) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = tot[i][j];
-  }
+    if (ck < nk) continue;
 
-  if (a.abl & 8) {
-    if (acc[0][0][0] == 12345.678f) a.C[0] = 1.f;
-    return;
-  }
-  // epilogue: D[n][m] layout -> lane holds, for each 8-row group g, n = 8g + 4*(lane>>5) + 0..3 of column m = lane&31
-  float* cz = a.C + z * a.c_z_elems;
+    // ---- tile finished.  D[n][m] layout: lane holds, for each 8-row group g, n = 8g + 4*(lane>>5) + 0..3 of column
+    //      m = lane & 31 -> 16-byte stores; they drain behind the loads already in flight for the next tile.
+    {
+      long z, bm;
+      int bn;
+      decode(ct, z, bm, bn);
+      float* cz = a.C + z * a.c_z_elems;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const long m = bm * BM + wm * MT * 32 + i * 32 + (lane & 31);
+      for (int i = 0; i < MT; ++i) {
+        const long m = bm * BM + wm * MT * 32 + i * 32 + (lane & 31);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n0 = bn * BN + wn * NT * 32 + j * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < NT; ++j) {
+          const int n0 = bn * BN + wn * NT * 32 + j * 32 + 4 * (lane >> 5);
+          f32x16& d = FL > 0 ? tot[FL > 0 ? i : 0][FL > 0 ? j : 0] : acc[i][j];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        if (n0 + 8 * g < a.N) *reinterpret_cast<f32x4*>(cz + m * a.ldc + n0 + 8 * g) = v;
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+            if (n0 + 8 * g < a.N && !(a.abl & 8)) *reinterpret_cast<f32x4*>(cz + m * a.ldc + n0 + 8 * g) = v;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        }
       }
     }
+    ck = 0;
+    ct += G;
+    if (ct >= ntile) break;
   }
 }
 
+// ---------------------------------------------------------------- direct-to-LDS variant (shipped)
+// Same tiling and MFMA schedule, but the slabs travel global -> LDS by buffer_load_dwordx4 ... lds (no staging VGPRs,
+// no ds_write pass) into THREE LDS stages, two slabs in flight across each raw s_barrier with counted vmcnt waits.
+// An LDS-DMA instruction writes 64 consecutive 16-byte slots (wave-uniform base + lane*16), so the LDS image of a
+// stage is the slab-major global image itself with one dummy slot after every 16 rows (96 chunk slots): chunk c of
+// row r sits at slot 6r + c + (r >> 4), which makes every ds_read_b128 fragment read conflict-free
+// ((6r + (r>>4)) mod 16 is a bijection on each of the instruction's four 16-lane groups); the per-lane GLOBAL
+// offset skips the dummies instead (slot s -> chunk s - s/97).
+constexpr int region_slots(int rows) { return rows * 6 + rows / 16; }
+
 template <int WM, int WN, int MT, int NT, int FL>
-int launch_gemm3(const Gemm3Args& a, int nz, hipStream_t st) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_kernel(Gemm3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (LDS address-space casts and s_waitcnt asm do not parse for the host pass)
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
+  constexpr int SA = region_slots(BM), SB = region_slots(BN);
+  constexpr int NA = (SA + 63) / 64, NB = (SB + 63) / 64;  // wave-instructions per slab for A, B
+  constexpr int STAGE = (NA + NB) * 1024;                  // bytes; B region starts at slot NA*64
+  constexpr int NI = (NA + NB + NW - 1) / NW;              // instructions per wave per slab (last one maybe absent)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nbn = (a.N + BN - 1) / BN;
+  const long tiles_z = (a.M / BM) * nbn, ntile = tiles_z * a.nz;
+  const long G = gridDim.x;
+  auto decode = [&](long v, long& z, long& bm, int& bn) {
+    const long q = ntile >> 3, r = ntile & 7, xcd = v & 7, idx = v >> 3;
+    const long l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    z = l / tiles_z;
+    const long t = l - z * tiles_z;
+    bn = (int)(t % nbn);
+    bm = t / nbn;
+  };
+
+  // this wave's instructions: id w = wave + NW*j covers slots [64w, 64w+64) of the stage
+  unsigned voff[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int w = wave + NW * j;
+    const bool isa = w < NA;
+    const int s = 64 * (isa ? w : w - NA) + lane, lim = isa ? SA : SB;
+    voff[j] = (w < NA + NB && s < lim && s % 97 != 96) ? (unsigned)((s - s / 97) * 16) : 0xFFFFFFF0u;
+  }
+  const bool has_last = wave + NW * (NI - 1) < NA + NB;  // wave-uniform
+  const int nk = a.K / 16;
+  const long sa = a.a_slab_bytes, sb_ = a.b_slab_bytes;
+
+  long lt = blockIdx.x;
+  int lk = 0, bvalid = 0, avalid = 0;
+  const unsigned char *pa = a.A, *pb = a.B;
+  auto load_base = [&]() {
+    long z, bm;
+    int bn;
+    const bool live = lt < ntile;
+    decode(live ? lt : (long)blockIdx.x, z, bm, bn);
+    const long group = (bm * BM) / a.rows_per_group;
+    pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 96);
+    pb = uniform_ptr(a.B + z * a.b_z_bytes + group * a.b_group_bytes + (long)bn * BN * 96);
+    // past the last tile: nothing is read (zeros land in LDS)
+    bvalid = __builtin_amdgcn_readfirstlane(live ? min(BN, a.N - bn * BN) * 96 : 0);
+    avalid = __builtin_amdgcn_readfirstlane(live ? BM * 96 : 0);
+  };
+  auto issue = [&](int stage_off) {
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lk * sa), 0, avalid, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * sb_), 0, bvalid, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int w = wave + NW * j;
+      if (j + 1 < NI || has_last) {
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + stage_off + w * 1024);
+        if (w < NA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voff[j], 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, voff[j], 0, 0, 0);
+      }
+    }
+    if (++lk == nk) {
+      lk = 0;
+      lt += G;
+      load_base();
+    }
+  };
+
+  f32x16 acc[MT][NT], tot[FL > 0 ? MT : 1][FL > 0 ? NT : 1];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (FL > 0) tot[i][j][r] = 0.f;
+      }
+
+  const int r0 = wm * MT * 32 + (lane & 31), rb0 = wn * NT * 32 + (lane & 31);
+  const unsigned fa = (unsigned)((6 * r0 + (r0 >> 4) + (lane >> 5)) * 16);
+  const unsigned fb = (unsigned)((NA * 64 + 6 * rb0 + (rb0 >> 4) + (lane >> 5)) * 16);
+  constexpr int TSTEP = 194 * 16;  // bytes between consecutive 32-row MFMA tiles: 32 rows * 6 slots + 2 dummies
+
+  load_base();
+  issue(0);
+  issue(STAGE);
+  int cur = 0, nxt = 2 * STAGE, ck = 0;  // stage being computed / stage to fill next (byte offsets)
+  long ct = blockIdx.x;
+  for (;;) {
+    // slab `cur` was requested two iterations ago: wait for all but this wave's newest slab, then meet the block
+    if (has_last)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI - 1) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(nxt);  // the stage everybody finished reading in the previous iteration
+    const unsigned char* sb = smem + cur;
+    bf16x8 af[MT][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + fa + i * TSTEP + p * 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * TSTEP + p * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[2], af[i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][0], acc[i][j], 0, 0, 0);
+      }
+    }
+    cur = cur == 2 * STAGE ? 0 : cur + STAGE;
+    nxt = nxt == 2 * STAGE ? 0 : nxt + STAGE;
+    ++ck;
+    if constexpr (FL > 0) {
+      if ((ck & (FL - 1)) == 0 || ck == nk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            tot[i][j] += acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+      }
+    }
+    if (ck < nk) continue;
+    {
+      long z, bm;
+      int bn;
+      decode(ct, z, bm, bn);
+      float* cz = a.C + z * a.c_z_elems;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const long m = bm * BM + wm * MT * 32 + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n0 = bn * BN + wn * NT * 32 + j * 32 + 4 * (lane >> 5);
+          f32x16& d = FL > 0 ? tot[FL > 0 ? i : 0][FL > 0 ? j : 0] : acc[i][j];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+            if (n0 + 8 * g < a.N) *reinterpret_cast<f32x4*>(cz + m * a.ldc + n0 + 8 * g) = v;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        }
+      }
+    }
+    ck = 0;
+    ct += G;
+    if (ct >= ntile) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block
+#endif
+}
+
+static int gemm3_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int WM, int WN, int MT, int NT, int FL>
+int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  const size_t lds = (size_t)2 * (BM + BN) * ROWB;
+  static const bool use_reg = getenv("DSEE_G3_REG") != nullptr;  // register-staged variant (for A/B measurements)
+  constexpr int NSLOT = (region_slots(BM) + 63) / 64 + (region_slots(BN) + 63) / 64;
+  const size_t lds = use_reg ? (size_t)2 * (BM + BN) * ROWB : (size_t)3 * NSLOT * 1024;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<WM, WN, MT, NT, FL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (BM + BN) * ROWB));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3g_kernel<WM, WN, MT, NT, FL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * NSLOT * 1024));
     attr_done = true;
   }
-  const long tiles = (a.M / BM) * ((a.N + BN - 1) / BN);
-  gemm3_kernel<WM, WN, MT, NT, FL><<<dim3((unsigned)tiles, (unsigned)nz), WM * WN * 64, lds, st>>>(a);
+  a.nz = nz;
+  { const char* e = getenv("DSEE_G3_ABL"); a.abl = e ? atoi(e) : 0; }
+  const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN) * nz;
+  const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);   // resident blocks
+  const long grid = ntile < slots ? ntile : slots;
+  if (use_reg)
+    gemm3_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
+  else
+    gemm3g_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -213,7 +457,6 @@ int dsee_gemm_bf16x3(const void* A3, const void* B3, float* C, long M, int N, in
   DSEE_CHECK_ARG(A3 && B3 && C && M > 0 && N > 0 && K > 0 && K % 16 == 0 && N % 128 == 0 && M % 128 == 0);
   DSEE_CHECK_ARG(rows_per_group % 128 == 0 && M % rows_per_group == 0 && b_rows >= N);
   Gemm3Args a = {};
-  { const char* e = getenv("DSEE_G3_ABL"); a.abl = e ? atoi(e) : 0; }
   a.A = (const unsigned char*)A3; a.B = (const unsigned char*)B3; a.C = C;
   a.M = M; a.N = N; a.K = K; a.ldc = N; a.rows_per_group = rows_per_group;
   a.b_group_bytes = (long)b_rows * K * 6; a.a_slab_bytes = M * 96; a.b_slab_bytes = (long)b_rows * 96;

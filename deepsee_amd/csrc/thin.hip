@@ -1,0 +1,176 @@
+// 3x3 / stride-1 / pad-1 convolutions with a handful of output channels (the generator's to-RGB layer, sr.py:65,94:
+// 512 -> 3 at the output resolution).  As an implicit GEMM the N dimension is 3 of a 32-wide MFMA tile (11 TF/s
+// forward, 3.7 TF/s weight gradient measured); here the work is laid out along the INPUT channels instead:
+//   lane = 4 consecutive input channels (16-byte loads, a wave covers 256 channels of one pixel in one request),
+//   a wave walks along an image row keeping the 3x3 window of its channels in registers (3 new loads per pixel),
+//   forward : the 9 x 4 x Cout weights of the lane stay in registers, 108 FMAs per pixel, then a wave reduction
+//             over channels; lane l keeps the result of pixel l of the 64-pixel segment, waves (channel blocks) are
+//             combined through LDS once per segment, bias + activation fused;
+//   wgrad   : the 9 x 4 x Cout accumulators of the lane stay in registers (no cross-lane traffic at all), dout of the
+//             pixel is wave-uniform; per-block partial sums, then a deterministic reduce into OIHW.
+// fp32 VALU arithmetic (exact fp32 FMAs); Cout <= 4, C % 256 == 0, W % 64 == 0.
+#include "dsee_common.h"
+
+namespace {
+
+constexpr int TCO = 4;  // output channels handled (stored stride of out / dout is 4)
+
+__device__ __forceinline__ f32x4 ldx(const float* __restrict__ x, int n, int y, int xx, int H, int W, int C, int c) {
+  const bool ok = y >= 0 && y < H && xx >= 0 && xx < W;
+  return ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + y) * W + xx) * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// grid: N*H*(W/64) segments; block: (C/256) waves
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                       int H, int W, int C, int Cout, int act, float slope) {
+  __shared__ float part[4][TCO][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int c = wave * 256 + lane * 4;
+  const int segs = W / 64;
+  const int seg = blockIdx.x % segs, y = (blockIdx.x / segs) % H, n = blockIdx.x / (segs * H);
+  // weights of this lane's 4 channels: wr[co][tap][e] = w[co][c+e][tap]
+  f32x4 wr[TCO][9];
+#pragma unroll
+  for (int co = 0; co < TCO; ++co)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wr[co][t][e] = co < Cout ? w[((size_t)co * C + c + e) * 9 + t] : 0.f;
+  const int x0 = seg * 64;
+  f32x4 win[3][3];  // win[dy][dx] = x[y-1+dy][px-1+dx]
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    win[dy][1] = ldx(x, n, y - 1 + dy, x0 - 1, H, W, C, c);
+    win[dy][2] = ldx(x, n, y - 1 + dy, x0, H, W, C, c);
+  }
+  float res[TCO] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < 64; ++s) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      win[dy][0] = win[dy][1];
+      win[dy][1] = win[dy][2];
+      win[dy][2] = ldx(x, n, y - 1 + dy, x0 + s + 1, H, W, C, c);
+    }
+#pragma unroll
+    for (int co = 0; co < TCO; ++co) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) a += win[dy][dx] * wr[co][dy * 3 + dx];
+      const float v = wave_sum((a[0] + a[1]) + (a[2] + a[3]));
+      res[co] = lane == s ? v : res[co];
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < TCO; ++co) part[wave][co][lane] = res[co];
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 o;
+#pragma unroll
+    for (int co = 0; co < TCO; ++co) {
+      float v = part[0][co][lane];
+      for (int k = 1; k < nw; ++k) v += part[k][co][lane];
+      v += (bias && co < Cout) ? bias[co] : 0.f;
+      o[co] = co < Cout ? dsee_act(v, act, slope) : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + (((size_t)n * H + y) * W + x0 + lane) * TCO) = o;
+  }
+}
+
+// grid: (C/256, nstrip); block: one wave... 256 threads = 4 waves, each wave walks its own segments.
+// partial [nstrip*4 waves][TCO][C][9]
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                         float* __restrict__ partial, int N, int H, int W, int C,
+                                                         int nwalk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int segs = W / 64;
+  const long nseg = (long)N * H * segs;
+  const int walker = blockIdx.y * 4 + wave;  // 0 .. nwalk-1
+  f32x4 acc[TCO][9];
+#pragma unroll
+  for (int co = 0; co < TCO; ++co)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[co][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long sg = walker; sg < nseg; sg += nwalk) {
+    const int seg = (int)(sg % segs), y = (int)((sg / segs) % H), n = (int)(sg / ((long)segs * H));
+    const int x0 = seg * 64;
+    f32x4 win[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      win[dy][1] = ldx(x, n, y - 1 + dy, x0 - 1, H, W, C, c);
+      win[dy][2] = ldx(x, n, y - 1 + dy, x0, H, W, C, c);
+    }
+    const float* dr = dout + (((size_t)n * H + y) * W + x0) * TCO;
+    for (int s = 0; s < 64; ++s) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        win[dy][0] = win[dy][1];
+        win[dy][1] = win[dy][2];
+        win[dy][2] = ldx(x, n, y - 1 + dy, x0 + s + 1, H, W, C, c);
+      }
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dr + s * TCO);  // wave-uniform address
+#pragma unroll
+      for (int co = 0; co < TCO; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[co][t] += win[t / 3][t % 3] * d[co];
+    }
+  }
+  float* p = partial + (size_t)walker * TCO * C * 9;
+#pragma unroll
+  for (int co = 0; co < TCO; ++co)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p[((size_t)co * C + c + e) * 9 + t] = acc[co][t][e];
+}
+
+__global__ void thin_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nwalk, int C,
+                                         int Cout, int Cin) {
+  const long total = (long)Cout * Cin * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % 9);
+    const long r = i / 9;
+    const int ci = (int)(r % Cin), co = (int)(r / Cin);
+    float v = 0.f;
+    for (int k = 0; k < nwalk; ++k) v += partial[(((size_t)k * TCO + co) * C + ci) * 9 + t];
+    dw[i] = v;
+  }
+}
+
+constexpr int NWALK = 1024;  // row-segment walkers of the weight gradient (4 per block)
+
+}  // namespace
+
+extern "C" {
+
+/* out [N,H,W,4] = act(conv3x3(x [N,H,W,C], w OIHW [Cout][C][3][3]) + bias), Cout <= 4 (unused channels written 0).
+ * Replaces the generator's to-RGB convolution + tanh (sr.py:65,94-95).  C % 256 == 0 (<= 1024), W % 64 == 0. */
+int dsee_conv3x3_thin_fwd(const float* x, const float* w_oihw, const float* bias, float* out, int N, int H, int W, int C,
+                          int Cout, int act, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(x && w_oihw && out && Cout >= 1 && Cout <= TCO && C % 256 == 0 && C <= 1024 && W % 64 == 0);
+  thin_fwd_kernel<<<(unsigned)((long)N * H * (W / 64)), C / 4, 0, st>>>(x, w_oihw, bias, out, N, H, W, C, Cout, act,
+                                                                       slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+size_t dsee_conv3x3_thin_wgrad_workspace(int C) { return (size_t)NWALK * TCO * C * 9 * sizeof(float); }
+
+/* dw OIHW [Cout][Cin][3][3] of the same convolution from dout [N,H,W,4] (pre-activation gradient); Cin <= C. */
+int dsee_conv3x3_thin_wgrad(const float* x, const float* dout, float* workspace, float* dw_oihw, int N, int H, int W,
+                            int C, int Cout, int Cin, hipStream_t st) {
+  DSEE_CHECK_ARG(x && dout && workspace && dw_oihw && Cout >= 1 && Cout <= TCO && C % 256 == 0 && W % 64 == 0);
+  DSEE_CHECK_ARG(Cin <= C);
+  thin_wgrad_kernel<<<dim3(C / 256, NWALK / 4), 256, 0, st>>>(x, dout, workspace, N, H, W, C, NWALK);
+  DSEE_LAUNCH_CHECK();
+  const long total = (long)Cout * Cin * 9;
+  thin_wgrad_reduce_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(workspace, dw_oihw, NWALK, C, Cout,
+                                                                                 Cin);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"

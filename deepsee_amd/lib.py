@@ -40,7 +40,7 @@ def lib():
         _lib.dsee_last_error.restype = C.c_char_p
         for fn in ("conv2d_wgrad_workspace", "conv2d_wgrad_table_workspace", "norm_workspace", "channel_dot_workspace",
                    "onehot_conv3x3_wgrad_workspace", "label_segsum_workspace", "loss_workspace",
-                   "wino43_wgrad_workspace", "wino43_wgrad_table_workspace"):
+                   "wino43_wgrad_workspace", "wino43_wgrad_table_workspace", "conv3x3_thin_wgrad_workspace"):
             getattr(_lib, "dsee_" + fn).restype = C.c_size_t
     return _lib
 

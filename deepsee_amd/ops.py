@@ -316,7 +316,12 @@ class Conv2d(torch.autograd.Function):
         geom = L.geom_fwd(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
         w = w.contiguous()
         ctx.wino = _wino_ok(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
-        if ctx.wino:
+        ctx.thin = (kh == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and cin_s % 256 == 0 and cin_s <= 1024
+                    and wi % 64 == 0 and res is None)
+        if ctx.thin:
+            out = new(n, hi, wi, cout_s)
+            L.call("conv3x3_thin_fwd", x, w, bias, out, n, hi, wi, cin_s, co, act, LRELU_SLOPE)
+        elif ctx.wino:
             out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act)
         else:
             out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act)
@@ -346,7 +351,11 @@ class Conv2d(torch.autograd.Function):
                 L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
             else:
                 dx = dxl
-        if ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
+        if ctx.needs_input_grad[1] and ctx.thin:
+            ws = scratch(L.lib().dsee_conv3x3_thin_wgrad_workspace(geom.Cin), "wgrad")
+            dw = new(co, ci, 3, 3)
+            L.call("conv3x3_thin_wgrad", x, g, ws, dw, geom.N, geom.Hi, geom.Wi, geom.Cin, co, ci)
+        elif ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
             dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci)
         elif ctx.needs_input_grad[1]:
             dw = wgrad_raw(x, g, geom, co, ci, kh, kw)
@@ -751,14 +760,49 @@ class SeanNormTable(torch.autograd.Function):
         return dx, dw_sh, db_sh, dw2a, dtable, db2, None, None, None, None, None, None
 
 
+class _StyleGemm(torch.autograd.Function):
+    """t[nr][j] = sum_s style[nr][s] * wt[j][s]  (nr = N*19 style rows, j = 9*rows table columns) on the MFMA 1x1
+    conv kernel.  The gradient w.r.t. `style` contracts over j (K = 9216 with only N*19 = 152 output rows): run as
+    a 1x1 conv it is 2 tiles x 288 K-slabs on 2 CUs (0.7 ms), so it is computed with the split-K weight-gradient
+    kernel instead (j plays the pixel role): d_style^T[s][nr] = sum_j wt[j][s] * dt^T[j][nr]."""
+
+    @staticmethod
+    def forward(ctx, x, wt):
+        nr, sdim = x.shape
+        j = wt.shape[0]
+        geom = L.geom_fwd(1, nr, 1, sdim, L.pad4(j), 1, 1, 0)
+        t = conv_raw(x.reshape(1, nr, 1, sdim), _pack_fwd(wt.reshape(j, sdim, 1, 1), sdim, geom.korder), geom)
+        ctx.geom = geom
+        ctx.save_for_backward(x, wt)
+        return t.reshape(nr, -1)[:, :j]
+
+    @staticmethod
+    def backward(ctx, dt):
+        x, wt = ctx.saved_tensors
+        nr, sdim = x.shape
+        j = wt.shape[0]
+        dt = dt.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = wgrad_raw(x.reshape(1, nr, 1, sdim), dt.reshape(1, nr, 1, j), ctx.geom, j, sdim, 1, 1).reshape(j, sdim)
+        if ctx.needs_input_grad[0]:
+            nrp = L.pad4(nr)
+            dtt = torch.nn.functional.pad(dt.t(), (0, nrp - nr)).contiguous()            # [j][nr] (5 MB transpose)
+            g2 = L.geom_fwd(1, j, 1, nrp, sdim, 1, 1, 0)
+            dx = wgrad_raw(dtt.reshape(1, j, 1, nrp), wt.reshape(1, j, 1, sdim), g2, sdim, nr, 1, 1)
+            dx = dx.reshape(sdim, nr).t().contiguous()
+        return dx, dw
+
+
 def style_table(style, ws2):
     """T[n][tap][row][r(32)] from the style matrix [N,19,S] and the (row-permuted, blend-scaled) style conv weights
     ws2 [rows,S,3,3]: a 1x1 convolution over the N*19 style rows (HIP conv kernel, differentiable), then a
     parameter-sized transpose/pad (<= 6 MB) into the layout the modulate kernel reads."""
     n, nc, s = style.shape
     rows = ws2.shape[0]
-    wt = ws2.permute(2, 3, 0, 1).reshape(9 * rows, s, 1, 1)             # [(tap,row)][s]
-    t = conv2d(style.reshape(n, nc, 1, s).contiguous(), wt, None, None, 1, 0, 0, L.ACT_NONE)   # [N,19,1,9*rows]
+    assert s % 4 == 0 and (9 * rows) % 4 == 0
+    wt = ws2.permute(2, 3, 0, 1).reshape(9 * rows, s)                   # [(tap,row)][s]
+    t = _StyleGemm.apply(style.reshape(n * nc, s).contiguous(), wt.contiguous())   # [N*19, 9*rows]
     t = t.reshape(n, nc, 9, rows).permute(0, 2, 3, 1)                   # [N,9,rows,19]
     return torch.nn.functional.pad(t, (0, 32 - nc)).contiguous()
 

@@ -124,6 +124,15 @@ int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, i
 int dsee_gemm_bf16x3_tn(const void* P3t, const void* Q3t, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                         int splits, hipStream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with <= 4 output channels (the generator's to-RGB layer + tanh, sr.py:65,94-95)
+ * and its weight gradient, laid out along the input channels on the fp32 VALU (deepsee_amd/csrc/thin.hip): as an
+ * implicit GEMM its N dimension would fill 3 of 32 MFMA columns.  out / dout are [N,H,W,4]; C % 256 == 0, W % 64 == 0. */
+int dsee_conv3x3_thin_fwd(const float* x, const float* w_oihw, const float* bias, float* out, int N, int H, int W, int C,
+                          int Cout, int act, float slope, hipStream_t stream);
+size_t dsee_conv3x3_thin_wgrad_workspace(int C);
+int dsee_conv3x3_thin_wgrad(const float* x, const float* dout, float* workspace, float* dw_oihw, int N, int H, int W,
+                            int C, int Cout, int Cin, hipStream_t stream);
+
 /* Fused SPADE / SEAN / PureSEAN normalisation (normalization.py:107-120, 167-213, 258-286) + the
  * LeakyReLU of architecture.py:92,114:  the implicit GEMM produces (gamma-ish, beta-ish) for 32-channel
  * groups side by side (row order of the packed weight: for 64-channel block b, wave w, half h, lane c:

@@ -180,3 +180,32 @@ def test_gemm_bf16x3_is_fp32_accurate(groups, tg, n, k, tile):
     print("bf16x3 vs f64: %.2e | cpu sgemm vs f64: %.2e" % (e_split, e_f32))
     assert e_split < 5e-7 and e_split <= 2 * e_f32, (e_split, e_f32)
     assert ((c.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,act,use_bias", [(2, 256, 3, 8, 64, 3, True), (1, 512, 3, 12, 128, 0, False),
+                                                          (2, 512, 1, 4, 64, 1, True)])
+def test_thin_conv3x3(n, cin, cout, h, w, act, use_bias):
+    """The to-RGB layer (512 -> 3, tanh) runs on the channel-walking VALU kernels of thin.hip (forward + weight
+    gradient; exact fp32 FMAs, different summation order than ATen): ops.conv2d must route there."""
+    from deepsee_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + w)
+    x = torch.randn(n, cin, h, w, generator=g).requires_grad_()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).requires_grad_()
+    b = torch.randn(cout, generator=g).requires_grad_() if use_bias else None
+    y = F.conv2d(x, wt, b, padding=1)
+    y = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 3: torch.tanh}[act](y)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x.detach()).cuda().requires_grad_()
+    wd = wt.detach().cuda().requires_grad_()
+    bd = b.detach().cuda().requires_grad_() if use_bias else None
+    yd = ops.conv2d(xd, wd, bd, None, 1, 1, 0, act)
+    assert yd.grad_fn is not None and yd.shape[-1] == 4
+    yd.backward(nhwc(gy).cuda())
+    torch.cuda.synchronize()
+    assert rel(nchw(yd.detach().cpu(), cout), y.detach()) < 2e-5
+    assert float(yd.detach()[..., cout:].abs().max()) == 0.0
+    assert rel(nchw(xd.grad.cpu(), cin), x.grad) < 2e-5
+    assert rel(wd.grad.cpu(), wt.grad) < 2e-5
+    if use_bias:
+        assert rel(bd.grad.cpu(), b.grad) < 2e-5
