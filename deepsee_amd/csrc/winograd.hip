@@ -38,6 +38,38 @@ __device__ __forceinline__ void store_split4(unsigned short* base, size_t row, i
   }
 }
 
+// split 4 values into 3 terms, each packed as two dwords of 2 bf16
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_packed(const f32x4& v, unsigned (&pk)[3][2]) {
+  unsigned short h[4][3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3(v[e], h[e]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    pk[p][0] = (unsigned)h[0][p] | ((unsigned)h[1][p] << 16);
+    pk[p][1] = (unsigned)h[2][p] | ((unsigned)h[3][p] << 16);
+  }
+}
+// Two outputs (va -> row_a, vb -> row_b) of a lane pair (even / odd lane = adjacent 8-byte pieces of one 16-byte chunk):
+// the even lane hands its vb piece to the odd lane and receives the odd lane's va piece (one DPP swap per dword),
+// so every lane issues ONE 16-byte store per term instead of two 8-byte stores.  `idx8(row)` -> element index of the
+// pair's 16-byte chunk for term 0 (terms are 16 elements apart).
+__device__ __forceinline__ void store_split_pair(unsigned short* base, const f32x4& va, const f32x4& vb, bool odd,
+                                                 size_t ia, size_t ib) {
+  unsigned pa[3][2], pb[3][2];
+  split4_packed(va, pa);
+  split4_packed(vb, pb);
+  const size_t at = odd ? ib : ia;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const unsigned s0 = odd ? pa[p][0] : pb[p][0], s1 = odd ? pa[p][1] : pb[p][1];
+    const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
+    const u32x4 w = odd ? (u32x4){r0, r1, pb[p][0], pb[p][1]} : (u32x4){pa[p][0], pa[p][1], r0, r1};
+    *reinterpret_cast<u32x4*>(base + at + p * 16) = w;
+  }
+}
+
 // one column / row of B^T d : 6 -> 6
 __device__ __forceinline__ void bt6(const f32x4 (&d)[6], f32x4 (&o)[6]) {
   o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
@@ -62,23 +94,27 @@ __device__ __forceinline__ void at4(const f32x4 (&m)[6], f32x4 (&o)[4]) {
 constexpr int OUT_F32 = 0, OUT_SPLIT = 1, OUT_SPLIT_T = 2;
 
 // split modes: a wave = 16 consecutive tiles x one 16-channel slab (T % 16 == 0, C % 16 == 0), lane = (tile l>>2,
-// channel quad l&3); its three term stores then fill 1536 contiguous bytes of either split layout
-__device__ __forceinline__ void wave_tile_quad(long i, int C4, int& q, long& t) {
+// channel quad l&3); its three term stores then fill 1536 contiguous bytes of either split layout.  Waves are
+// ordered strip-major: 256 consecutive tile groups (4096 tiles, an L2-sized piece of x) for slab 0, the same tiles
+// for slab 1, ... so that every (xi, slab) output stream is written in long sequential runs while x is read from
+// HBM once.
+__device__ __forceinline__ void wave_tile_quad(long i, int C4, long T, int& q, long& t, long& tg, int& kb) {
   const int C16 = C4 >> 2;
+  const long G16 = T >> 4;
+  const long S = G16 % 256 == 0 ? 256 : G16;
   const long w = i >> 6;
   const int l = (int)(i & 63);
-  q = (int)(w % C16) * 4 + (l & 3);
-  t = (w / C16) * 16 + (l >> 2);
+  const long strip = w / (C16 * S), rem = w - strip * (C16 * S);
+  kb = (int)(rem / S);
+  tg = strip * S + rem % S;
+  q = kb * 4 + (l & 3);
+  t = tg * 16 + (l >> 2);
 }
 
 // OUT_SPLIT_T: transpose the wave's 16 tiles x 16 channels through LDS so that lane (channel l>>2, tile quad l&3)
 // holds 4 consecutive tiles of one channel, then split and store 8 bytes per term
-__device__ __forceinline__ void emit_split_t(float* tb, unsigned short* base, int xi, long T, int C, long i,
-                                             const f32x4& o) {
-  const int l = (int)(i & 63), C16 = C >> 4;
-  const long w = i >> 6;
-  const int ch0 = (int)(w % C16) * 16;
-  const long tblk = w / C16;
+__device__ __forceinline__ void emit_split_t(float* tb, unsigned short* base, int xi, long T, int C, int l, long tblk,
+                                             int ch0, const f32x4& o) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) tb[(4 * (l & 3) + e) * 20 + (l >> 2)] = o[e];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -107,8 +143,10 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int q;
     long t;
+    long tg = 0;
+    int kb = 0;
     if constexpr (OUT != OUT_F32) {
-      wave_tile_quad(i, C4, q, t);
+      wave_tile_quad(i, C4, T, q, t, tg, kb);
     } else {
       q = (int)(i % C4);
       t = i / C4;
@@ -136,12 +174,20 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
     for (int k = 0; k < 6; ++k) {
       f32x4 o[6];
       bt6(tmp[k], o);  // (B^T d) B : same combination along the row
+      if constexpr (OUT == OUT_SPLIT) {
+        // lanes 2m / 2m+1 hold channel quads (8m, 8m+4) of the same tile: one 16-byte store per term and xi pair
+        const int k8 = (q & ~1) * 4;
+#pragma unroll
+        for (int j = 0; j < 6; j += 2)
+          store_split_pair(reinterpret_cast<unsigned short*>(V), o[j], o[j + 1], (threadIdx.x & 1) != 0,
+                           split_index((size_t)(k * 6 + j) * T + t, k8, (size_t)36 * T, 0),
+                           split_index((size_t)(k * 6 + j + 1) * T + t, k8, (size_t)36 * T, 0));
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        if constexpr (OUT == OUT_SPLIT)
-          store_split4(reinterpret_cast<unsigned short*>(V), (size_t)(k * 6 + j) * T + t, q * 4, (size_t)36 * T, o[j]);
-        else if constexpr (OUT == OUT_SPLIT_T)
-          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(V), k * 6 + j, T, C, i, o[j]);
+        if constexpr (OUT == OUT_SPLIT_T)
+          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(V), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
         else
           *reinterpret_cast<f32x4*>(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
       }
@@ -168,10 +214,10 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q;
-    long t;
+    int q, kb = 0;
+    long t, tg = 0;
     if constexpr (OUT != OUT_F32) {
-      wave_tile_quad(i, C4, q, t);
+      wave_tile_quad(i, C4, T, q, t, tg, kb);
     } else {
       q = (int)(i % C4);
       t = i / C4;
@@ -197,7 +243,7 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         if constexpr (OUT == OUT_SPLIT_T)
-          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, i, o[j]);
+          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
         else
           *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
       }

@@ -60,7 +60,7 @@ def scratch(nbytes, tag="ws"):
     """Grow-only device scratch (fp32).  Safe to share: all kernels run in stream order and every
     workspace is consumed inside the C call that fills it."""
     n = (int(nbytes) + 3) // 4
-    key = (tag, torch.cuda.current_device())
+    key = (tag, torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     t = _scratch.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(max(n, 1024), dtype=torch.float32, device="cuda")
@@ -70,6 +70,39 @@ def scratch(nbytes, tag="ws"):
 
 def new(*shape):
     return torch.empty(*shape, dtype=torch.float32, device="cuda")
+
+
+# The weight gradient and the data gradient of a layer are independent and can run on two HIP streams (DSEE_STREAMS=1).
+# Off by default: measured 184.5 vs 184.8 ms/step -- the persistent GEMM holds 216 VGPRs x 8 waves per CU, so the
+# 178-VGPR transform kernels of the other stream cannot become resident beside it and nothing overlaps.
+STREAMS = os.environ.get("DSEE_STREAMS", "0") == "1"
+_side_streams = {}
+
+
+class _OnSide:
+    """with _OnSide() as s: ... enqueue on the side stream (ordered after everything already on the current stream);
+    s.join(t0, t1, ...) makes the current stream wait for it and hands the result tensors over."""
+
+    def __enter__(self):
+        self.main = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
+        if dev not in _side_streams:
+            _side_streams[dev] = torch.cuda.Stream()
+        self.side = _side_streams[dev]
+        self.side.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.main)
 
 
 def pad_vec(v, n):
@@ -341,7 +374,12 @@ class Conv2d(torch.autograd.Function):
         else:
             g = dy
         dx = dw = db = dres = None
-        if ctx.needs_input_grad[0] and ctx.wino:
+        if STREAMS and ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            with _OnSide() as sd:
+                dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci)
+            dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
+            sd.join(dw)
+        elif ctx.needs_input_grad[0] and ctx.wino:
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
         elif ctx.needs_input_grad[0]:
             gd = L.geom_dgrad(geom)
@@ -351,7 +389,9 @@ class Conv2d(torch.autograd.Function):
                 L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
             else:
                 dx = dxl
-        if ctx.needs_input_grad[1] and ctx.thin:
+        if dw is not None:
+            pass
+        elif ctx.needs_input_grad[1] and ctx.thin:
             ws = scratch(L.lib().dsee_conv3x3_thin_wgrad_workspace(geom.Cin), "wgrad")
             dw = new(co, ci, 3, 3)
             L.call("conv3x3_thin_wgrad", x, g, ws, dw, geom.N, geom.Hi, geom.Wi, geom.Cin, co, ci)
@@ -697,29 +737,11 @@ class SeanNormTable(torch.autograd.Function):
         L.call("modulate_bwd", dh.contiguous(), out, x, scale, mean, invstd, None, dx, dgb, rows, cs, n, h * w, c,
                LRELU_SLOPE, ws)
         dw_sh = db_sh = dw2a = dtable = db2 = None
-        if ctx.has_a:
-            # data gradient only w.r.t. the 128 embedding channels (the one-hot channels need none)
-            ga = L.ConvGeom(n, h, w, rows, h, w, NHIDDEN, 3, 3, 1, 1, -1, 0, 0, 1)
-            wino_d = ctx.wino_nb and _wino_chunk(n, h, w, rows) is not None
-            if ctx.has_t:
-                # ReLU backward fused into the dgrad epilogue; the gradient of mlp_shared (a conv over the one-hot
-                # label) is then the weight gradient w.r.t. the one-hot channels already sitting in `cat` (MFMA)
-                if wino_d:
-                    dactv = _wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True, None, cat, L.ACT_MASK, res_ld=ld)
-                else:
-                    dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga, None, cat, L.ACT_MASK, res_ld=ld)
-                gs = L.geom_fwd(n, h, w, ld, NHIDDEN, 3, 1, 1, 0)
-                dw_sh = wgrad_raw(cat, dactv, gs, NHIDDEN, lab.nc, 3, 3, cin_first=NHIDDEN)
-                db_sh = channel_dot(dactv, None, NHIDDEN).clone()
-            else:
-                dactv = (_wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True) if wino_d
-                         else conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga))
-                dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
-                wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
-                L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw_sh,
-                       db_sh, wso)
         nb = ctx.wino_nb
-        if nb and (ctx.has_t or ctx.needs_input_grad[3]):
+        wino_w = bool(nb) and (ctx.has_t or ctx.needs_input_grad[3])
+
+        def wino_wgrad():
+            dw2a = dtable = None
             # weight gradient in the Winograd domain: groups (xi, image), shared columns summed over images
             tpi, ca = (h // 4) * (w // 4), (NHIDDEN if ctx.has_a else 0)
             if ctx.has_t:
@@ -742,6 +764,39 @@ class SeanNormTable(torch.autograd.Function):
                                NHIDDEN, int(split))
                 if dwc is not None:
                     dw2a = dwc if dw2a is None else dw2a.add_(dwc)
+            return dw2a, dtable
+
+        side = None
+        if wino_w and STREAMS and ctx.has_a:
+            with _OnSide() as side:          # weight / table gradient on the second stream, data gradient below
+                dw2a, dtable = wino_wgrad()
+        if ctx.has_a:
+            # data gradient only w.r.t. the 128 embedding channels (the one-hot channels need none)
+            ga = L.ConvGeom(n, h, w, rows, h, w, NHIDDEN, 3, 3, 1, 1, -1, 0, 0, 1)
+            wino_d = ctx.wino_nb and _wino_chunk(n, h, w, rows) is not None
+            if ctx.has_t:
+                # ReLU backward fused into the dgrad epilogue; the gradient of mlp_shared (a conv over the one-hot
+                # label) is then the weight gradient w.r.t. the one-hot channels already sitting in `cat` (MFMA)
+                if wino_d:
+                    dactv = _wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True, None, cat, L.ACT_MASK, res_ld=ld)
+                else:
+                    dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga, None, cat, L.ACT_MASK, res_ld=ld)
+                gs = L.geom_fwd(n, h, w, ld, NHIDDEN, 3, 1, 1, 0)
+                dw_sh = wgrad_raw(cat, dactv, gs, NHIDDEN, lab.nc, 3, 3, cin_first=NHIDDEN)
+                db_sh = channel_dot(dactv, None, NHIDDEN).clone()
+            else:
+                dactv = (_wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True) if wino_d
+                         else conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga))
+                dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
+                wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
+                L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw_sh,
+                       db_sh, wso)
+        if side is not None:
+            side.join(dw2a, dtable)
+        elif wino_w:
+            dw2a, dtable = wino_wgrad()
+        if wino_w:
+            pass
         elif ctx.has_t:
             # one split-K launch (image-aligned splits): shared columns -> dw2a, one-hot columns per image -> dtable
             nbytes = L.lib().dsee_conv2d_wgrad_table_workspace(C.byref(geom))
