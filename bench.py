@@ -11,8 +11,11 @@ batch that is already resident in HBM: independent 8x 32->256, 19-class blocky m
 
 Extra objects on the line:
   roofline     — the dominant kernel (by summed time in a step), measured live with HIP events on the launch
-                 stream in one extra instrumented step after the timed region: algorithmic FLOPs (2*M*N*K of every
-                 launch of that kernel) / summed duration, against the fp32 MFMA peak (157.3 TFLOP/s).
+                 stream in one extra instrumented step after the timed region: algorithmic fp32 FLOPs (2*M*N*K of
+                 every launch of that kernel) / summed duration.  Peak: 157.3 TFLOP/s for the v_mfma_f32 kernels;
+                 for the bf16x3 kernels (fp32 multiply = 6 exact bf16 MFMA products, deepsee_amd/csrc/gemm_bf16x3.hip)
+                 the dense bf16 MFMA peak / 6 = 419.4 TFLOP/s of fp32 work.
+  f32_mfma_only— the same step with every GEMM kept on v_mfma_f32_32x32x2_f32 (DSEE_F32_MFMA=1 path), rank 0 / N=1.
   cpu_baseline — the oracle (CPU restatement of the reference path, oracle/deepsee_oracle.py) timed on this box's
                  host cores: one G+D iteration at bs=1 of the same workload (rank 0, N=1 only).
 """
@@ -29,6 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense (same guide); a bf16x3 fp32 multiply-add costs 6 bf16 MFMA products
+
+
+def kernel_peak(name):
+    return BF16_MFMA_PEAK_TFLOPS / 6.0 if "bf16x3" in name else FP32_MFMA_PEAK_TFLOPS
 N_PER_GPU = 8
 
 
@@ -81,6 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-run", action="store_true", help="skip the extra v_mfma_f32-only measurement")
     ap.add_argument("--batch-per-gpu", type=int, default=N_PER_GPU)
     args = ap.parse_args()
 
@@ -135,7 +144,22 @@ def main():
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     kd = kernels[dom]
     achieved = kd["tflop"] / (kd["ms"] / 1e3)
+    peak = kernel_peak(dom)
     mfma_ms = sum(k["ms"] for k in kernels.values())
+
+    f32_only = None
+    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run:
+        ops.GEMM_SPLIT = False
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        fence()
+        dt = (time.perf_counter() - t1) / 3
+        ops.GEMM_SPLIT = True
+        f32_only = {"value": n / dt, "unit": "img/s", "ms_per_step": dt * 1e3, "steps": 3,
+                    "note": "same step, Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 instead of bf16x3"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -147,19 +171,28 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
+            "arithmetic": ("fp32 storage and accumulation; the wide 3x3 layers run as Winograd F(4x4,3x3) GEMMs whose "
+                           "fp32 products are formed exactly from 3-term bf16 operand splits (6 bf16 MFMA products, "
+                           "error below one fp32 rounding; tests/test_gpu_conv.py::test_gemm_bf16x3_is_fp32_accurate)"
+                           if ops.GEMM_SPLIT else "fp32 (v_mfma_f32_32x32x2_f32)"),
             "config": {"workload": "independent 8x 32->256, 19-class masks, bs=%d per GPU, fp32 G+D train step "
                                    "(BASELINE.json configs[1])" % n,
                        "global_batch": n * world, "parallelism": "dp%d" % world,
                        "losses": {k: float(v.detach()) for k, v in tm.get_latest_losses().items()}},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "peak_note": ("fp32 work on the bf16 matrix cores: 2516.6 dense bf16 TFLOP/s / 6 products per "
+                                       "fp32 multiply-add" if "bf16x3" in dom else "v_mfma_f32 dense peak"),
                          "launches_per_step": kd["launches"], "avg_launch_ms": kd["ms"] / kd["launches"],
                          "algorithmic_tflop_per_step": kd["tflop"],
                          "mfma_kernels_ms_per_step": mfma_ms,
                          "all_mfma_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                                  "tflops": round(v["tflop"] / (v["ms"] / 1e3), 2)}
+                                                  "tflops": round(v["tflop"] / (v["ms"] / 1e3), 2),
+                                                  "frac": round(v["tflop"] / (v["ms"] / 1e3) / kernel_peak(k), 3)}
                                               for k, v in kernels.items()}},
         }
+        if f32_only:
+            out["f32_mfma_only"] = f32_only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -6,6 +6,7 @@ save(epoch) / load_weights().  All activation-space compute runs in libdeepsee_h
 """
 import math
 import os
+import sys
 from collections import OrderedDict
 
 import torch
@@ -131,7 +132,7 @@ class SRModel(nn.Module):
             for k, p in self.netE.named_parameters():
                 (g_low if "mini" in k else g_main).append(("E." + k, p))
         lr_g, lr_d = (opt.lr, opt.lr) if opt.no_TTUR else (opt.lr / 2, opt.lr * 2)
-        print("lr G: {}, lr D: {}".format(lr_g, lr_d))
+        print("lr G: {}, lr D: {}".format(lr_g, lr_d), file=sys.stderr)   # (sr_model.py:112 prints this; keep stdout clean)
         groups = [{"params": g_main, "lr": lr_g}]
         if g_low:
             groups.append({"params": g_low, "lr": lr_g / 4})
