@@ -1239,8 +1239,8 @@ int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const floa
 }
 
 // split count per transform position for the Winograd weight gradient (36 * sper splits in all)
-static int wino_sper(long T, int Cin_s, int Cout_s) {
-  const int tiles = dsee_cdiv(dsee_conv_kpad(1, 1, Cin_s), 128) * dsee_cdiv(Cout_s, 128);
+static int wino_sper(long T, int Cin_s, int Cout_s, int groups_per_xi = 1) {
+  const int tiles = dsee_cdiv(dsee_conv_kpad(1, 1, Cin_s), 128) * dsee_cdiv(Cout_s, 128) * groups_per_xi;
   const int want = 4608 / (36 * tiles) > 1 ? 4608 / (36 * tiles) : 1;
   int sper = 1;
   while (sper * 2 <= want && T % (sper * 2) == 0 && (T / (sper * 2)) % 32 == 0 && T / (sper * 2) >= 512) sper *= 2;
@@ -1290,7 +1290,7 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
 }
 
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows) {
-  return (size_t)36 * N * wino_sper(T / N, ca + 32, rows) * rows * dsee_conv_kpad(1, 1, ca + 32) * sizeof(float);
+  return (size_t)36 * N * wino_sper(T / N, ca + 32, rows, N) * rows * dsee_conv_kpad(1, 1, ca + 32) * sizeof(float);
 }
 
 /* Weight gradient of the SEAN gamma/beta GEMM in the Winograd domain (per-image groups, see dsee_wino43_weights_table):
@@ -1304,7 +1304,7 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
   const int ld = ca + 32;
   if (split) {
     DSEE_CHECK_ARG(rows % 128 == 0);
-    const int sper = wino_sper(T / N, ld, rows), Kpad = dsee_conv_kpad(1, 1, ld);
+    const int sper = wino_sper(T / N, ld, rows, N), Kpad = dsee_conv_kpad(1, 1, ld);
     int rc = dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
     if (rc) return rc;
     const long total = (long)rows * ld;
@@ -1320,7 +1320,7 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
   a.mul = 1; a.off = 0; a.kdir = 1; a.dshift = 0; a.ups = 0;
   a.M = (int)(36 * T); a.rows = rows;
   a.korder = 0; a.Kuse = a.Ktot; a.Kstart = 0;
-  const int sper = wino_sper(T / N, ld, rows);
+  const int sper = wino_sper(T / N, ld, rows, N);
   a.msplit = (int)(T / N / sper);
   int rc = wgrad_launch(a, 36 * N * sper, st);
   if (rc) return rc;

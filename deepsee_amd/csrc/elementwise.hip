@@ -353,6 +353,17 @@ __device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&
   for (int k = 0; k < 4; ++k) out[k] = c[k];
 }
 
+// Box-Muller on two pairs of 32-bit draws
+__device__ __forceinline__ f32x4 box_muller4(const uint32_t (&r)[4]) {
+  const float u0 = ((float)r[0] + 1.f) * 2.3283064e-10f, u1 = (float)r[1] * 2.3283064e-10f;
+  const float u2 = ((float)r[2] + 1.f) * 2.3283064e-10f, u3 = (float)r[3] * 2.3283064e-10f;
+  const float a = sqrtf(-2.f * __logf(u0)), b = sqrtf(-2.f * __logf(u2));
+  float s0, c0, s1, c1;
+  __sincosf(6.2831853f * u1, &s0, &c0);
+  __sincosf(6.2831853f * u3, &s1, &c1);
+  return (f32x4){a * c0, a * s0, b * c1, b * s1};
+}
+
 __global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, long total4, uint64_t seed,
                                                        uint64_t offset, int normal) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -360,14 +371,7 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, 
     philox4(seed, offset + (uint64_t)i, r);
     f32x4 v;
     if (normal) {
-      // Box-Muller on two pairs
-      const float u0 = ((float)r[0] + 1.f) * 2.3283064e-10f, u1 = (float)r[1] * 2.3283064e-10f;
-      const float u2 = ((float)r[2] + 1.f) * 2.3283064e-10f, u3 = (float)r[3] * 2.3283064e-10f;
-      const float a = sqrtf(-2.f * __logf(u0)), b = sqrtf(-2.f * __logf(u2));
-      float s0, c0, s1, c1;
-      __sincosf(6.2831853f * u1, &s0, &c0);
-      __sincosf(6.2831853f * u3, &s1, &c1);
-      v = (f32x4){a * c0, a * s0, b * c1, b * s1};
+      v = box_muller4(r);
     } else {
       v = (f32x4){(float)(r[0] >> 8), (float)(r[1] >> 8), (float)(r[2] >> 8), (float)(r[3] >> 8)} * 5.9604645e-8f;
     }
@@ -375,9 +379,80 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, 
   }
 }
 
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t ctr) {
+  uint32_t r[4];
+  philox4(seed, ctr, r);
+  return box_muller4(r);
+}
+
+// same as up_noise_fwd_kernel with eps = the Philox N(0,1) stream (seed, offset + element/4) generated in registers:
+// identical values to dsee_rng_fill(..., seed, offset, normal = 1) followed by the tensor form, without the tensor
+__global__ __launch_bounds__(256) void up_noise_rng_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nw,
+                                                               float* __restrict__ y, int N, int H, int W, int C, int ups,
+                                                               uint64_t seed, uint64_t offset) {
+  const long total4 = (long)N * H * W * C / 4;
+  const int C4 = C / 4, h0 = H >> ups, w0 = W >> ups;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * h0 + (h >> ups)) * w0 + (w >> ups)) * C + q * 4);
+    v += *reinterpret_cast<const f32x4*>(nw + q * 4) * philox_normal4(seed, offset + (uint64_t)i);
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// part[blk][C] = sum_pixels a * eps(seed, offset)   (gradient of the noise weights without the eps tensor)
+__global__ __launch_bounds__(256) void chdot_rng_partial_kernel(const float* __restrict__ a, float* __restrict__ part,
+                                                                long M, int C, int chunk_px, uint64_t seed,
+                                                                uint64_t offset) {
+  __shared__ f32x4 red[256];
+  const int tpp = C / 4, ppb = 256 / tpp > 0 ? 256 / tpp : 1;
+  const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
+  const bool active = threadIdx.x < ppb * tpp;
+  const long p0 = (long)blockIdx.x * chunk_px, p1 = min(M, p0 + chunk_px);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (active)
+    for (long p = p0 + s; p < p1; p += ppb)
+      acc += *reinterpret_cast<const f32x4*>(a + p * C + q * 4) * philox_normal4(seed, offset + (uint64_t)(p * tpp + q));
+  if (active) red[s * tpp + q] = acc;
+  __syncthreads();
+  if (active && s == 0) {
+    f32x4 v = red[q];
+    for (int j = 1; j < ppb; ++j) v += red[j * tpp + q];
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + q * 4) = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+/* y = nearest_up(x) + noise_w[c] * eps with eps = N(0,1) from the Philox stream (seed, offset): the values
+ * dsee_rng_fill(seed, offset, normal) would write, generated in registers (normalization.py:289-304 without the tensor) */
+int dsee_upsample_noise_rng_fwd(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
+                                uint64_t seed, uint64_t offset, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && noise_w && C % 4 == 0);
+  up_noise_rng_fwd_kernel<<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* out[c] = sum_m a[m][c] * eps[m][c] with the same generated eps: d(noise weight), normalization.py:303-304 */
+int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* workspace, uint64_t seed, uint64_t offset,
+                         hipStream_t st) {
+  DSEE_CHECK_ARG(a && out && workspace && C % 4 == 0 && C <= 1024);
+  long cp = (M + 1023) / 1024;
+  if (cp < 64) cp = 64;
+  const int parts = (int)((M + cp - 1) / cp);
+  chdot_rng_partial_kernel<<<parts, 256, 0, st>>>(a, workspace, M, C, (int)cp, seed, offset);
+  DSEE_LAUNCH_CHECK();
+  chdot_finalize_kernel<<<dsee_cdiv(C, 32), 256, 0, st>>>(workspace, parts, C, out);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
 
 int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise_w, float* y, int N, int H, int W, int C,
                             int ups, hipStream_t st) {

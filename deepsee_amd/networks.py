@@ -103,7 +103,14 @@ class DeviceNoise:
         return t
 
     def normal_nhwc(self, shape_nhwc, tag):
-        return self._fill(shape_nhwc, True)
+        """The noise-injection draws are consumed lazily (ops.PhiloxNormal): same stream positions as _fill."""
+        n = 1
+        for s in shape_nhwc:
+            n *= s
+        assert n % 4 == 0
+        t = ops.PhiloxNormal(shape_nhwc, self.seed, self.offset)
+        self.offset += n // 4
+        return t
 
     def uniform(self, shape, tag):
         return self._fill(shape, False)

@@ -172,6 +172,17 @@ class Labels:
         return s
 
 
+class PhiloxNormal:
+    """A N(0,1) tensor that is never materialised: the Philox stream (seed, offset) of dsee_rng_fill, regenerated in
+    registers by the consumers (UpNoise forward and the noise-weight gradient)."""
+
+    def __init__(self, shape, seed, offset):
+        self.shape, self.seed, self.offset = tuple(shape), int(seed), int(offset)
+
+    def materialize(self):
+        return rng_fill(self.shape, self.seed, self.offset, True)
+
+
 def rng_fill(shape, seed, offset, normal=True):
     t = new(*shape)
     assert t.numel() % 4 == 0
@@ -485,7 +496,14 @@ class UpNoise(torch.autograd.Function):
     def forward(ctx, x, noise_w, eps, ups):
         n, h0, w0, c = x.shape
         y = new(n, h0 << ups, w0 << ups, c)
-        L.call("upsample_noise_fwd", x, eps, noise_w if eps is not None else None, y, n, h0 << ups, w0 << ups, c, ups)
+        ctx.philox = eps if isinstance(eps, PhiloxNormal) else None
+        if ctx.philox is not None:
+            assert eps.shape == tuple(y.shape)
+            L.call("upsample_noise_rng_fwd", x, noise_w, y, n, h0 << ups, w0 << ups, c, ups, C.c_uint64(eps.seed),
+                   C.c_uint64(eps.offset))
+            eps = None
+        else:
+            L.call("upsample_noise_fwd", x, eps, noise_w if eps is not None else None, y, n, h0 << ups, w0 << ups, c, ups)
         ctx.ups = ups
         ctx.save_for_backward(eps)
         ctx.xshape = x.shape
@@ -503,7 +521,13 @@ class UpNoise(torch.autograd.Function):
                 L.call("sumpool", dy, dx, n, h, w, c, ctx.ups)
             else:
                 dx = dy
-        if eps is not None and ctx.needs_input_grad[1]:
+        if ctx.philox is not None and ctx.needs_input_grad[1]:
+            m = dy.numel() // c
+            ws = scratch(L.lib().dsee_channel_dot_workspace(C.c_long(m), c), "chdot")
+            dw = new(c)
+            L.call("channel_dot_rng", dy, dw, C.c_long(m), c, ws, C.c_uint64(ctx.philox.seed),
+                   C.c_uint64(ctx.philox.offset))
+        elif eps is not None and ctx.needs_input_grad[1]:
             dw = channel_dot(dy, eps, c).clone()
         return dx, dw, None, None
 

@@ -217,6 +217,13 @@ int dsee_label_segsum(const uint8_t* lab, const float* in, int ld, int coff, flo
 /* y = nearest_up(x, 2^ups) + noise_w[c] * eps   (nn.Upsample sr.py:57 + NoiseInjection normalization.py:299-304) */
 int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise_w, float* y, int N, int H, int W, int C,
                             int ups, hipStream_t stream);
+/* The same with eps generated in registers from the Philox stream (seed, offset) -- bit-identical to
+ * dsee_rng_fill(eps, n, seed, offset, 1) followed by the tensor form, without the 4*M*C-byte tensor -- and the
+ * gradient of the noise weights against the regenerated eps (normalization.py:303-304). */
+int dsee_upsample_noise_rng_fwd(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
+                                uint64_t seed, uint64_t offset, hipStream_t stream);
+int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* workspace, uint64_t seed, uint64_t offset,
+                         hipStream_t stream);
 int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t stream);
 size_t dsee_channel_dot_workspace(long M, int C);
 int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, float* workspace, hipStream_t stream);

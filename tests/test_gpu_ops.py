@@ -182,6 +182,18 @@ def test_upsample_noise_and_sumpool():
     assert rel(nchw(ys.detach(), 16), y.detach()) < TOL
     assert rel(nchw(xs.grad, 16), x.grad) < TOL
     assert rel(ws.grad.cpu(), w.grad) < TOL
+    # production form: eps is the Philox stream regenerated in registers -- must equal the materialised tensor
+    tok = ops.PhiloxNormal((2, 12, 12, 16), seed=77, offset=1234)
+    xa, wa = xs.detach().clone().requires_grad_(), ws.detach().clone().requires_grad_()
+    xb, wb = xs.detach().clone().requires_grad_(), ws.detach().clone().requires_grad_()
+    ya = ops.UpNoise.apply(xa, wa, tok, 1)
+    yb = ops.UpNoise.apply(xb, wb, tok.materialize(), 1)
+    ya.backward(nhwc(gy))
+    yb.backward(nhwc(gy))
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    assert rel(wa.grad.cpu(), wb.grad.cpu()) < 1e-6
+    e = tok.materialize()
+    assert abs(float(e.mean())) < 0.05 and abs(float(e.std()) - 1.0) < 0.05
 
 
 def test_spectral_norm_fwd_bwd_and_buffers():
