@@ -209,3 +209,30 @@ def test_thin_conv3x3(n, cin, cout, h, w, act, use_bias):
     assert rel(wd.grad.cpu(), wt.grad) < 2e-5
     if use_bias:
         assert rel(bd.grad.cpu(), b.grad) < 2e-5
+
+
+def test_bf16x3_adds_no_error_to_the_winograd_conv():
+    """The same 3x3 convolution three ways against float64: direct fp32-MFMA implicit GEMM, Winograd with the 36 GEMMs
+    on v_mfma_f32, Winograd with the GEMMs on the bf16 matrix cores (bf16x3 operand split).  The Winograd transforms
+    set the error level (~10x the direct form); moving the GEMM to bf16x3 must not add to it."""
+    from deepsee_amd import ops
+    n, c, h = 2, 256, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    xd, wd = nhwc(x).cuda(), w.cuda()
+    errs = {}
+    saved = (ops.WINOGRAD, ops.GEMM_SPLIT)
+    try:
+        for name, wino, split in (("direct", False, False), ("winograd_f32", True, False), ("winograd_bf16x3", True, True)):
+            ops.WINOGRAD, ops.GEMM_SPLIT = wino, split
+            y = ops.conv2d(xd, wd, None, None, 1, 1, 0, 0)
+            torch.cuda.synchronize()
+            errs[name] = float((nchw(y.cpu(), c).double() - ref).norm() / ref.norm())
+    finally:
+        ops.WINOGRAD, ops.GEMM_SPLIT = saved
+    print(errs)
+    assert errs["direct"] < 1e-6
+    assert errs["winograd_f32"] < 2e-5
+    assert errs["winograd_bf16x3"] <= 1.1 * errs["winograd_f32"] + 1e-7, errs

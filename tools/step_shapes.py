@@ -25,6 +25,7 @@ _t = ops._timed
 class T(_t):
     def __init__(self, name, flops):
         if name.startswith("conv_wgrad"): name = getattr(ops, "_wg", name)
+        if name.startswith("winograd"): name = "%s %.3f TFLOP" % (name, flops / 1e12)
         super().__init__(name, flops)
 ops._timed = T
 ops.PROFILE = {}
