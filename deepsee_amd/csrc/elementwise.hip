@@ -75,16 +75,16 @@ __global__ __launch_bounds__(256) void chdot_partial_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void chdot_finalize_kernel(const float* __restrict__ part, int parts, int C,
                                                              float* __restrict__ out) {
-  __shared__ float sv[8][32];
-  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float sv[32][8];   // 8 channels x 32 part-lanes per block, lanes folded in order
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   float v = 0.f;
   if (c < C)
-    for (int p = lane; p < parts; p += 8) v += part[(size_t)p * C + c];
+    for (int p = lane; p < parts; p += 32) v += part[(size_t)p * C + c];
   sv[lane][cl] = v;
   __syncthreads();
   if (lane == 0 && c < C) {
-    for (int l = 1; l < 8; ++l) v += sv[l][cl];
+    for (int l = 1; l < 32; ++l) v += sv[l][cl];
     out[c] = v;
   }
 }
@@ -449,7 +449,7 @@ int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* works
   const int parts = (int)((M + cp - 1) / cp);
   chdot_rng_partial_kernel<<<parts, 256, 0, st>>>(a, workspace, M, C, (int)cp, seed, offset);
   DSEE_LAUNCH_CHECK();
-  chdot_finalize_kernel<<<dsee_cdiv(C, 32), 256, 0, st>>>(workspace, parts, C, out);
+  chdot_finalize_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, parts, C, out);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -484,7 +484,7 @@ int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, 
   const int parts = (int)((M + cp - 1) / cp);
   chdot_partial_kernel<<<parts, 256, 0, st>>>(a, b, workspace, M, C, (int)cp);
   DSEE_LAUNCH_CHECK();
-  chdot_finalize_kernel<<<dsee_cdiv(C, 32), 256, 0, st>>>(workspace, parts, C, out);
+  chdot_finalize_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, parts, C, out);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

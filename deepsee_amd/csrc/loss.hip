@@ -49,12 +49,11 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
 }
 
 __global__ void loss_finalize_kernel(const float* __restrict__ part, int parts, float scale, float* __restrict__ out) {
-  // single thread, fixed order: deterministic
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float v = 0.f;
-    for (int i = 0; i < parts; ++i) v += part[i];
-    *out += v * scale;
-  }
+  // one wave, fixed order (lane l folds parts l, l+64, ...; then the butterfly): deterministic
+  float v = 0.f;
+  for (int i = threadIdx.x; i < parts; i += 64) v += part[i];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) *out += v * scale;
 }
 
 }  // namespace

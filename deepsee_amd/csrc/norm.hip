@@ -85,21 +85,21 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restr
   }
 }
 
-// block = 32 channels x 8 chunk-lanes: lane l merges chunks l, l+8, ... (Chan's parallel update), lane 0 then merges
-// the 8 partial triples in lane order -> fixed order, bit-reproducible.
+// block = 8 channels x 32 chunk-lanes: lane l merges chunks l, l+32, ... (Chan's parallel update), lane 0 then merges
+// the 32 partial triples in lane order -> fixed order, bit-reproducible (2048 chunks: 64 serial steps per lane).
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part,
                                                              float* __restrict__ mean_out,
                                                              float* __restrict__ invstd_out,
                                                              float* __restrict__ run_mean, float* __restrict__ run_var,
                                                              RedGeom g, float eps, float momentum) {
-  __shared__ float sn[8][32], sm[8][32], s2[8][32];
-  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cl;
+  __shared__ float sn[32][8], sm[32][8], s2[32][8];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + cl;
   const bool ok = i < g.groups * g.C;
   const int grp = ok ? i / g.C : 0, c = ok ? i % g.C : 0;
   float n = 0.f, mean = 0.f, m2 = 0.f;
   if (ok)
-    for (int k = lane; k < g.chunks; k += 8) {
+    for (int k = lane; k < g.chunks; k += 32) {
       const int p0 = k * g.chunk_px, p1 = min(g.P, p0 + g.chunk_px);
       const float nb = (float)(p1 - p0);
       const float mb = part[((size_t)(grp * g.chunks + k) * 2) * g.C + c];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   s2[lane][cl] = m2;
   __syncthreads();
   if (lane != 0 || !ok) return;
-  for (int l = 1; l < 8; ++l) {
+  for (int l = 1; l < 32; ++l) {
     const float nb = sn[l][cl];
     if (nb == 0.f) continue;
     const float d = sm[l][cl] - mean, nt = n + nb;
@@ -220,20 +220,20 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums,
                                                             int K, RedGeom g) {
-  // sums[k][grp][c] = sum over chunks; 32 outputs x 8 chunk-lanes per block, lanes folded in order
-  __shared__ float sv[8][32];
-  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cl;
+  // sums[k][grp][c] = sum over chunks; 8 outputs x 32 chunk-lanes per block, lanes folded in order
+  __shared__ float sv[32][8];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + cl;
   const bool ok = i < K * g.groups * g.C;
   float v = 0.f;
   if (ok) {
     const int c = i % g.C, grp = (i / g.C) % g.groups, k = i / (g.C * g.groups);
-    for (int ch = lane; ch < g.chunks; ch += 8) v += part[((size_t)(grp * g.chunks + ch) * K + k) * g.C + c];
+    for (int ch = lane; ch < g.chunks; ch += 32) v += part[((size_t)(grp * g.chunks + ch) * K + k) * g.C + c];
   }
   sv[lane][cl] = v;
   __syncthreads();
   if (lane == 0 && ok) {
-    for (int l = 1; l < 8; ++l) v += sv[l][cl];
+    for (int l = 1; l < 32; ++l) v += sv[l][cl];
     sums[i] = v;
   }
 }
@@ -290,7 +290,7 @@ int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps,
   RedGeom g = make_geom(N, HW, C, groups);
   stats_partial_kernel<<<dim3(g.chunks, g.groups), 256, 0, st>>>(x, workspace, g);
   DSEE_LAUNCH_CHECK();
-  stats_finalize_kernel<<<dsee_cdiv((long)g.groups * C, 32), 256, 0, st>>>(workspace, mean, invstd, running_mean,
+  stats_finalize_kernel<<<dsee_cdiv((long)g.groups * C, 8), 256, 0, st>>>(workspace, mean, invstd, running_mean,
                                                                            running_var, g, eps, momentum);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
@@ -325,7 +325,7 @@ int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const flo
   norm_bwd_reduce_kernel<0><<<dim3(g.chunks, g.groups), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, nullptr, 0,
                                                                        workspace, g, act, slope);
   DSEE_LAUNCH_CHECK();
-  sums_finalize_kernel<<<dsee_cdiv((long)2 * g.groups * C, 32), 256, 0, st>>>(workspace, sums, 2, g);
+  sums_finalize_kernel<<<dsee_cdiv((long)2 * g.groups * C, 8), 256, 0, st>>>(workspace, sums, 2, g);
   DSEE_LAUNCH_CHECK();
   const long total4 = (long)N * HW * C / 4;
   norm_bwd_apply_kernel<0><<<grid_for(total4), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, sums, nullptr, dx, total4,
@@ -349,7 +349,7 @@ int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const flo
   norm_bwd_reduce_kernel<1><<<dim3(g.chunks, 1), 256, 0, st>>>(dh, h, x, scale, mean, invstd, dgb, dgb_ld, workspace, g,
                                                                 DSEE_ACT_LRELU, slope);
   DSEE_LAUNCH_CHECK();
-  sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 32), 256, 0, st>>>(workspace, sums, 4, g);
+  sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 8), 256, 0, st>>>(workspace, sums, 4, g);
   DSEE_LAUNCH_CHECK();
   (void)hipMemcpyAsync(col_sums, sums + 2 * C, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, st);
   const long total4 = (long)N * HW * C / 4;
