@@ -420,13 +420,15 @@ static int gemm3_num_cus() {
 template <int WM, int WN, int MT, int NT, int FL>
 int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  static const bool use_reg = getenv("DSEE_G3_REG") != nullptr;  // register-staged variant (for A/B measurements)
+  constexpr bool reg_ok = (BM * 6) % (WM * WN * 64) == 0 && (BN * 6) % (WM * WN * 64) == 0;
+  static const bool use_reg = reg_ok && getenv("DSEE_G3_REG") != nullptr;  // register-staged variant (A/B measurements)
   constexpr int NSLOT = (region_slots(BM) + 63) / 64 + (region_slots(BN) + 63) / 64;
   const size_t lds = use_reg ? (size_t)2 * (BM + BN) * ROWB : (size_t)3 * NSLOT * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<WM, WN, MT, NT, FL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (BM + BN) * ROWB));
+    if constexpr (reg_ok)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<WM, WN, MT, NT, FL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (BM + BN) * ROWB));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3g_kernel<WM, WN, MT, NT, FL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * NSLOT * 1024));
     attr_done = true;
@@ -436,10 +438,14 @@ int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN) * nz;
   const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);   // resident blocks
   const long grid = ntile < slots ? ntile : slots;
-  if (use_reg)
-    gemm3_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
-  else
-    gemm3g_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
+  if constexpr (reg_ok) {
+    if (use_reg) {
+      gemm3_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
+      DSEE_LAUNCH_CHECK();
+      return DSEE_OK;
+    }
+  }
+  gemm3g_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -484,7 +490,11 @@ int dsee_gemm_bf16x3_tn(const void* P3t, const void* Q3t, float* C, int groups, 
   a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p; a.b_group_bytes = 0;
   a.a_slab_bytes = (long)rows_p * 96; a.b_slab_bytes = (long)rows_q * 96;
   a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
-  // 128x128 tiles (two blocks per CU, registers to spare for the second accumulator level)
+  // 128x128 tiles (two blocks per CU, registers to spare for the second accumulator level); the SPADE/SEAN table
+  // gradient has 160 columns: a 256x160 tile (8 waves x (32 rows x 160 columns)) fits them exactly
+  if (rows_q == 160 && rows_p % 256 == 0) return launch_gemm3<8, 1, 1, 5, 16>(a, groups * splits, st);
+  if (rows_p % 256 == 0 && rows_q % 128 == 0 && (long)(rows_p / 256) * (rows_q / 128) * groups * splits >= 512)
+    return launch_gemm3<4, 2, 2, 2, 16>(a, groups * splits, st);  // 256x128, 8 waves
   return launch_gemm3<2, 2, 2, 2, 16>(a, groups * splits, st);
 }
 
