@@ -89,6 +89,31 @@ __device__ __forceinline__ void at4(const f32x4 (&m)[6], f32x4 (&o)[4]) {
   o[3] = d12 + 8.f * d34 + m[5];
 }
 
+// Wave-wide linear store of one 16-row x 96-byte block of a split matrix (rows contiguous in memory): every lane drops
+// its 4 values x 3 terms (8 bytes per term) into a wave-private 1536-byte LDS image of the block at
+// row*96 + term*32 + quad*8 and the wave then writes the image with fully contiguous 16-byte-per-lane stores
+// (64 + 32 lanes) -- 1 KB runs per store instruction instead of 32-byte pieces at a 96-byte stride.
+__device__ __forceinline__ void store_block_linear(unsigned* sb, unsigned short* gblock, int l, int row, int quad,
+                                                   const f32x4& v) {
+  unsigned pk[3][2];
+  split4_packed(v, pk);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const uint2 w = {pk[p][0], pk[p][1]};
+    *reinterpret_cast<uint2*>(sb + row * 24 + p * 8 + quad * 2) = w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const u32x4 a = *reinterpret_cast<const u32x4*>(sb + l * 4);
+  u32x4 b = {0u, 0u, 0u, 0u};
+  if (l < 32) b = *reinterpret_cast<const u32x4*>(sb + 256 + l * 4);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  *reinterpret_cast<u32x4*>(gblock + l * 8) = a;
+  if (l < 32) *reinterpret_cast<u32x4*>(gblock + 512 + l * 8) = b;
+}
+
 // Output modes of the transform kernels: fp32 rows | bf16x3 slab-major with k = channel (forward / data-gradient GEMM
 // operands) | bf16x3 slab-major with k = tile (weight-gradient operands, [xi][T/16][C][3][16 tiles])
 constexpr int OUT_F32 = 0, OUT_SPLIT = 1, OUT_SPLIT_T = 2;
@@ -113,8 +138,8 @@ __device__ __forceinline__ void wave_tile_quad(long i, int C4, long T, int& q, l
 
 // OUT_SPLIT_T: transpose the wave's 16 tiles x 16 channels through LDS so that lane (channel l>>2, tile quad l&3)
 // holds 4 consecutive tiles of one channel, then split and store 8 bytes per term
-__device__ __forceinline__ void emit_split_t(float* tb, unsigned short* base, int xi, long T, int C, int l, long tblk,
-                                             int ch0, const f32x4& o) {
+__device__ __forceinline__ void emit_split_t(float* tb, unsigned* lb, unsigned short* base, int xi, long T, int C, int l,
+                                             long tblk, int ch0, const f32x4& o) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) tb[(4 * (l & 3) + e) * 20 + (l >> 2)] = o[e];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -123,21 +148,15 @@ __device__ __forceinline__ void emit_split_t(float* tb, unsigned short* base, in
   const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (l >> 2) * 20 + 4 * (l & 3));
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  unsigned short h[4][3];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) split3(v[e], h[e]);
-  const size_t row = ((size_t)xi * (T >> 4) + tblk) * C + ch0 + (l >> 2);
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    const u16x4 wv = {h[0][p], h[1][p], h[2][p], h[3][p]};
-    *reinterpret_cast<u16x4*>(base + (row * 3 + p) * 16 + 4 * (l & 3)) = wv;
-  }
+  // rows = the 16 channels ch0.. of tile block tblk (contiguous 96-byte rows): one linear 1536-byte block
+  store_block_linear(lb, base + (((size_t)xi * (T >> 4) + tblk) * C + ch0) * 48, l, l >> 2, l & 3, v);
 }
 
 template <int OUT>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N,
                                                            int H, int W, int C) {
   __shared__ __attribute__((aligned(16))) float tbuf[OUT == OUT_SPLIT_T ? 4 : 1][16 * 20];
+  __shared__ __attribute__((aligned(16))) unsigned lbuf[OUT != OUT_F32 ? 4 : 1][384];
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -175,19 +194,20 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
       f32x4 o[6];
       bt6(tmp[k], o);  // (B^T d) B : same combination along the row
       if constexpr (OUT == OUT_SPLIT) {
-        // lanes 2m / 2m+1 hold channel quads (8m, 8m+4) of the same tile: one 16-byte store per term and xi pair
-        const int k8 = (q & ~1) * 4;
+        // the wave's 16 tiles are 16 consecutive rows of slab kb: one contiguous 1536-byte block per xi
+        const int l = (int)(i & 63);
 #pragma unroll
-        for (int j = 0; j < 6; j += 2)
-          store_split_pair(reinterpret_cast<unsigned short*>(V), o[j], o[j + 1], (threadIdx.x & 1) != 0,
-                           split_index((size_t)(k * 6 + j) * T + t, k8, (size_t)36 * T, 0),
-                           split_index((size_t)(k * 6 + j + 1) * T + t, k8, (size_t)36 * T, 0));
+        for (int j = 0; j < 6; ++j)
+          store_block_linear(lbuf[threadIdx.x >> 6],
+                             reinterpret_cast<unsigned short*>(V) +
+                                 split_index((size_t)(k * 6 + j) * T + tg * 16, kb * 16, (size_t)36 * T, 0),
+                             l, l >> 2, l & 3, o[j]);
         continue;
       }
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         if constexpr (OUT == OUT_SPLIT_T)
-          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(V), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
+          emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(V), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
         else
           *reinterpret_cast<f32x4*>(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
       }
@@ -211,6 +231,7 @@ template <int OUT>
 __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N,
                                                           int H, int W, int C) {
   __shared__ __attribute__((aligned(16))) float tbuf[OUT == OUT_SPLIT_T ? 4 : 1][16 * 20];
+  __shared__ __attribute__((aligned(16))) unsigned lbuf[OUT != OUT_F32 ? 4 : 1][384];
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         if constexpr (OUT == OUT_SPLIT_T)
-          emit_split_t(tbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
+          emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
         else
           *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
       }
