@@ -14,7 +14,7 @@
 //   ONE contiguous block of rows x 96 B, so every cache line fetched is used whole, once).
 // Kernel: BK = 16 slabs, two LDS stages of [(BM+BN) rows][3 terms][16 k] (+16 B pad: 112 B rows, conflict-free
 // ds_read_b128 fragments), register-staged buffer loads (per-thread offsets fixed, buffer base advanced per slab),
-// operands swapped in the MFMA so that a lane ends up with 4 consecutive n per row m -> 16-byte stores.
+// a lane ends with one output column and 16 rows: dword stores, whole 128-byte lines per half-wave.
 #include <stdlib.h>
 
 #include "dsee_common.h"
@@ -352,12 +352,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
       for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * TSTEP + p * 32);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][2], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[2], af[i][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][0], acc[i][j], 0, 0, 0);
+        // smallest terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][j], 0, 0, 0);
       }
     }
     cur = cur == 2 * STAGE ? 0 : cur + STAGE;
@@ -383,16 +384,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
       float* cz = a.C + z * a.c_z_elems;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const long m = bm * BM + wm * MT * 32 + i * 32 + (lane & 31);
+        const long mb = bm * BM + wm * MT * 32 + i * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const int n0 = bn * BN + wn * NT * 32 + j * 32 + 4 * (lane >> 5);
+          // D[m][n]: lane = column n, registers = rows m.  Dword stores, 128 contiguous bytes per row and half-wave:
+          // measured 5 % (K = 512) to 11 % (K = 160) faster than the operand-swapped form with 16-byte stores in
+          // 32-byte pieces -- the write path wants whole lines, not fewer instructions.
+          const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
           f32x16& d = FL > 0 ? tot[FL > 0 ? i : 0][FL > 0 ? j : 0] : acc[i][j];
+          if (n < a.N)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-            if (n0 + 8 * g < a.N) *reinterpret_cast<f32x4*>(cz + m * a.ldc + n0 + 8 * g) = v;
-          }
+            for (int r = 0; r < 16; ++r) cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = d[r];
 #pragma unroll
           for (int r = 0; r < 16; ++r) d[r] = 0.f;
         }
