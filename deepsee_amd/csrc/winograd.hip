@@ -164,7 +164,21 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
     long t;
     long tg = 0;
     int kb = 0;
-    if constexpr (OUT != OUT_F32) {
+    if constexpr (OUT == OUT_SPLIT) {
+      // k = channel layout: a wave = 8 consecutive tiles x 32 channels (two slabs).  Loads are whole 128-byte lines
+      // (8 quads of a pixel), stores two 768-byte runs (8 rows x 96 B of each slab) through the LDS image.
+      // Strip-major wave order as below (C % 32 == 0, T % 8 == 0).
+      const int C32 = C4 >> 3;
+      const long G8 = T >> 3;
+      const long S = G8 % 512 == 0 ? 512 : G8;
+      const long w = i >> 6;
+      const int l = (int)(i & 63);
+      const long strip = w / (C32 * S), rem = w - strip * (C32 * S);
+      kb = (int)(rem / S);            // 32-channel block
+      tg = strip * S + rem % S;       // group of 8 tiles
+      q = kb * 8 + (l & 7);
+      t = tg * 8 + (l >> 3);
+    } else if constexpr (OUT == OUT_SPLIT_T) {
       wave_tile_quad(i, C4, T, q, t, tg, kb);
     } else {
       q = (int)(i % C4);
@@ -194,14 +208,33 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
       f32x4 o[6];
       bt6(tmp[k], o);  // (B^T d) B : same combination along the row
       if constexpr (OUT == OUT_SPLIT) {
-        // the wave's 16 tiles are 16 consecutive rows of slab kb: one contiguous 1536-byte block per xi
         const int l = (int)(i & 63);
+        unsigned* sb = lbuf[threadIdx.x >> 6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          store_block_linear(lbuf[threadIdx.x >> 6],
-                             reinterpret_cast<unsigned short*>(V) +
-                                 split_index((size_t)(k * 6 + j) * T + tg * 16, kb * 16, (size_t)36 * T, 0),
-                             l, l >> 2, l & 3, o[j]);
+        for (int j = 0; j < 6; ++j) {
+          unsigned pk[3][2];
+          split4_packed(o[j], pk);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const uint2 wv = {pk[p][0], pk[p][1]};
+            *reinterpret_cast<uint2*>(sb + ((l & 7) >> 2) * 192 + (l >> 3) * 24 + p * 8 + (l & 3) * 2) = wv;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const u32x4 c0 = *reinterpret_cast<const u32x4*>(sb + l * 4);
+          u32x4 c1 = {0u, 0u, 0u, 0u};
+          if (l < 32) c1 = *reinterpret_cast<const u32x4*>(sb + 256 + l * 4);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // chunk l of the image: run l / 48 (slab 2*kb + run), 16-byte piece l % 48; second pass: chunks 64 + l
+          unsigned short* g0 = reinterpret_cast<unsigned short*>(V) +
+                               split_index((size_t)(k * 6 + j) * T + tg * 8, kb * 32, (size_t)36 * T, 0);
+          unsigned short* g1 = reinterpret_cast<unsigned short*>(V) +
+                               split_index((size_t)(k * 6 + j) * T + tg * 8, kb * 32 + 16, (size_t)36 * T, 0);
+          *reinterpret_cast<u32x4*>((l < 48 ? g0 + l * 8 : g1 + (l - 48) * 8)) = c0;
+          if (l < 32) *reinterpret_cast<u32x4*>(g1 + (l + 16) * 8) = c1;
+        }
         continue;
       }
 #pragma unroll
@@ -506,9 +539,9 @@ int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipS
   return DSEE_OK;
 }
 
-/* same transform, output as bf16x3-split rows for dsee_gemm_bf16x3: V3 [C/16][36*T][3][16] bf16 (C % 16 == 0) */
+/* same transform, output as bf16x3-split rows for dsee_gemm_bf16x3: V3 [C/16][36*T][3][16] bf16 (C % 32 == 0) */
 int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C, hipStream_t st) {
-  DSEE_CHECK_ARG(x && V3 && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
+  DSEE_CHECK_ARG(x && V3 && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 8 == 0);
   wino43_input_kernel<OUT_SPLIT><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
       x, reinterpret_cast<float*>(V3), N, H, W, C);
   DSEE_LAUNCH_CHECK();
