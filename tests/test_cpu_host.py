@@ -141,3 +141,36 @@ def test_data_parallel_grad_allreduce_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bf16x3_split_arithmetic_emulated_on_cpu():
+    """The numerical argument behind deepsee_amd/csrc/gemm_bf16x3.hip, emulated with torch on the CPU: an fp32 value is
+    EXACTLY the sum of three bf16 terms, and the six partial products of weight above 2^-26 accumulated in fp32 give a
+    GEMM error (vs float64) no larger than a plain fp32 GEMM's; with only three products it is ~16x larger."""
+    import torch
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(256, 512, generator=g) * torch.rand(256, 1, generator=g).exp()
+    b = torch.randn(512, 192, generator=g)
+
+    def split(x):
+        x0 = x.bfloat16().float()
+        r = x - x0
+        x1 = r.bfloat16().float()
+        r = r - x1
+        x2 = r.bfloat16().float()
+        assert torch.equal(x0 + x1 + x2, x) and float((r - x2).abs().max()) == 0.0
+        return x0, x1, x2
+
+    a0, a1, a2 = split(a)
+    b0, b1, b2 = split(b)
+    ref = a.double() @ b.double()
+    err = lambda y: float((y.double() - ref).norm() / ref.norm())
+    acc = torch.zeros(256, 192)
+    for k in range(0, 512, 16):                      # one MFMA = 16 k's; smallest terms first, one fp32 accumulator
+        s = slice(k, k + 16)
+        for x, y in ((a2, b0), (a1, b1), (a0, b2), (a1, b0), (a0, b1), (a0, b0)):
+            acc = acc + x[:, s] @ y[s]
+    e6, e32 = err(acc), err(a @ b)
+    e3 = err(a0 @ b0 + (a0 @ b1 + a1 @ b0))
+    assert e6 <= 1.5 * e32 and e6 < 5e-7, (e6, e32)
+    assert e3 > 8 * e6                               # the three small products are what makes it fp32-accurate
