@@ -338,7 +338,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(nxt);  // the stage everybody finished reading in the previous iteration
     const unsigned char* sb = smem + cur;
     bf16x8 af[MT][3];
 #pragma unroll
@@ -350,6 +349,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
       bf16x8 bf[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * TSTEP + p * 32);
+      if (j == 0) {
+        // the LDS-DMA of the stage everybody finished reading in the previous iteration is issued behind this slab's
+        // fragment reads, so that the first MFMAs do not wait for 7 M0 updates + buffer_loads
+        __builtin_amdgcn_sched_barrier(0);
+        issue(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         // smallest terms first
