@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void wino43_output_modulate_kernel(
         f32x4 v = xh * sc + (yb[k][j] + bb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-        *reinterpret_cast<f32x4*>(scale + off) = sc;
+        if (scale) *reinterpret_cast<f32x4*>(scale + off) = sc;  // saved for the backward pass only
         *reinterpret_cast<f32x4*>(out + off) = v;
       }
   }
@@ -598,7 +598,7 @@ int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int tr
 int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const float* x, const float* mean,
                                 const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
                                 int rows, float add_one, float slope, hipStream_t st) {
-  DSEE_CHECK_ARG(M && x && mean && invstd && out_h && out_scale && C % 64 == 0 && rows == 2 * C);
+  DSEE_CHECK_ARG(M && x && mean && invstd && out_h && C % 64 == 0 && rows == 2 * C);  // out_scale may be NULL
   DSEE_CHECK_ARG(H % 4 == 0 && W % 4 == 0);
   wino43_output_modulate_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
       M, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W, C, rows, add_one, slope);

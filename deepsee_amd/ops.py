@@ -723,8 +723,10 @@ class SeanNormTable(torch.autograd.Function):
         if has_a:
             w2a = w2a.contiguous()
         tb = table.contiguous() if has_t else None
-        out, scale = torch.empty_like(x), torch.empty_like(x)
         nb = ctx.wino_nb = _wino_mod_chunk(n, h, w, c, rows, has_t)
+        # `scale` is only read by the backward pass: the no-grad generator forward of the D step does not write it
+        need_scale = any(ctx.needs_input_grad) or not nb
+        out, scale = torch.empty_like(x), (torch.empty_like(x) if need_scale else None)
         if nb:
             tpi = (h // 4) * (w // 4)
             kp = L.kpad(1, 1, ld)
@@ -738,7 +740,7 @@ class SeanNormTable(torch.autograd.Function):
                     u = _wino_u(w2a, rows, ca, False, rows, kp, split)
                 m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split)
                 L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
-                       scale[n0:n0 + nb], nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
+                       scale[n0:n0 + nb] if need_scale else None, nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
         else:
             wp = _pack_fwd(w2a, ca, 1) if has_a else None
             with _timed(_variant(geom, True), _flops(geom)):
