@@ -242,13 +242,16 @@ GEMM_SPLIT = os.environ.get("DSEE_F32_MFMA", "0") != "1"
 
 
 def _wino_chunk(n, h, w, cmax, per_image=False):
-    """Images per Winograd pass: the transformed tensors [36][T][C] are addressed with 32-bit byte offsets, and a
-    128-row GEMM tile must not straddle two groups (transform positions; with per_image also images)."""
+    """Images per Winograd pass.  A 128-row GEMM tile must not straddle two groups (transform positions; with
+    per_image also images).  The fp32-MFMA kernels address the transformed tensors [36][T][C] with 32-bit byte
+    offsets; the bf16x3 path (64-bit tile bases) is only bounded to 16 GB per operand."""
     if h % 4 or w % 4:
         return None
     tpi = (h // 4) * (w // 4)
+    wide = GEMM_SPLIT and cmax % 32 == 0
     for nb in range(n, 0, -1):
-        if n % nb == 0 and 36 * nb * tpi * cmax * 4 < 0xF0000000 and ((tpi if per_image else nb * tpi) % 128 == 0):
+        fits = 36 * nb * tpi * cmax * 6 < (1 << 34) if wide else 36 * nb * tpi * cmax * 4 < 0xF0000000
+        if n % nb == 0 and fits and ((tpi if per_image else nb * tpi) % 128 == 0):
             return nb
     return None
 
