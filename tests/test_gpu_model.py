@@ -119,6 +119,28 @@ def test_train_step_matches_oracle(name):
     print("G-grad rel err: median %.2e max %.2e; D-grad max %.2e" % (errs[len(errs) // 2], errs[-1], derrs[-1]))
 
 
+def test_full_size_step_matches_oracle():
+    """BASELINE.json configs[1] at its full size (independent 8x 32 -> 256, 512-channel generator, every Winograd /
+    bf16x3 / per-image-table kernel at the shapes the benchmark runs) with bs = 1 against the CPU oracle: one G step +
+    one D step on identical weights, inputs, noise and branch decisions (~10 s of oracle time on the host cores)."""
+    over = dict(batchSize=1)
+    orc, tm, out = run_case(over, seed=4242)
+    r = out[0]
+    for k, v in r["gl"].items():
+        assert abs(r["hgl"][k] - v) <= 1e-4 * abs(v), (k, r["hgl"][k], v)
+    dev = rel(r["hfake"], r["fake"])
+    assert dev < 1e-4, dev
+    assert r["touched_g"] == set(r["ggrads"])
+    gmax = max(float(v.norm()) for v in r["ggrads"].values())
+    errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
+                  for k, v in r["ggrads"].items())
+    assert errs[len(errs) // 2] < 2e-2 and errs[-1] < 1e-1, (errs[len(errs) // 2], errs[-1])
+    for k, v in r["dl"].items():
+        assert abs(r["hdl"][k] - v) <= 2e-3 * abs(v), (k, r["hdl"][k], v)
+    print("full size: |fake - oracle| / |oracle| = %.2e, G-grad rel err median %.2e max %.2e, losses %s"
+          % (dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
+
+
 @pytest.mark.parametrize("name", ["indep_8to64_ngf8", "guided_4to32_ngf8", "puresean_4to128_ngf4", "config1_4to32_full"])
 def test_smooth_loss_backward(name):
     """Backward parity with the sign-function losses taken out: L_G = <fake, R>, L_D = sum_k <D_k(cat[fake;real]), R_k>,
