@@ -1,6 +1,6 @@
 """SRModel — the model facade of the hot path, same surface as the reference's
 deepsee_models/sr_model.py::SRModel: attributes netSR / netD / netE / opt / model_variant / logs /
-last_encoded_style_is_full / last_encoded_style_is_noisy; forward(data, mode) with modes 'generator',
+last_encoded_style_is_full / last_encoded_style_is_noisy; forward(data, mode) with modes 'generator', 'encode_only', 'demo',
 'discriminator', 'inference' (anything else raises ValueError like sr_model.py:445-446); create_optimizers(opt);
 save(epoch) / load_weights().  All activation-space compute runs in libdeepsee_hip.so.
 """
@@ -118,6 +118,16 @@ class SRModel(nn.Module):
         elif mode == "inference":
             with torch.no_grad():
                 fake, _ = self.generate_fake(d, no_noise=True)
+            data["fake_image"] = ops.to_nchw(fake, 3)
+            return {k: v for k, v in data.items() if v is not None}
+        elif mode == "encode_only":
+            # sr_model.py:92-99: the (uncorrupted) style matrix [N, label_nc, regional_style_size]
+            return self.encode_style(d, no_noise=True)
+        elif mode == "demo":
+            # sr_model.py:100-108: the generator alone on an explicit style matrix `encoded_style`
+            with torch.no_grad():
+                style = data["encoded_style"].to("cuda", torch.float32).contiguous()
+                fake = self.netSR(d["image_lr"], d["labels"], style, self.noise, self.training)
             data["fake_image"] = ops.to_nchw(fake, 3)
             return {k: v for k, v in data.items() if v is not None}
         else:

@@ -771,6 +771,31 @@ class Oracle:
         return fake
 
 
+    def encode_only(self, batch):
+        """sr_model.py:92-99 (`encode_only`, as the inference / demo managers call it: eval mode): the style matrix
+        [N, label_nc, regional_style_size] of the style image without corruption noise."""
+        was = self.training
+        self.training = False
+        try:
+            with torch.no_grad():
+                style = self.encode_style(self.preprocess(batch), no_noise=True)
+        finally:
+            self.training = was
+        return style
+
+    def demo(self, batch, encoded_style):
+        """sr_model.py:100-108 (`demo`): the generator alone on an explicit style matrix (eval mode, no noise)."""
+        was = self.training
+        self.training = False
+        try:
+            with torch.no_grad():
+                data = self.preprocess(batch)
+                fake = self.sr_forward(data["image_lr"], data["input_semantics"], encoded_style)
+        finally:
+            self.training = was
+        return fake
+
+
 # --------------------------------------------------------------------------- synthetic batches
 def synthetic_batch(opt, n, seed=1234, guided=None):
     """blocky 19-class label map (16x16 cells, nearest-upsampled) and

@@ -150,6 +150,28 @@ def run_case(name, spec, tol0=2e-5):
     worst = max(worst, e)
     assert e < tol, (name, "inference", e)
     inference_rec = {"fake_norm": float(out["fake_image"].norm()), "fake_slice": slice_of(out["fake_image"])}
+    # encode_only / demo (sr_model.py:92-108), eval mode as the inference and demo managers run them
+    model.eval()
+    with torch.no_grad():
+        b = {k: v.clone() for k, v in batch.items()}
+        pre = tm.preprocess_input(b)
+        rstyle = model(dict(pre), mode="encode_only")
+        # an explicit, perturbed style matrix so that `demo` is not just `inference` again
+        given = (rstyle.detach() * 0.5 + 0.1).clamp(-1, 1)
+        pre2 = dict(tm.preprocess_input({k: v.clone() for k, v in batch.items()}))
+        pre2["encoded_style"] = given
+        rdemo = model(pre2, mode="demo")["fake_image"]
+    model.train()
+    ostyle = orc.encode_only({k: v.clone() for k, v in batch.items()})
+    odemo = orc.demo({k: v.clone() for k, v in batch.items()}, given)
+    for what, a_, b_ in (("encode_only", ostyle, rstyle), ("demo", odemo, rdemo)):
+        e = rel(a_, b_)
+        worst = max(worst, e)
+        assert e < tol, (name, what, e)
+    inference_rec["style_norm"] = float(rstyle.norm())
+    inference_rec["style_slice"] = slice_of(rstyle)
+    inference_rec["demo_fake_norm"] = float(rdemo.norm())
+    inference_rec["demo_fake_slice"] = slice_of(rdemo)
     ref_rng = None
     orc_rng = None
     for it in range(spec["iters"]):

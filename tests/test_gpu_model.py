@@ -267,6 +267,17 @@ def test_inference_mode_matches_oracle():
     out = tm.sr_model(tm.preprocess_input({k: v.clone() for k, v in batch.items()}), mode="inference")
     tm.sr_model.train()
     assert rel(out["fake_image"].cpu(), want) < 1e-4
+    # encode_only / demo (sr_model.py:92-108)
+    tm.sr_model.eval()
+    pre = tm.preprocess_input({k: v.clone() for k, v in batch.items()})
+    style = tm.sr_model(dict(pre), mode="encode_only")
+    want_style = orc.encode_only({k: v.clone() for k, v in batch.items()})
+    assert tuple(style.shape) == tuple(want_style.shape) and rel(style.detach().cpu(), want_style) < 1e-4
+    given = (want_style * 0.5 + 0.1).clamp(-1, 1)
+    pre["encoded_style"] = given
+    demo = tm.sr_model(pre, mode="demo")
+    tm.sr_model.train()
+    assert rel(demo["fake_image"].cpu(), orc.demo({k: v.clone() for k, v in batch.items()}, given)) < 1e-4
     with pytest.raises(ValueError):
         tm.sr_model({}, mode="bogus")
 

@@ -53,6 +53,14 @@ def test_oracle_matches_reference_fixture(case):
     fake = orc.inference({k: v.clone() for k, v in batch.items()})
     assert close(slice_of(fake), rec["inference"]["fake_slice"], TOL_OUT)
     assert abs(float(fake.norm()) - rec["inference"]["fake_norm"]) <= TOL_OUT * rec["inference"]["fake_norm"]
+    # encode_only / demo modes: the reference's style matrix, and its generator output for the explicit
+    # style matrix 0.5 * style + 0.1 (the transformation gen_golden.py applied)
+    style = orc.encode_only({k: v.clone() for k, v in batch.items()})
+    assert close(slice_of(style), rec["inference"]["style_slice"], TOL_OUT)
+    assert abs(float(style.norm()) - rec["inference"]["style_norm"]) <= TOL_OUT * rec["inference"]["style_norm"]
+    demo = orc.demo({k: v.clone() for k, v in batch.items()}, (style * 0.5 + 0.1).clamp(-1, 1))
+    assert close(slice_of(demo), rec["inference"]["demo_fake_slice"], TOL_OUT)
+    assert abs(float(demo.norm()) - rec["inference"]["demo_fake_norm"]) <= TOL_OUT * rec["inference"]["demo_fake_norm"]
 
     random.seed(rec["rng_seed"])
     torch.manual_seed(rec["rng_seed"])
