@@ -174,3 +174,21 @@ def test_bf16x3_split_arithmetic_emulated_on_cpu():
     e3 = err(a0 @ b0 + (a0 @ b1 + a1 @ b0))
     assert e6 <= 1.5 * e32 and e6 < 5e-7, (e6, e32)
     assert e3 > 8 * e6                               # the three small products are what makes it fp32-accurate
+
+
+def test_style_matrix_csv_roundtrip(tmp_path):
+    """deepsee_amd.util.save_style_matrix writes what the reference's util/util.py:150-158 writes (numpy.savetxt with
+    ',' delimiter) and load_style_matrix reads it back bit-exactly in fp32."""
+    import numpy as np
+    import torch
+    from deepsee_amd.util import load_style_matrix, save_style_matrix
+    m = (torch.rand(19, 128, generator=torch.Generator().manual_seed(3)) * 2 - 1)
+    p = str(tmp_path / "sub" / "style.csv")
+    save_style_matrix(m, p, create_dir=True)
+    want = str(tmp_path / "ref.csv")
+    np.savetxt(want, np.array(m), delimiter=",")
+    assert open(p).read() == open(want).read()
+    assert torch.equal(load_style_matrix(p, device="cpu"), m)
+    import pytest
+    with pytest.raises(AssertionError):
+        save_style_matrix(m[None], p)
