@@ -35,6 +35,11 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense (same guide); a bf16x3 fp32 multiply-add costs 6 bf16 MFMA products
 
 
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --steps 2 --warmup 1` (372 launches of the kernel):
+# FETCH_SIZE 0.3932 GB reported -> x2 (gfx950 correction, MI355X_MICROARCH.md) = 0.786 GB, WRITE_SIZE 0.546 GB per launch
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"winograd_gemm_bf16x3": 1.332e9}
+
+
 def kernel_peak(name):
     return BF16_MFMA_PEAK_TFLOPS / 6.0 if "bf16x3" in name else FP32_MFMA_PEAK_TFLOPS
 N_PER_GPU = 8
@@ -134,6 +139,7 @@ def main():
 
     # ---- one extra instrumented step: per-launch HIP events around every MFMA conv kernel
     ops.PROFILE = {}
+    ops.PROFILE_BYTES.clear()
     step()
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
@@ -180,10 +186,18 @@ def main():
                        "global_batch": n * world, "parallelism": "dp%d" % world,
                        "losses": {k: float(v.detach()) for k, v in tm.get_latest_losses().items()}},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
+                         # HBM bytes per launch of this kernel from PMC passes over this same command (not live:
+                         # counters need rocprofv3), profiles/r01_pmc_gemm_bf16x3.md
+                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(dom),
                          "peak_note": ("fp32 work on the bf16 matrix cores: 2516.6 dense bf16 TFLOP/s / 6 products per "
                                        "fp32 multiply-add" if "bf16x3" in dom else "v_mfma_f32 dense peak"),
                          "launches_per_step": kd["launches"], "avg_launch_ms": kd["ms"] / kd["launches"],
+                         "algorithmic_gb_per_launch": (ops.PROFILE_BYTES.get(dom, 0.0) / kd["launches"] / 1e9) or None,
+                         "traffic_note": ("PMC passes over this command (profiles/r01_pmc_gemm_bf16x3.md): FETCH_SIZE x2 "
+                                          "(gfx950 correction) + WRITE_SIZE, averaged over the step's launches of this "
+                                          "kernel; 7.04 GB vs 6.06 GB algorithmic at the dominant shape"
+                                          if "bf16x3" in dom else None),
                          "algorithmic_tflop_per_step": kd["tflop"],
                          "mfma_kernels_ms_per_step": mfma_ms,
                          "all_mfma_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),

@@ -21,8 +21,9 @@ NHIDDEN = 128
 _scratch = {}
 
 # bench.py sets this to a dict to time every MFMA conv launch with HIP events on the launch stream:
-# PROFILE[kernel_name] = [(start_event, end_event, algorithmic_flops), ...]
+# PROFILE[kernel_name] = [(start_event, end_event, algorithmic_flops), ...]; PROFILE_BYTES[kernel_name] = algorithmic HBM bytes
 PROFILE = None
+PROFILE_BYTES = {}
 
 
 def _variant(geom, modulate=False):
@@ -42,8 +43,8 @@ def _flops(geom):
 
 
 class _timed:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -54,6 +55,7 @@ class _timed:
         if PROFILE is not None:
             self.e.record()
             PROFILE.setdefault(self.name, []).append((self.s, self.e, self.flops))
+            PROFILE_BYTES[self.name] = PROFILE_BYTES.get(self.name, 0.0) + self.nbytes
 
 
 def scratch(nbytes, tag="ws"):
@@ -292,7 +294,9 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split):
     if split:
         v = _i16(36 * t * k_s * 3)
         L.call("wino43_input_split", xc, v, nb, h, wd, k_s)
-        with _timed("winograd_gemm_bf16x3", 2.0 * 36 * t * k_s * r_s):
+        # algorithmic HBM bytes: A3 (6 B/element) + B3 + C (fp32)
+        with _timed("winograd_gemm_bf16x3", 2.0 * 36 * t * k_s * r_s,
+                    6.0 * 36 * t * k_s + 6.0 * groups * rows * k_s + 4.0 * 36 * t * r_s):
             L.call("gemm_bf16x3", v, u, m, C.c_long(36 * t), r_s, k_s, C.c_long(t_g), rows, 0)
     else:
         v = new(36, t, k_s)
