@@ -47,6 +47,17 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
   return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
 }
 
+// exact 3-term bf16 split of an fp32 value (same arithmetic as the producers in winograd.hip)
+__device__ __forceinline__ void split3_dev(float x, unsigned short (&h)[3]) {
+  const __bf16 b0 = (__bf16)x;
+  const float r1 = x - (float)b0;
+  const __bf16 b1 = (__bf16)r1;
+  const __bf16 b2 = (__bf16)(r1 - (float)b1);
+  h[0] = __builtin_bit_cast(unsigned short, b0);
+  h[1] = __builtin_bit_cast(unsigned short, b1);
+  h[2] = __builtin_bit_cast(unsigned short, b2);
+}
+
 constexpr int ROWB = 112;  // LDS bytes per row per stage: 3 terms x 16 k x 2 B + 16 B pad
 
 // FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `acc`, which is then folded into `tot`
@@ -414,6 +425,204 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
 #endif
 }
 
+// ---------------------------------------------------------------- fp32 A operand, split inside the kernel
+// Same GEMM with the A operand (the Winograd-domain activations, the large one) left in fp32 [M][K] in HBM: 4 instead
+// of 6 bytes per element on the producer's write and on this kernel's read.  Per 16-k slab the A rows arrive by
+// LDS-DMA as fp32 (64 B per row) into a 2-stage staging area; every wave converts the 32 rows it loaded itself (so only
+// its own vmcnt matters) into the bf16x3 LDS image one slab ahead of the MFMAs: lane = (row, k-half), 8 values ->
+// 3 x 8 bf16 -> the same 6r + c + (r>>4) slot layout the fragments are read from.  B (weights) stays pre-split.
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_kernel(Gemm3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
+  static_assert(BM / 16 == 2 * NW, "two fp32 A instructions (16 rows each) per wave");
+  constexpr int SA = region_slots(BM), SB = region_slots(BN);
+  constexpr int NB = (SB + 63) / 64;
+  constexpr int NIB = (NB + NW - 1) / NW;                // B instructions per wave per slab (last maybe absent)
+  constexpr int F32_STAGE = BM * 64;                     // bytes of one fp32 A stage
+  constexpr int IMG = (SA * 16 + 255) / 256 * 256;       // bytes of one bf16x3 A image
+  constexpr int BST = NB * 1024;                         // bytes of one B stage
+  constexpr int OFF_IMG = 2 * F32_STAGE, OFF_B = OFF_IMG + 2 * IMG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nbn = (a.N + BN - 1) / BN;
+  const long tiles_z = (a.M / BM) * nbn, ntile = tiles_z * a.nz;
+  const long G = gridDim.x;
+  auto decode = [&](long v, long& z, long& bm, int& bn) {
+    const long q = ntile >> 3, r = ntile & 7, xcd = v & 7, idx = v >> 3;
+    const long l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    z = l / tiles_z;
+    const long t = l - z * tiles_z;
+    bn = (int)(t % nbn);
+    bm = t / nbn;
+  };
+  const long arow = (long)a.K * 4;  // bytes per A row
+  // A instruction jj (0,1) of this wave: rows 16*(wave + NW*jj) .. +15, lane -> (row l>>2, 16-byte chunk l&3)
+  unsigned voffa[2], voffb[NIB];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) voffa[jj] = (unsigned)((16 * (wave + NW * jj) + (lane >> 2)) * arow + (lane & 3) * 16);
+#pragma unroll
+  for (int j = 0; j < NIB; ++j) {
+    const int s = 64 * (wave + NW * j) + lane;
+    voffb[j] = (wave + NW * j < NB && s < SB && s % 97 != 96) ? (unsigned)((s - s / 97) * 16) : 0xFFFFFFF0u;
+  }
+  const bool has_last = wave + NW * (NIB - 1) < NB;  // wave-uniform
+  const int nk = a.K / 16;
+  const long sb_ = a.b_slab_bytes;
+
+  long lt = blockIdx.x;
+  int lk = 0, bvalid = 0, avalid = 0;
+  const unsigned char *pa = a.A, *pb = a.B;
+  auto load_base = [&]() {
+    long z, bm;
+    int bn;
+    const bool live = lt < ntile;
+    decode(live ? lt : (long)blockIdx.x, z, bm, bn);
+    const long group = (bm * BM) / a.rows_per_group;
+    pa = uniform_ptr(a.A + bm * BM * arow);
+    pb = uniform_ptr(a.B + group * a.b_group_bytes + (long)bn * BN * 96);
+    bvalid = __builtin_amdgcn_readfirstlane(live ? min(BN, a.N - bn * BN) * 96 : 0);
+    avalid = __builtin_amdgcn_readfirstlane(live ? (int)min((long)BM * arow, 0x7FFFFFFFL) : 0);
+  };
+  auto issue = [&](int fstage, int bstage) {
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lk * 64), 0, avalid, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * sb_), 0, bvalid, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      auto* dst = (__attribute__((address_space(3))) void*)(smem + fstage * F32_STAGE + (wave + NW * jj) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NIB; ++j)
+      if (j + 1 < NIB || has_last) {
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + OFF_B + bstage * BST + (wave + NW * j) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, voffb[j], 0, 0, 0);
+      }
+    if (++lk == nk) {
+      lk = 0;
+      lt += G;
+      load_base();
+    }
+  };
+  // conversion of this wave's 32 rows of fp32 stage `fstage` into image `img`: lane = (instruction jj = lane>>5, row
+  // (lane&31)>>1 of its 16, k-half lane&1)
+  const int crow = 16 * (wave + NW * (lane >> 5)) + ((lane & 31) >> 1), ckh = lane & 1;
+  const unsigned csrc = (unsigned)(crow * 64 + ckh * 32), cdst = (unsigned)((6 * crow + (crow >> 4) + ckh) * 16);
+  auto convert = [&](int fstage, int img) {
+    const unsigned char* f = smem + fstage * F32_STAGE + csrc;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(f), v1 = *reinterpret_cast<const f32x4*>(f + 16);
+    unsigned short h[8][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      split3_dev(v0[e], h[e]);
+      split3_dev(v1[e], h[4 + e]);
+    }
+    unsigned char* d = smem + OFF_IMG + img * IMG + cdst;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const u32x4 w = {(unsigned)h[0][p] | ((unsigned)h[1][p] << 16), (unsigned)h[2][p] | ((unsigned)h[3][p] << 16),
+                       (unsigned)h[4][p] | ((unsigned)h[5][p] << 16), (unsigned)h[6][p] | ((unsigned)h[7][p] << 16)};
+      *reinterpret_cast<u32x4*>(d + p * 32) = w;
+    }
+  };
+  auto wait_own = [&]() {  // everything but this wave's newest slab has landed
+    if (has_last)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NIB) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + NIB) : "memory");
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int r0 = wm * MT * 32 + (lane & 31), rb0 = wn * NT * 32 + (lane & 31);
+  const unsigned fa = (unsigned)((6 * r0 + (r0 >> 4) + (lane >> 5)) * 16);
+  const unsigned fb = (unsigned)((6 * rb0 + (rb0 >> 4) + (lane >> 5)) * 16);
+  constexpr int TSTEP = 194 * 16;
+
+  load_base();
+  issue(0, 0);
+  issue(1, 1);
+  wait_own();
+  asm volatile("" ::: "memory");
+  convert(0, 0);
+  int par = 0, bcur = 0, bnxt = 2, ck = 0;  // slab parity (fp32 stage / image), B stage being computed / to fill
+  long ct = blockIdx.x;
+  for (;;) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned char* sa_ = smem + OFF_IMG + par * IMG;
+    const unsigned char* sb = smem + OFF_B + bcur * BST;
+    bf16x8 af[MT][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(sa_ + fa + i * TSTEP + p * 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * TSTEP + p * 32);
+      if (j == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue(par, bnxt);  // fp32 stage `par` was converted one iteration ago (by this wave); B stage bnxt is free
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][j], 0, 0, 0);
+      }
+    }
+    // next slab: its fp32 rows (this wave's own) and B chunks have been in flight for a whole iteration
+    __builtin_amdgcn_sched_barrier(0);
+    wait_own();
+    asm volatile("" ::: "memory");
+    convert(par ^ 1, par ^ 1);
+    par ^= 1;
+    bcur = bcur == 2 ? 0 : bcur + 1;
+    bnxt = bnxt == 2 ? 0 : bnxt + 1;
+    ++ck;
+    if (ck < nk) continue;
+    {
+      long z, bm;
+      int bn;
+      decode(ct, z, bm, bn);
+      float* cz = a.C + z * a.c_z_elems;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const long mb = bm * BM + wm * MT * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
+          if (n < a.N)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = acc[i][j][r];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+      }
+    }
+    ck = 0;
+    ct += G;
+    if (ct >= ntile) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 static int gemm3_num_cus() {
   static int n = 0;
   if (!n) {
@@ -454,6 +663,25 @@ int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
     }
   }
   gemm3g_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  constexpr int NB = (region_slots(BN) + 63) / 64;
+  constexpr int IMG = (region_slots(BM) * 16 + 255) / 256 * 256;
+  const size_t lds = (size_t)2 * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN);
+  const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);
+  gemm3a_kernel<WM, WN, MT, NT><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -504,6 +732,25 @@ int dsee_gemm_bf16x3_tn(const void* P3t, const void* Q3t, float* C, int groups, 
   if (rows_p % 256 == 0 && rows_q % 128 == 0 && (long)(rows_p / 256) * (rows_q / 128) * groups * splits >= 512)
     return launch_gemm3<4, 2, 2, 2, 16>(a, groups * splits, st);  // 256x128, 8 waves
   return launch_gemm3<2, 2, 2, 2, 16>(a, groups * splits, st);
+}
+
+/* The same product with A left in fp32: A [M][K] fp32 row-major (e.g. the output of dsee_wino43_input), split into
+ * bf16x3 inside the kernel; B3, C, grouping and tile selection as dsee_gemm_bf16x3. */
+int dsee_gemm_bf16x3_af32(const float* A, const void* B3, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                          int tile, hipStream_t st) {
+  DSEE_CHECK_ARG(A && B3 && C && M > 0 && N > 0 && K > 0 && K % 16 == 0 && N % 128 == 0 && M % 128 == 0);
+  DSEE_CHECK_ARG(rows_per_group % 128 == 0 && M % rows_per_group == 0 && b_rows >= N && (long)K * 4 * 256 < 0x7FFFFFFFL);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)A; a.B = (const unsigned char*)B3; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.ldc = N; a.rows_per_group = rows_per_group;
+  a.b_group_bytes = (long)b_rows * K * 6; a.b_slab_bytes = (long)b_rows * 96; a.nz = 1;
+  const bool big_ok = rows_per_group % 256 == 0 && N % 256 == 0;
+  if (tile == 0) tile = (big_ok && (M / 256) * (N / 256) >= 512) ? 2 : 1;
+  if (tile == 2) {
+    DSEE_CHECK_ARG(big_ok);
+    return launch_gemm3a<2, 4, 4, 2>(a, st);
+  }
+  return launch_gemm3a<2, 2, 2, 2>(a, st);
 }
 
 }  // extern "C"

@@ -241,6 +241,9 @@ WINOGRAD_MOD = True
 # fp32 GEMMs of the Winograd domain on the bf16 matrix cores via exact 3-term operand splitting (gemm_bf16x3.hip);
 # DSEE_F32_MFMA=1 keeps them on v_mfma_f32_32x32x2_f32
 GEMM_SPLIT = os.environ.get("DSEE_F32_MFMA", "0") != "1"
+# A operand of the forward / data-gradient GEMMs kept in fp32 in HBM (4 instead of 6 bytes per element written by the
+# input transform and read by the GEMM) and split inside the GEMM kernel; DSEE_A_PRESPLIT=1 uses pre-split A operands
+GEMM_AF32 = os.environ.get("DSEE_A_PRESPLIT", "0") != "1"
 
 
 def _wino_chunk(n, h, w, cmax, per_image=False):
@@ -291,7 +294,14 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split):
     t = nb * tpi
     groups, t_g = (36 * nb, tpi) if per_image else (36, t)
     m = new(36, t, r_s)
-    if split:
+    if split and GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF:
+        v = new(36, t, k_s)
+        L.call("wino43_input", xc, v, nb, h, wd, k_s)
+        # algorithmic HBM bytes: A (fp32) + B3 + C (fp32)
+        with _timed("winograd_gemm_bf16x3", 2.0 * 36 * t * k_s * r_s,
+                    4.0 * 36 * t * k_s + 6.0 * groups * rows * k_s + 4.0 * 36 * t * r_s):
+            L.call("gemm_bf16x3_af32", v, u, m, C.c_long(36 * t), r_s, k_s, C.c_long(t_g), rows, 0)
+    elif split:
         v = _i16(36 * t * k_s * 3)
         L.call("wino43_input_split", xc, v, nb, h, wd, k_s)
         # algorithmic HBM bytes: A3 (6 B/element) + B3 + C (fp32)

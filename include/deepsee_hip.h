@@ -92,6 +92,9 @@ int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int tr
  * [K/16][rows][3][16] bf16 (1.5x the fp32 bytes) instead of fp32 rows:
  *   C[m][n] = sum_k A[m][k] * B[m / rows_per_group][n][k],  A3 [K/16][M][3][16], B3 [groups][K/16][b_rows][3][16]. */
 int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C, hipStream_t stream);
+/* dsee_gemm_bf16x3_af32: A stays fp32 [M][K] (4 instead of 6 bytes per element) and is split inside the kernel */
+int dsee_gemm_bf16x3_af32(const float* A, const void* B3, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                          int tile, hipStream_t stream);
 int dsee_gemm_bf16x3(const void* A3, const void* B3, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                      int tile, hipStream_t stream);
 int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,

@@ -236,3 +236,23 @@ def test_bf16x3_adds_no_error_to_the_winograd_conv():
     assert errs["direct"] < 1e-6
     assert errs["winograd_f32"] < 2e-5
     assert errs["winograd_bf16x3"] <= 1.1 * errs["winograd_f32"] + 1e-7, errs
+
+
+@pytest.mark.parametrize("groups,tg,n,k,tile", [(3, 256, 256, 160, 1), (2, 512, 256, 512, 2), (36, 128, 128, 32, 1),
+                                                (1, 1024, 512, 1024, 0)])
+def test_gemm_bf16x3_af32(groups, tg, n, k, tile):
+    """Same contract with the A operand left in fp32 and split inside the kernel (dsee_gemm_bf16x3_af32): identical
+    arithmetic, so the result must equal the pre-split kernel's bit for bit."""
+    from deepsee_amd import lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(groups * 77 + k)
+    a = torch.randn(groups * tg, k, generator=g) * torch.rand(groups * tg, 1, generator=g).exp()
+    b = torch.randn(groups, n, k, generator=g)
+    a3 = _split_rows(a).cuda()
+    b3 = torch.stack([_split_rows(b[i]) for i in range(groups)]).cuda()
+    c0 = torch.full((groups * tg, n), float("nan"), device="cuda")
+    c1 = torch.full((groups * tg, n), float("nan"), device="cuda")
+    L.call("gemm_bf16x3", a3, b3, c0, C.c_long(groups * tg), n, k, C.c_long(tg), n, tile)
+    L.call("gemm_bf16x3_af32", a.cuda(), b3, c1, C.c_long(groups * tg), n, k, C.c_long(tg), n, tile)
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1)

@@ -17,6 +17,11 @@ for (g, tg, n, k) in shapes:
     a3 = torch.cat([a3, a3])[: m * k * 3]
     b3 = torch.randn(g * n * k * 3, device="cuda").bfloat16().view(torch.int16)
     c = torch.empty(m, n, device="cuda")
+    af = torch.randn(m, k, device="cuda")
+    for tile in (1, 2):
+        if tile == 2 and (n % 256 or tg % 256): continue
+        t = timeit(lambda: L.call("gemm_bf16x3_af32", af, b3, c, C.c_long(m), n, k, C.c_long(tg), n, tile))
+        print("   fp32-A variant tile=%s: %.3f ms  %.0f TF/s" % ("128x128" if tile == 1 else "256x256", t, 2.0 * m * n * k / t / 1e9))
     for tile in (1, 2):
         if tile == 2 and (n % 256 or tg % 256): continue
         t = timeit(lambda: L.call("gemm_bf16x3", a3, b3, c, C.c_long(m), n, k, C.c_long(tg), n, tile))
