@@ -36,8 +36,8 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense (same guide); a bf16x3 fp32 multiply-add
 
 
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --steps 2 --warmup 1` (372 launches of the kernel):
-# FETCH_SIZE 0.3932 GB reported -> x2 (gfx950 correction, MI355X_MICROARCH.md) = 0.786 GB, WRITE_SIZE 0.546 GB per launch
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {"winograd_gemm_bf16x3": 1.332e9}
+# FETCH_SIZE 0.2816 GB reported -> x2 (gfx950 correction, MI355X_MICROARCH.md) = 0.563 GB, WRITE_SIZE 0.546 GB per launch
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"winograd_gemm_bf16x3": 1.109e9}
 
 
 def kernel_peak(name):
