@@ -1,4 +1,10 @@
 // Experiment: semantics of ds_read_b64_tr_b16 on gfx950 (which lane receives which LDS element).
+// Build: hipcc --offload-arch=gfx950 -O2 tr16.hip -o tr16 ; run on the GPU box.
+// Observed (round 1): within each 16-lane group the 16 lanes' 8-byte pieces form a 4 x 16 matrix -- row e (0..3) is
+// supplied by lanes 4e..4e+3 (each lane's address points at 4 consecutive bf16 = columns 4q..4q+3 of that row; the rows
+// may be anywhere in LDS) -- and lane i receives column i: out[i][e] = piece[lane 4e + (i>>2)][i & 3].
+// => an MFMA operand whose reduction index is the SLOW axis of the LDS image ([k][m], m contiguous) can be fetched with
+//    two tr reads per 8 k's (a transposed A/B path for gemm_bf16x3.hip; not used yet).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef short v4i16 __attribute__((ext_vector_type(4)));
