@@ -1263,7 +1263,9 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
     // operands are the transposed bf16x3 layouts of dsee_wino43_dout_split_t / dsee_wino43_input_split_t
     DSEE_CHECK_ARG(Cout_s % 128 == 0 && Cin_s % 32 == 0);
     const int sper = wino_sper(T, Cin_s, Cout_s), Kpad = dsee_conv_kpad(1, 1, Cin_s);
-    int rc = dsee_gemm_bf16x3_tn(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st);
+    // split == 2: V / dM are the plain fp32 transforms, transposed + split inside the GEMM
+    int rc = split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st)
+                        : dsee_gemm_bf16x3_tn(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st);
     if (rc) return rc;
     const long total = (long)Cout * Cin;
     wino43_wgrad_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(workspace, dw_oihw, sper,
@@ -1305,7 +1307,8 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
   if (split) {
     DSEE_CHECK_ARG(rows % 128 == 0);
     const int sper = wino_sper(T / N, ld, rows, N), Kpad = dsee_conv_kpad(1, 1, ld);
-    int rc = dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
+    int rc = split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st)
+                        : dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
     if (rc) return rc;
     const long total = (long)rows * ld;
     wino43_wgrad_table_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(

@@ -623,6 +623,204 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 #endif
 }
 
+// ---------------------------------------------------------------- split-K TN form with fp32 operands
+// C[z][i][j] = sum_t P[t][i] * Q[t][j] over the tiles t of batch / split z, with P (A dY A^T, [T][rows_p] fp32) and Q
+// (B^T d B, [T][rows_q] fp32: the plain outputs of dsee_wino43_dout / dsee_wino43_input -- Q can be the V the forward
+// pass already computed) left in fp32 in HBM.  A slab is 16 tiles; every wave DMAs, for all 16 of them, the 32 P
+// columns / RB Q columns it owns (whole 128-byte / RB*4-byte pieces) and transposes + splits them itself into the
+// bf16x3 images (rows = channels, 16 t contiguous), again one slab ahead of the MFMAs and with no barrier of its own.
+template <int WM, int WN, int MT, int NT, int FL>
+__global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
+  static_assert(BM == 32 * NW, "every wave owns 32 rows of the P tile");
+  constexpr int RB = BN / NW;                       // Q rows (channels) owned by a wave
+  static_assert(BN % NW == 0 && RB % 4 == 0 && 2 * RB <= 64, "Q rows per wave");
+  constexpr int QCH = RB / 4;                       // 16-byte chunks per tile row of a wave's Q piece
+  constexpr int QI = (16 * QCH + 63) / 64;          // Q DMA instructions per wave per slab
+  constexpr int SA = region_slots(BM), SB = region_slots(BN);
+  constexpr int IMGA = (SA * 16 + 255) / 256 * 256, IMGB = (SB * 16 + 255) / 256 * 256;
+  constexpr int FA = NW * 2048, FB = NW * QI * 1024;  // bytes of one fp32 stage (P, Q)
+  constexpr int OFF_FB = 2 * FA, OFF_IA = OFF_FB + 2 * FB, OFF_IB = OFF_IA + 2 * IMGA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nbn = a.N / BN;
+  const long tiles_z = (a.M / BM) * nbn, ntile = tiles_z * a.nz;
+  const long G = gridDim.x;
+  auto decode = [&](long v, long& z, long& bm, int& bn) {
+    const long q = ntile >> 3, r = ntile & 7, xcd = v & 7, idx = v >> 3;
+    const long l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    z = l / tiles_z;
+    const long t = l - z * tiles_z;
+    bn = (int)(t % nbn);
+    bm = t / nbn;
+  };
+  const long lda = (long)a.M * 4, ldb = (long)a.N * 4;  // bytes per tile row of P / Q
+  // P instruction jj: tiles 8jj .. 8jj+7 of the slab, lane -> (tile l>>3, 16-byte chunk l&7 of the wave's 128 bytes)
+  unsigned voffa[2], voffb[QI];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) voffa[jj] = (unsigned)((8 * jj + (lane >> 3)) * lda + wave * 128 + (lane & 7) * 16);
+#pragma unroll
+  for (int j = 0; j < QI; ++j) {
+    const int s = 64 * j + lane;  // (tile s / QCH, chunk s % QCH)
+    voffb[j] = s < 16 * QCH ? (unsigned)((s / QCH) * ldb + wave * RB * 4 + (s % QCH) * 16) : 0xFFFFFFF0u;
+  }
+  const int nk = a.K / 16;
+
+  long lt = blockIdx.x;
+  int lk = 0, live_bytes_a = 0, live_bytes_b = 0;
+  const unsigned char *pa = a.A, *pb = a.B;
+  auto load_base = [&]() {
+    long z, bm;
+    int bn;
+    const bool live = lt < ntile;
+    decode(live ? lt : (long)blockIdx.x, z, bm, bn);
+    pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 4);
+    pb = uniform_ptr(a.B + z * a.b_z_bytes + (long)bn * BN * 4);
+    live_bytes_a = __builtin_amdgcn_readfirstlane(live ? (int)min(16 * lda, 0x7FFFFFFFL) : 0);
+    live_bytes_b = __builtin_amdgcn_readfirstlane(live ? (int)min(16 * ldb, 0x7FFFFFFFL) : 0);
+  };
+  auto issue = [&](int fs) {
+    __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lk * a.a_slab_bytes), 0, live_bytes_a, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * a.b_slab_bytes), 0, live_bytes_b, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      auto* dst = (__attribute__((address_space(3))) void*)(smem + fs * FA + wave * 2048 + jj * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+      auto* dst = (__attribute__((address_space(3))) void*)(smem + OFF_FB + fs * FB + (wave * QI + j) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, voffb[j], 0, 0, 0);
+    }
+    if (++lk == nk) {
+      lk = 0;
+      lt += G;
+      load_base();
+    }
+  };
+  // transpose + split of this wave's pieces: item = (channel, tile half); 8 tiles of one channel -> 3 x 8 bf16
+  auto conv_item = [&](const unsigned char* f, int stride, int ch, int th, unsigned char* img, int row) {
+    unsigned short h[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3_dev(*reinterpret_cast<const float*>(f + (8 * th + j) * stride + ch * 4), h[j]);
+    unsigned char* d = img + (6 * row + (row >> 4) + th) * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const u32x4 w = {(unsigned)h[0][p] | ((unsigned)h[1][p] << 16), (unsigned)h[2][p] | ((unsigned)h[3][p] << 16),
+                       (unsigned)h[4][p] | ((unsigned)h[5][p] << 16), (unsigned)h[6][p] | ((unsigned)h[7][p] << 16)};
+      *reinterpret_cast<u32x4*>(d + p * 32) = w;
+    }
+  };
+  auto convert = [&](int fs, int im) {
+    conv_item(smem + fs * FA + wave * 2048, 128, lane >> 1, lane & 1, smem + OFF_IA + im * IMGA, 32 * wave + (lane >> 1));
+    if (lane < 2 * RB)
+      conv_item(smem + OFF_FB + fs * FB + wave * QI * 1024, RB * 4, lane >> 1, lane & 1, smem + OFF_IB + im * IMGB,
+                RB * wave + (lane >> 1));
+  };
+
+  f32x16 acc[MT][NT], tot[FL > 0 ? MT : 1][FL > 0 ? NT : 1];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (FL > 0) tot[i][j][r] = 0.f;
+      }
+  const int r0 = wm * MT * 32 + (lane & 31), rb0 = wn * NT * 32 + (lane & 31);
+  const unsigned fa = (unsigned)((6 * r0 + (r0 >> 4) + (lane >> 5)) * 16);
+  const unsigned fb = (unsigned)((6 * rb0 + (rb0 >> 4) + (lane >> 5)) * 16);
+  constexpr int TSTEP = 194 * 16;
+
+  load_base();
+  issue(0);
+  issue(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI) : "memory");
+  convert(0, 0);
+  int par = 0, ck = 0;
+  long ct = blockIdx.x;
+  for (;;) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned char* sa_ = smem + OFF_IA + par * IMGA;
+    const unsigned char* sb = smem + OFF_IB + par * IMGB;
+    bf16x8 af[MT][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(sa_ + fa + i * TSTEP + p * 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * TSTEP + p * 32);
+      if (j == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue(par);  // fp32 stage `par` was converted one iteration ago by this wave
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI) : "memory");
+    convert(par ^ 1, par ^ 1);
+    par ^= 1;
+    ++ck;
+    if constexpr (FL > 0) {
+      if ((ck & (FL - 1)) == 0 || ck == nk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            tot[i][j] += acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+      }
+    }
+    if (ck < nk) continue;
+    {
+      long z, bm;
+      int bn;
+      decode(ct, z, bm, bn);
+      float* cz = a.C + z * a.c_z_elems;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const long mb = bm * BM + wm * MT * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
+          f32x16& d = FL > 0 ? tot[FL > 0 ? i : 0][FL > 0 ? j : 0] : acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = d[r];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        }
+      }
+    }
+    ck = 0;
+    ct += G;
+    if (ct >= ntile) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 static int gemm3_num_cus() {
   static int n = 0;
   if (!n) {
@@ -682,6 +880,26 @@ int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN);
   const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);
   gemm3a_kernel<WM, WN, MT, NT><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+template <int WM, int WN, int MT, int NT, int FL>
+int launch_gemm3t(Gemm3Args a, int nz, hipStream_t st) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
+  constexpr int QI = (16 * (BN / NW / 4) + 63) / 64;
+  constexpr int IMGA = (region_slots(BM) * 16 + 255) / 256 * 256, IMGB = (region_slots(BN) * 16 + 255) / 256 * 256;
+  const size_t lds = (size_t)2 * NW * 2048 + (size_t)2 * NW * QI * 1024 + 2 * IMGA + 2 * IMGB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  a.nz = nz;
+  const long ntile = (a.M / BM) * (a.N / BN) * nz;
+  const long slots = gemm3_num_cus();
+  gemm3t_kernel<WM, WN, MT, NT, FL><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -751,6 +969,24 @@ int dsee_gemm_bf16x3_af32(const float* A, const void* B3, float* C, long M, int 
     return launch_gemm3a<2, 4, 4, 2>(a, st);
   }
   return launch_gemm3a<2, 2, 2, 2>(a, st);
+}
+
+/* dsee_gemm_bf16x3_tn with both operands left in fp32: P [groups*T][rows_p], Q [groups*T][rows_q] fp32 row-major (the
+ * plain outputs of dsee_wino43_dout / dsee_wino43_input), transposed and split inside the kernel.
+ * rows_p % 256 == 0 and rows_q == 160 or rows_q % 128 == 0; returns DSEE_EINVAL otherwise (use the pre-split form). */
+int dsee_gemm_bf16x3_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                            int splits, hipStream_t st) {
+  DSEE_CHECK_ARG(P && Q && C && groups > 0 && T % 16 == 0 && rows_p % 256 == 0 && splits > 0);
+  DSEE_CHECK_ARG((T / 16) % splits == 0 && ldc >= rows_q && (rows_q == 160 || rows_q % 128 == 0));
+  DSEE_CHECK_ARG((long)rows_p * 64 < 0x7FFFFFFFL && (long)rows_q * 64 < 0x7FFFFFFFL);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)P; a.B = (const unsigned char*)Q; a.C = C;
+  const long nk = T / 16 / splits;
+  a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p;
+  a.a_slab_bytes = (long)16 * rows_p * 4; a.b_slab_bytes = (long)16 * rows_q * 4;
+  a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
+  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16>(a, groups * splits, st);
+  return launch_gemm3t<4, 2, 2, 2, 16>(a, groups * splits, st);
 }
 
 }  // extern "C"

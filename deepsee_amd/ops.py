@@ -244,6 +244,8 @@ GEMM_SPLIT = os.environ.get("DSEE_F32_MFMA", "0") != "1"
 # A operand of the forward / data-gradient GEMMs kept in fp32 in HBM (4 instead of 6 bytes per element written by the
 # input transform and read by the GEMM) and split inside the GEMM kernel; DSEE_A_PRESPLIT=1 uses pre-split A operands
 GEMM_AF32 = os.environ.get("DSEE_A_PRESPLIT", "0") != "1"
+# keep the forward's fp32 V for the weight gradient (DSEE_KEEP_V=0: transform x again in the backward pass)
+KEEP_V = os.environ.get("DSEE_KEEP_V", "1") != "0"
 
 
 def _wino_chunk(n, h, w, cmax, per_image=False):
@@ -288,8 +290,9 @@ def _wino_u(w, co, ci, transpose_flip, rows, kp, split):
     return u
 
 
-def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split):
-    """M [36][t][r_s] = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs."""
+def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=None):
+    """M [36][t][r_s] = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs.
+    `keep` (a list) receives the fp32 V when it exists in that form (it is the weight gradient's Q operand)."""
     tpi = (h // 4) * (wd // 4)
     t = nb * tpi
     groups, t_g = (36 * nb, tpi) if per_image else (36, t)
@@ -301,6 +304,8 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split):
         with _timed("winograd_gemm_bf16x3", 2.0 * 36 * t * k_s * r_s,
                     4.0 * 36 * t * k_s + 6.0 * groups * rows * k_s + 4.0 * 36 * t * r_s):
             L.call("gemm_bf16x3_af32", v, u, m, C.c_long(36 * t), r_s, k_s, C.c_long(t_g), rows, 0)
+        if keep is not None:
+            keep.append(v)
     elif split:
         v = _i16(36 * t * k_s * 3)
         L.call("wino43_input_split", xc, v, nb, h, wd, k_s)
@@ -317,8 +322,9 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split):
     return m
 
 
-def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0):
-    """y = conv3x3(x, w) (transpose_flip: data gradient of that conv) through 36 Winograd-domain GEMMs."""
+def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0, keep=None):
+    """y = conv3x3(x, w) (transpose_flip: data gradient of that conv) through 36 Winograd-domain GEMMs.
+    `keep`: list that receives the fp32 V of the input when the whole batch went through in one pass."""
     co, ci = w.shape[0], w.shape[1]
     r_s, k_s = (cin_s, cout_s) if transpose_flip else (cout_s, cin_s)   # GEMM output / reduction channels
     rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
@@ -327,40 +333,55 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     y = new(n, h, wd, r_s)
     nb = _wino_chunk(n, h, wd, max(r_s, k_s))
     for n0 in range(0, n, nb):
-        m = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split)
+        m = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None)
         L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
                r_s, act, LRELU_SLOPE)
     return y
 
 
-def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, split):
-    """(V, dM) of one image chunk for the Winograd-domain weight gradient (fp32 rows, or transposed bf16x3)."""
+def _wgrad_mode(cin_s, cout_s):
+    """0: fp32-MFMA reduction; 1: bf16x3 with pre-split transposed operands; 2: bf16x3 with fp32 operands transposed and
+    split inside the GEMM (256-row tiles: cout_s % 256 == 0, cin_s == 160 or % 128 == 0)."""
+    if not (GEMM_SPLIT and cout_s % 128 == 0 and cin_s % 32 == 0):
+        return 0
+    if GEMM_AF32 and cout_s % 256 == 0 and (cin_s == 160 or cin_s % 128 == 0) and max(cin_s, cout_s) * 64 < 0x7FFFFFFF:
+        return 2
+    return 1
+
+
+def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None):
+    """(V, dM) of one image chunk for the Winograd-domain weight gradient: fp32 rows (modes 0, 2; `v` may be the V the
+    forward pass kept) or transposed bf16x3 (mode 1)."""
     t = nb * (h // 4) * (wd // 4)
-    if split:
+    if mode == 1:
         v, dm = _i16(36 * t * cin_s * 3), _i16(36 * t * cout_s * 3)
         L.call("wino43_input_split_t", xc, v, nb, h, wd, cin_s)
         L.call("wino43_dout_split_t", gc, dm, nb, h, wd, cout_s)
     else:
-        v, dm = new(36, t, cin_s), new(36, t, cout_s)
-        L.call("wino43_input", xc, v, nb, h, wd, cin_s)
+        dm = new(36, t, cout_s)
+        if v is None:
+            v = new(36, t, cin_s)
+            L.call("wino43_input", xc, v, nb, h, wd, cin_s)
         L.call("wino43_dout", gc, dm, nb, h, wd, cout_s)
     return v, dm
 
 
-def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci):
-    """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain."""
+def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None):
+    """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain.  `v_fwd`: the fp32 V of x
+    kept by the forward pass (used when the weight gradient takes fp32 operands and runs in one pass)."""
     nb = _wino_chunk(n, h, wd, max(cin_s, cout_s))
     t = nb * (h // 4) * (wd // 4)
-    split = GEMM_SPLIT and cout_s % 128 == 0 and cin_s % 32 == 0
+    mode = _wgrad_mode(cin_s, cout_s)
     nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(t), cin_s, cout_s)
     ws = scratch(nbytes, "wgrad")
     total = None
     for n0 in range(0, n, nb):
-        v, dm = _wino_wgrad_operands(x[n0:n0 + nb], g[n0:n0 + nb], nb, h, wd, cin_s, cout_s, split)
+        v, dm = _wino_wgrad_operands(x[n0:n0 + nb], g[n0:n0 + nb], nb, h, wd, cin_s, cout_s, mode,
+                                     v_fwd if (mode == 2 and nb == n) else None)
         dw = new(co, ci, 3, 3)
-        with _timed("winograd_wgrad_bf16x3" if split else "winograd_wgrad_128x128(36 groups)",
+        with _timed("winograd_wgrad_bf16x3" if mode else "winograd_wgrad_128x128(36 groups)",
                     2.0 * 36 * t * cin_s * cout_s):
-            L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci, int(split))
+            L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci, mode)
         total = dw if total is None else total.add_(dw)
     return total
 
@@ -376,6 +397,7 @@ class Conv2d(torch.autograd.Function):
         cout_s = L.pad4(co)
         geom = L.geom_fwd(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
         w = w.contiguous()
+        vkeep = None
         ctx.wino = _wino_ok(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
         ctx.thin = (kh == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and cin_s % 256 == 0 and cin_s <= 1024
                     and wi % 64 == 0 and res is None)
@@ -383,16 +405,20 @@ class Conv2d(torch.autograd.Function):
             out = new(n, hi, wi, cout_s)
             L.call("conv3x3_thin_fwd", x, w, bias, out, n, hi, wi, cin_s, co, act, LRELU_SLOPE)
         elif ctx.wino:
-            out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act)
+            # the fp32 V of x is the weight gradient's Q operand: keep it instead of transforming x again (2.25x the
+            # bytes of x; KEEP_V = False trades the memory back for one more transform pass)
+            keep = [] if (KEEP_V and ctx.needs_input_grad[1] and _wgrad_mode(cin_s, cout_s) == 2) else None
+            out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act, keep=keep)
+            vkeep = keep[0] if keep else None
         else:
             out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act)
         ctx.geom, ctx.act, ctx.has_bias, ctx.has_res = geom, act, bias is not None, res is not None
-        ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None)
+        ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None, vkeep)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, out = ctx.saved_tensors
+        x, w, out, vkeep = ctx.saved_tensors
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
@@ -404,7 +430,7 @@ class Conv2d(torch.autograd.Function):
         dx = dw = db = dres = None
         if STREAMS and ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             with _OnSide() as sd:
-                dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci)
+                dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep)
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
             sd.join(dw)
         elif ctx.needs_input_grad[0] and ctx.wino:
@@ -424,7 +450,7 @@ class Conv2d(torch.autograd.Function):
             dw = new(co, ci, 3, 3)
             L.call("conv3x3_thin_wgrad", x, g, ws, dw, geom.N, geom.Hi, geom.Wi, geom.Cin, co, ci)
         elif ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
-            dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci)
+            dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep)
         elif ctx.needs_input_grad[1]:
             dw = wgrad_raw(x, g, geom, co, ci, kh, kw)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -793,18 +819,18 @@ class SeanNormTable(torch.autograd.Function):
             else:
                 nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(nb * tpi), ld, rows)
             wsw = scratch(nbytes, "wgrad")
-            split = GEMM_SPLIT and rows % 128 == 0 and ld % 32 == 0
+            mode = _wgrad_mode(ld, rows)
             for n0 in range(0, n, nb):
-                v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], dgb[n0:n0 + nb], nb, h, w, ld, rows, split)
+                v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], dgb[n0:n0 + nb], nb, h, w, ld, rows, mode)
                 dwc = new(rows, NHIDDEN, 3, 3) if ctx.has_a else None
-                with _timed("winograd_wgrad_bf16x3" if split else "winograd_wgrad_128x128(36 groups)",
+                with _timed("winograd_wgrad_bf16x3" if mode else "winograd_wgrad_128x128(36 groups)",
                             2.0 * 36 * nb * tpi * ld * rows):
                     if ctx.has_t:
                         L.call("wino43_wgrad_table", v, dm, wsw, C.c_size_t(nbytes), dwc, dtable[n0:n0 + nb],
-                               C.c_long(nb * tpi), nb, ca, rows, lab.nc, int(split))
+                               C.c_long(nb * tpi), nb, ca, rows, lab.nc, mode)
                     else:
                         L.call("wino43_wgrad", v, dm, wsw, C.c_size_t(nbytes), dwc, C.c_long(nb * tpi), ld, rows, rows,
-                               NHIDDEN, int(split))
+                               NHIDDEN, mode)
                 if dwc is not None:
                     dw2a = dwc if dw2a is None else dw2a.add_(dwc)
             return dw2a, dtable

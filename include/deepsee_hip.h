@@ -120,10 +120,15 @@ int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hip
 size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
                       long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, hipStream_t stream);
-/* split = 1: V / dM are the transposed bf16x3 operands [36][T/16][C][3][16 tiles] written by the two producers below
+/* split = 2: V / dM are the plain fp32 transforms (dsee_wino43_input / dsee_wino43_dout), transposed and split inside
+ * dsee_gemm_bf16x3_tn_f32 (Cout_stored % 256 == 0, Cin_stored == 160 or % 128 == 0).
+ * split = 1: V / dM are the transposed bf16x3 operands [36][T/16][C][3][16 tiles] written by the two producers below
  * and the reduction over tiles runs on the bf16 matrix cores (dsee_gemm_bf16x3_tn, fp32-accurate). */
 int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, int C, hipStream_t stream);
 int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, int C, hipStream_t stream);
+/* fp32 operands [groups*T][rows] (plain transform outputs), transposed + split inside the kernel */
+int dsee_gemm_bf16x3_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                            int splits, hipStream_t stream);
 int dsee_gemm_bf16x3_tn(const void* P3t, const void* Q3t, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                         int splits, hipStream_t stream);
 
