@@ -775,13 +775,15 @@ class SeanNormTable(torch.autograd.Function):
             kp = L.kpad(1, 1, ld)
             b2c = b2.contiguous()
             split = _split_ok(ld, rows)
+            # the fp32 V of `cat` is the Q operand of the weight / table gradient: kept for the backward pass
+            keep = [] if (KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2) else None
             for n0 in range(0, n, nb):
                 if has_t:
                     u = _i16(36 * nb * rows * kp * 3) if split else new(36, nb, rows, kp)
                     L.call("wino43_weights_table", w2a if has_a else None, tb[n0:n0 + nb], u, nb, rows, ca, int(split))
                 else:
                     u = _wino_u(w2a, rows, ca, False, rows, kp, split)
-                m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split)
+                m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split, keep)
                 L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
                        scale[n0:n0 + nb] if need_scale else None, nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
         else:
@@ -790,12 +792,13 @@ class SeanNormTable(torch.autograd.Function):
                 L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, tb, ca, b2.contiguous(), x, mean, invstd, out,
                        scale, c, float(add_one), LRELU_SLOPE)
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
-        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd)
+        vcat = keep[0] if (nb and keep) else None
+        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, vcat)
         return out
 
     @staticmethod
     def backward(ctx, dh):
-        x, cat, w2a, out, scale, mean, invstd = ctx.saved_tensors
+        x, cat, w2a, out, scale, mean, invstd, vcat = ctx.saved_tensors
         geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
         n, h, w, c = x.shape
         ld = cat.shape[3]
@@ -821,7 +824,8 @@ class SeanNormTable(torch.autograd.Function):
             wsw = scratch(nbytes, "wgrad")
             mode = _wgrad_mode(ld, rows)
             for n0 in range(0, n, nb):
-                v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], dgb[n0:n0 + nb], nb, h, w, ld, rows, mode)
+                v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], dgb[n0:n0 + nb], nb, h, w, ld, rows, mode,
+                                             vcat if (mode == 2 and nb == n) else None)
                 dwc = new(rows, NHIDDEN, 3, 3) if ctx.has_a else None
                 with _timed("winograd_wgrad_bf16x3" if mode else "winograd_wgrad_128x128(36 groups)",
                             2.0 * 36 * nb * tpi * ld * rows):
