@@ -22,7 +22,8 @@ Extra objects on the line:
 import argparse
 import json
 import os
-import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -88,6 +89,21 @@ def cpu_baseline():
                       "restatement pinned to the reference), %.1f s" % dt}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with one
+    rank per GPU (the in-process counterpart of the reference's DataParallel wrap, base_manager.py:15-23) and pass the
+    single JSON line of rank 0 through."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +113,8 @@ def main():
     ap.add_argument("--no-f32-run", action="store_true", help="skip the extra v_mfma_f32-only measurement")
     ap.add_argument("--batch-per-gpu", type=int, default=N_PER_GPU)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
 
     from deepsee_amd import ops, parallel
     from deepsee_amd.managers import TrainerManager
@@ -104,14 +122,13 @@ def main():
     import torch.distributed as dist
 
     rank, local, world = parallel.init_distributed()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:   # never report a number for a world size other than the one asked for
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local)
     n = args.batch_per_gpu
     opt = make_opt("independent_8x_256", batchSize=n, seed=0)
-    random.seed(1234)                       # identical encoder-branch coins on every rank
-    tm = TrainerManager(opt)
-    tm.sr_model.noise.seed += 1000 * rank   # different noise per shard
-    parallel.attach(tm, world)
+    tm = TrainerManager(opt)                # encoder-branch coins: DeviceNoise's own RNG, identical on every rank
+    parallel.attach(tm, world)              # gradient all-reduce hooks, rank-0 broadcast, per-rank noise seed
     batch = synthetic_batch(opt, n, 1234 + rank, dev)
 
     def step():

@@ -971,9 +971,7 @@ int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
 }
 
 static bool halo_ok(const ConvArgs& a) {
-  static int disable = -1;
-  if (disable < 0) disable = getenv("DSEE_NO_HALO") ? 1 : 0;
-  return !disable && a.korder == 1 && a.KH == 3 && a.KW == 3 && a.mul == 1 && a.Hi == a.Ho && a.Wi == a.Wo &&
+  return a.korder == 1 && a.KH == 3 && a.KW == 3 && a.mul == 1 && a.Hi == a.Ho && a.Wi == a.Wo &&
          a.Ho % 8 == 0 && a.Wo % 16 == 0 && a.off == -a.kdir && (a.kdir == 1 || a.kdir == -1) &&
          (long)a.N * a.Hi * a.Wi * a.Cin * 4 + 65536 < 0xFFFFFFFEL;
 }

@@ -284,6 +284,42 @@ __global__ void extract_image_grad_kernel(const float* __restrict__ din, float* 
   }
 }
 
+// Device input pipeline (data/base_dataset.py:87-116,171-201 without the host-side float tensors): the loader ships
+// uint8 images [N][H][W][3] and uint8 label maps [N][H][W]; ToTensor (v/255), Normalize((.5,.5,.5),(.5,.5,.5)), the
+// per-sample horizontal flip and the 255 -> label_nc 'unknown' remap happen here, straight into the NHWC RGB0 fp32 /
+// uint8 label layout the kernels consume.
+__global__ void image_u8_to_nhwc_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ flip,
+                                        float* __restrict__ out, int N, int H, int W, int cs) {
+  const long total = (long)N * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long r = i / W;
+    const int n = (int)(r / H);
+    const int ws = (flip && flip[n]) ? W - 1 - w : w;
+    const uint8_t* p = img + (r * W + ws) * 3;
+    float* o = out + i * cs;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = (float)p[c] / 255.f;   // transforms.ToTensor
+      o[c] = (x - 0.5f) / 0.5f;              // transforms.Normalize
+    }
+    for (int c = 3; c < cs; ++c) o[c] = 0.f;
+  }
+}
+
+__global__ void label_u8_prepare_kernel(const uint8_t* __restrict__ lab, const uint8_t* __restrict__ flip,
+                                        uint8_t* __restrict__ out, int N, int H, int W, int unknown_to) {
+  const long total = (long)N * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long r = i / W;
+    const int n = (int)(r / H);
+    const int ws = (flip && flip[n]) ? W - 1 - w : w;
+    const uint8_t v = lab[r * W + ws];
+    out[i] = v == 255 ? (uint8_t)unknown_to : v;   // base_dataset.py:95: 'unknown' is opt.label_nc
+  }
+}
+
 __device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
   const float A = -0.75f;  // PyTorch bicubic
   float x = t + 1.f;
@@ -557,6 +593,22 @@ int dsee_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int 
 int dsee_label_to_u8(const float* label, uint8_t* out, long n, hipStream_t st) {
   DSEE_CHECK_ARG(label && out);
   label_to_u8_kernel<<<egrid(n), 256, 0, st>>>(label, out, n);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_image_u8_to_nhwc(const uint8_t* img, const uint8_t* flip, float* out, int N, int H, int W, int cs_out,
+                          hipStream_t st) {
+  DSEE_CHECK_ARG(img && out && cs_out >= 3 && cs_out % 4 == 0);
+  image_u8_to_nhwc_kernel<<<egrid((long)N * H * W), 256, 0, st>>>(img, flip, out, N, H, W, cs_out);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_label_u8_prepare(const uint8_t* lab, const uint8_t* flip, uint8_t* out, int N, int H, int W, int unknown_to,
+                          hipStream_t st) {
+  DSEE_CHECK_ARG(lab && out && unknown_to >= 0 && unknown_to < 256);
+  label_u8_prepare_kernel<<<egrid((long)N * H * W), 256, 0, st>>>(lab, flip, out, N, H, W, unknown_to);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -12,8 +12,7 @@
 //   C[m][n] = sum_k A[m][k] * B[group(m)][n][k],   C: [M][N] fp32, group(m) = m / rows_per_group,
 //   A3: [K/16][M][3][16] bf16,  B3: [groups][K/16][rowsB][3][16] bf16   ("slab-major": the 16-k slab of a row tile is
 //   ONE contiguous block of rows x 96 B, so every cache line fetched is used whole, once).
-// Kernel: BK = 16 slabs, two LDS stages of [(BM+BN) rows][3 terms][16 k] (+16 B pad: 112 B rows, conflict-free
-// ds_read_b128 fragments), register-staged buffer loads (per-thread offsets fixed, buffer base advanced per slab),
+// Kernels: 16-k slabs, global -> LDS by buffer_load ... lds into a 3-stage ring, conflict-free ds_read_b128 fragments;
 // a lane ends with one output column and 16 rows: dword stores, whole 128-byte lines per half-wave.
 #include <stdlib.h>
 
@@ -36,7 +35,6 @@ struct Gemm3Args {
   long a_slab_bytes, b_slab_bytes;   // distance between consecutive 16-k slabs
   long a_z_bytes, b_z_bytes, c_z_elems;  // batch / split-K index offsets
   int nz;
-  int abl;  // debug ablations (DSEE_G3_ABL): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no C stores
 };
 
 // force a value the compiler cannot prove wave-uniform into SGPRs (buffer resources / M0 must be scalar; without this
@@ -58,186 +56,11 @@ __device__ __forceinline__ void split3_dev(float x, unsigned short (&h)[3]) {
   h[2] = __builtin_bit_cast(unsigned short, b2);
 }
 
-constexpr int ROWB = 112;  // LDS bytes per row per stage: 3 terms x 16 k x 2 B + 16 B pad
-
+// ---------------------------------------------------------------- pre-split operands, direct to LDS
 // FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `acc`, which is then folded into `tot`
 // (long reductions of the weight gradients: keeps the fp32 accumulation error at the blocked-sum level).
-//
 // Persistent: gridDim.x blocks walk the (z, M tile, N tile) list with stride gridDim.x, and the slab stream never
-// drains at a tile boundary -- the loads run two slabs ahead of the MFMAs straight into the next tile's first slabs,
-// and a finished tile's stores are issued behind the already-started loads, so neither the prologue latency nor the
-// epilogue is paid per tile (K = 160 .. 512 means only 10 .. 32 slabs per tile).
-template <int WM, int WN, int MT, int NT, int FL>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3_kernel(Gemm3Args a) {
-  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64;
-  constexpr int ACH = BM * 6 / NTHR, BCH = BN * 6 / NTHR;  // 16-byte chunks per thread per slab
-  static_assert(BM * 6 % NTHR == 0 && BN * 6 % NTHR == 0, "uniform A/B chunk split");
-  constexpr int STAGE = (BM + BN) * ROWB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int nbn = (a.N + BN - 1) / BN;
-  const long tiles_z = (a.M / BM) * nbn, ntile = tiles_z * a.nz;
-  const long G = gridDim.x;
-  // XCD-aware tile order (speed only): hardware puts workgroup b on XCD b % 8 (gridDim.x is a multiple of 8 or covers
-  // every tile); give each XCD a contiguous range of logical tiles, N tiles of one M tile adjacent, so blocks sharing
-  // A rows meet in one L2.
-  auto decode = [&](long v, long& z, long& bm, int& bn) {
-    const long q = ntile >> 3, r = ntile & 7, xcd = v & 7, idx = v >> 3;
-    const long l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    z = l / tiles_z;
-    const long t = l - z * tiles_z;
-    bn = (int)(t % nbn);
-    bm = t / nbn;
-  };
-
-  unsigned voff[ACH + BCH], loff[ACH + BCH];
-#pragma unroll
-  for (int j = 0; j < ACH + BCH; ++j) {
-    const int q = tid + NTHR * (j < ACH ? j : j - ACH);
-    const int row = q / 6, c = q % 6;
-    voff[j] = (unsigned)(q * 16);
-    loff[j] = (unsigned)(((j < ACH ? 0 : BM) + row) * ROWB + c * 16);
-  }
-  const int nk = a.K / 16;
-  const long sa = a.a_slab_bytes, sb_ = a.b_slab_bytes;
-
-  // ---- loader state: tile lt, slab lk (runs two slabs ahead of the compute state)
-  long lt = blockIdx.x;
-  int lk = 0, bvalid = 0;
-  const unsigned char *pa = a.A, *pb = a.B;
-  auto load_base = [&]() {
-    long z, bm;
-    int bn;
-    decode(lt < ntile ? lt : (long)blockIdx.x, z, bm, bn);  // past the end: harmless re-fetch of the first tile
-    const long group = (bm * BM) / a.rows_per_group;
-    // slab k of a tile: A rows [bm*BM, +BM) at A + z*a_z + k*a_slab + bm*BM*96; B likewise (+ group matrix)
-    pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 96);
-    pb = uniform_ptr(a.B + z * a.b_z_bytes + group * a.b_group_bytes + (long)bn * BN * 96);
-    bvalid = __builtin_amdgcn_readfirstlane(min(BN, a.N - bn * BN) * 96);  // rows of B past N read as zeros
-  };
-  u32x4 st[ACH + BCH];
-  auto gload = [&]() {
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lk * sa), 0, BM * 96, 0x00020000);
-    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * sb_), 0, bvalid, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < ACH; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff[j], 0, 0);
-#pragma unroll
-    for (int j = ACH; j < ACH + BCH; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff[j], 0, 0);
-    if (++lk == nk) {
-      lk = 0;
-      lt += G;
-      load_base();
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < ACH + BCH; ++j) *reinterpret_cast<u32x4*>(smem + buf * STAGE + loff[j]) = st[j];
-  };
-
-  f32x16 acc[MT][NT], tot[FL > 0 ? MT : 1][FL > 0 ? NT : 1];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[i][j][r] = 0.f;
-        if constexpr (FL > 0) tot[i][j][r] = 0.f;
-      }
-
-  // fragment addresses: lane (row = lane & 31, k-half = lane >> 5) reads the 8 k's of its half for each term
-  const unsigned fa = (unsigned)((wm * MT * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16);
-  const unsigned fb = (unsigned)((BM + wn * NT * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16);
-
-  load_base();
-  gload();
-  lstore(0);
-  __syncthreads();
-  gload();
-  int cur = 0, ck = 0;
-  long ct = blockIdx.x;
-  for (;;) {
-    const unsigned char* sb = smem + cur * STAGE;
-    bf16x8 af[MT][3];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + fa + i * 32 * ROWB + p * 32);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      bf16x8 bf[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * 32 * ROWB + p * 32);
-      if (a.abl & 4) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][j][0] += (float)bf[0][0] * (float)af[i][2][1] + (float)bf[1][2] * (float)af[i][1][3] + (float)bf[2][4] * (float)af[i][0][5];
-        continue;
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        // smallest terms first; B fragment is the MFMA "A" operand so that acc rows run along n
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][2], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[2], af[i][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[i][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[i][0], acc[i][j], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(a.abl & 2)) lstore(cur ^ 1);  // next slab of the stream (requested one slab ago)
-    __syncthreads();
-    if (!(a.abl & 1)) gload();          // two slabs ahead; crosses into the next tile of this block without draining
-    cur ^= 1;
-    ++ck;
-    if constexpr (FL > 0) {
-      if ((ck & (FL - 1)) == 0 || ck == nk) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            tot[i][j] += acc[i][j];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-          }
-      }
-    }
-    if (ck < nk) continue;
-
-    // ---- tile finished.  D[n][m] layout: lane holds, for each 8-row group g, n = 8g + 4*(lane>>5) + 0..3 of column
-    //      m = lane & 31 -> 16-byte stores; they drain behind the loads already in flight for the next tile.
-    {
-      long z, bm;
-      int bn;
-      decode(ct, z, bm, bn);
-      float* cz = a.C + z * a.c_z_elems;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const long m = bm * BM + wm * MT * 32 + i * 32 + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n0 = bn * BN + wn * NT * 32 + j * 32 + 4 * (lane >> 5);
-          f32x16& d = FL > 0 ? tot[FL > 0 ? i : 0][FL > 0 ? j : 0] : acc[i][j];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-            if (n0 + 8 * g < a.N && !(a.abl & 8)) *reinterpret_cast<f32x4*>(cz + m * a.ldc + n0 + 8 * g) = v;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) d[r] = 0.f;
-        }
-      }
-    }
-    ck = 0;
-    ct += G;
-    if (ct >= ntile) break;
-  }
-}
-
-// ---------------------------------------------------------------- direct-to-LDS variant (shipped)
-// Same tiling and MFMA schedule, but the slabs travel global -> LDS by buffer_load_dwordx4 ... lds (no staging VGPRs,
+// drains at a tile boundary.  The slabs travel global -> LDS by buffer_load_dwordx4 ... lds (no staging VGPRs,
 // no ds_write pass) into THREE LDS stages, two slabs in flight across each raw s_barrier with counted vmcnt waits.
 // An LDS-DMA instruction writes 64 consecutive 16-byte slots (wave-uniform base + lane*16), so the LDS image of a
 // stage is the slab-major global image itself with one dummy slot after every 16 rows (96 chunk slots): chunk c of
@@ -835,31 +658,18 @@ static int gemm3_num_cus() {
 template <int WM, int WN, int MT, int NT, int FL>
 int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  constexpr bool reg_ok = (BM * 6) % (WM * WN * 64) == 0 && (BN * 6) % (WM * WN * 64) == 0;
-  static const bool use_reg = reg_ok && getenv("DSEE_G3_REG") != nullptr;  // register-staged variant (A/B measurements)
   constexpr int NSLOT = (region_slots(BM) + 63) / 64 + (region_slots(BN) + 63) / 64;
-  const size_t lds = use_reg ? (size_t)2 * (BM + BN) * ROWB : (size_t)3 * NSLOT * 1024;
+  const size_t lds = (size_t)3 * NSLOT * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    if constexpr (reg_ok)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<WM, WN, MT, NT, FL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * (BM + BN) * ROWB));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3g_kernel<WM, WN, MT, NT, FL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * NSLOT * 1024));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   a.nz = nz;
-  { const char* e = getenv("DSEE_G3_ABL"); a.abl = e ? atoi(e) : 0; }
   const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN) * nz;
   const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);   // resident blocks
   const long grid = ntile < slots ? ntile : slots;
-  if constexpr (reg_ok) {
-    if (use_reg) {
-      gemm3_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
-      DSEE_LAUNCH_CHECK();
-      return DSEE_OK;
-    }
-  }
   gemm3g_kernel<WM, WN, MT, NT, FL><<<(unsigned)grid, WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;

@@ -48,6 +48,31 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
   block_sum_to(acc, part);
 }
 
+// grad[i] = upstream * gscale * dl/da  (the backward half on its own: the loss graph may scale a term, e.g. loss
+// scaling or gradient accumulation with 1/k, so the upstream gradient is a device scalar read here)
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ grad, long n, int ld, int valid_c, int mode,
+                                                        float gscale, const float* __restrict__ upstream) {
+  const float gs = gscale * (upstream ? *upstream : 1.f);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float d = 0.f;
+    if ((int)(i % ld) < valid_c) {
+      const float x = a[i];
+      if (mode == 0) {
+        const float df = x - b[i];
+        d = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+      } else if (mode == 1) {
+        d = -1.f;
+      } else if (mode == 2) {
+        d = x - 1.f < 0.f ? -1.f : 0.f;
+      } else {
+        d = -x - 1.f < 0.f ? 1.f : 0.f;
+      }
+    }
+    grad[i] = d * gs;
+  }
+}
+
 __global__ void loss_finalize_kernel(const float* __restrict__ part, int parts, float scale, float* __restrict__ out) {
   // one wave, fixed order (lane l folds parts l, l+64, ...; then the butterfly): deterministic
   float v = 0.f;
@@ -73,6 +98,19 @@ int dsee_loss_fwd_bwd(int mode, const float* a, const float* b, float* grad, lon
   loss_partial_kernel<<<parts, 256, 0, st>>>(a, b, grad, n, ld, valid_c, mode, weight / cnt, workspace);
   DSEE_LAUNCH_CHECK();
   loss_finalize_kernel<<<1, 64, 0, st>>>(workspace, parts, weight / cnt, loss_out);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* grad = (*upstream) * weight * d mean_valid(l(a[,b])) / da  -- the backward of dsee_loss_fwd_bwd(grad = NULL) for an
+ * arbitrary upstream gradient (device scalar; NULL = 1). */
+int dsee_loss_bwd(int mode, const float* a, const float* b, float* grad, long rows, int ld, int valid_c, float weight,
+                  const float* upstream, hipStream_t st) {
+  DSEE_CHECK_ARG(a && grad && mode >= 0 && mode <= 3 && (mode != 0 || b) && valid_c <= ld);
+  const long n = rows * ld;
+  const float cnt = (float)rows * (float)valid_c;
+  loss_grad_kernel<<<(int)min(4096L, (n + 255) / 256), 256, 0, st>>>(a, b, grad, n, ld, valid_c, mode, weight / cnt,
+                                                                    upstream);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

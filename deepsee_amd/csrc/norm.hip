@@ -131,6 +131,69 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   }
 }
 
+// SyncBN over RCCL, forward half 1: this rank's shard reduced to ONE (mean, M2) row pair per channel (same fixed-order
+// Chan merge as stats_finalize_kernel, no eps / running statistics) -- the 2*C floats that travel.
+__global__ __launch_bounds__(256) void stats_local_kernel(const float* __restrict__ part, float* __restrict__ local,
+                                                          RedGeom g) {
+  __shared__ float sn[32][8], sm[32][8], s2[32][8];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  const bool ok = c < g.C;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (ok)
+    for (int k = lane; k < g.chunks; k += 32) {
+      const int p0 = k * g.chunk_px, p1 = min(g.P, p0 + g.chunk_px);
+      const float nb = (float)(p1 - p0);
+      const float mb = part[((size_t)k * 2) * g.C + c];
+      const float m2b = part[((size_t)k * 2 + 1) * g.C + c];
+      const float d = mb - mean, nt = n + nb;
+      mean += d * nb / nt;
+      m2 += m2b + d * d * n * nb / nt;
+      n = nt;
+    }
+  sn[lane][cl] = n;
+  sm[lane][cl] = mean;
+  s2[lane][cl] = m2;
+  __syncthreads();
+  if (lane != 0 || !ok) return;
+  for (int l = 1; l < 32; ++l) {
+    const float nb = sn[l][cl];
+    if (nb == 0.f) continue;
+    const float d = sm[l][cl] - mean, nt = n + nb;
+    mean += d * nb / nt;
+    m2 += s2[l][cl] + d * d * n * nb / nt;
+    n = nt;
+  }
+  local[c] = mean;
+  local[g.C + c] = m2;
+}
+
+// forward half 2: merge the gathered rows [world][2][C] in rank order (every rank computes the same bits) into the
+// statistics of the GLOBAL batch.  clamp != 0: inv_std = max(var, eps)^-1/2 (the reference's DataParallel branch,
+// sync_batchnorm/batchnorm.py:128-145); clamp == 0: (var + eps)^-1/2 (F.batch_norm, the single-device branch).
+__global__ void stats_merge_kernel(const float* __restrict__ gathered, int world, float count, int C, float eps,
+                                   float momentum, int clamp, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int r = 0; r < world; ++r) {
+    const float mb = gathered[((size_t)r * 2) * C + c], m2b = gathered[((size_t)r * 2 + 1) * C + c];
+    const float d = mb - mean, nt = n + count;
+    mean += d * count / nt;
+    m2 += m2b + d * d * n * count / nt;
+    n = nt;
+  }
+  const float var = m2 / n;
+  mean_out[c] = mean;
+  invstd_out[c] = 1.0f / sqrtf(clamp ? fmaxf(var, eps) : var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+  }
+}
+
 __global__ void eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
                                   float* __restrict__ mean_out, float* __restrict__ invstd_out, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,6 +359,29 @@ int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps,
   return DSEE_OK;
 }
 
+/* SyncBN-over-RCCL (option; reference: the DataParallel branch of SynchronizedBatchNorm2d,
+ * sync_batchnorm/batchnorm.py:70-145).  dsee_norm_stats_local reduces this rank's shard to local[2][C] = (mean, M2);
+ * the caller all-gathers the rows of all ranks (2*C floats each) and dsee_norm_stats_merge folds them in rank order. */
+int dsee_norm_stats_local(const float* x, int N, int HW, int C, float* local, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(x && local && workspace && C % 4 == 0 && C <= 1024);
+  RedGeom g = make_geom(N, HW, C, 1);
+  stats_partial_kernel<<<dim3(g.chunks, 1), 256, 0, st>>>(x, workspace, g);
+  DSEE_LAUNCH_CHECK();
+  stats_local_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, local, g);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_norm_stats_merge(const float* gathered, int world, long count_per_rank, int C, float eps, float momentum,
+                          int clamp, float* mean, float* invstd, float* running_mean, float* running_var,
+                          hipStream_t st) {
+  DSEE_CHECK_ARG(gathered && mean && invstd && world >= 1 && count_per_rank > 0 && C > 0);
+  stats_merge_kernel<<<dsee_cdiv(C, 256), 256, 0, st>>>(gathered, world, (float)count_per_rank, C, eps, momentum, clamp,
+                                                        mean, invstd, running_mean, running_var);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
 int dsee_norm_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
                          float* invstd, hipStream_t st) {
   DSEE_CHECK_ARG(running_mean && running_var && mean && invstd);
@@ -338,26 +424,45 @@ int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const flo
 /* BN + modulate + LeakyReLU backward:
  *   in : dh, h (saved output), x, scale (saved), mean/invstd [C]
  *   out: dgb [M][dgb_ld] in packed gamma/beta order (g*xhat | g), col_sums [2][C] = (sum g*xhat, sum g),
- *        dx = invstd*(g*scale - mean(g*scale) - xhat*mean(g*scale*xhat)) + add */
-int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
-                      const float* invstd, const float* add, float* dx, float* dgb, int dgb_ld, float* col_sums, int N,
-                      int HW, int C, float slope, float* workspace, hipStream_t st) {
-  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && dx && dgb && col_sums && workspace);
+ *        dx = invstd*(g*scale - mean(g*scale) - xhat*mean(g*scale*xhat)) + add
+ * Two halves so that the data-parallel SyncBN option can all-reduce the per-channel sums in between:
+ *   dsee_modulate_bwd_reduce -> sums[4][C] = (sum d, sum d*xhat, sum g*xhat, sum g) over THIS rank's pixels, d = g*scale
+ *   dsee_modulate_bwd_apply  <- sums[0..1] (local, or summed over the ranks) and inv_count = 1 / (pixels behind them) */
+int dsee_modulate_bwd_reduce(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                             const float* invstd, float* dgb, int dgb_ld, float* sums, int N, int HW, int C, float slope,
+                             float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && dgb && sums && workspace);
   DSEE_CHECK_ARG(C % 4 == 0 && C <= 1024 && dgb_ld >= (C + 63) / 64 * 128);
   RedGeom g = make_geom(N, HW, C, 1);
-  float* sums = workspace + (size_t)g.chunks * 4 * g.C;
   norm_bwd_reduce_kernel<1><<<dim3(g.chunks, 1), 256, 0, st>>>(dh, h, x, scale, mean, invstd, dgb, dgb_ld, workspace, g,
                                                                 DSEE_ACT_LRELU, slope);
   DSEE_LAUNCH_CHECK();
   sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 8), 256, 0, st>>>(workspace, sums, 4, g);
   DSEE_LAUNCH_CHECK();
-  (void)hipMemcpyAsync(col_sums, sums + 2 * C, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  return DSEE_OK;
+}
+
+int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                            const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
+                            float inv_count, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && sums && dx && C % 4 == 0 && inv_count > 0.f);
   const long total4 = (long)N * HW * C / 4;
   norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
-                                                             (long)N * HW * C, 1, 1.0f / (float)g.P, DSEE_ACT_LRELU,
-                                                             slope);
+                                                             (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
+}
+
+int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                      const float* invstd, const float* add, float* dx, float* dgb, int dgb_ld, float* col_sums, int N,
+                      int HW, int C, float slope, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(col_sums && workspace && C % 4 == 0 && C <= 1024);
+  RedGeom g = make_geom(N, HW, C, 1);
+  float* sums = workspace + (size_t)g.chunks * 4 * g.C;
+  int rc = dsee_modulate_bwd_reduce(dh, h, x, scale, mean, invstd, dgb, dgb_ld, sums, N, HW, C, slope, workspace, st);
+  if (rc != DSEE_OK) return rc;
+  (void)hipMemcpyAsync(col_sums, sums + 2 * C, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  return dsee_modulate_bwd_apply(dh, h, x, scale, mean, invstd, sums, add, dx, N, HW, C, 1.0f / (float)g.P, slope, st);
 }
 
 }  // extern "C"

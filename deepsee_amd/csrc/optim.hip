@@ -146,17 +146,18 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                    const dsee_adam_tensor* __restrict__ tensors,
-                                                   const int* __restrict__ block_tensor, float beta1, float beta2,
-                                                   float eps, float grad_scale, float clip) {
-  const int t = block_tensor[blockIdx.x];
+                                                   const int* __restrict__ block_tensor, int first_block,
+                                                   float beta1, float beta2, float eps, float grad_scale, float clip) {
+  const int blk = first_block + (int)blockIdx.x;
+  const int t = block_tensor[blk];
   const dsee_adam_tensor d = tensors[t];
   if (!d.active) return;
-  const int step = d.step + 1;  // the host bumps d.step after the launch (same value on every block)
+  const int step = d.step + 1;  // d.step is bumped by the caller after the last launch of a step (same value on every block)
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   const float step_size = d.lr / bc1;
   const float bc2_sqrt = sqrtf(bc2);
-  const long b0 = (long)(blockIdx.x - d.first_block) * 1024;
+  const long b0 = (long)(blk - d.first_block) * 1024;
   for (long i = b0 + threadIdx.x; i < d.numel && i < b0 + 1024; i += 256) {
     const long o = d.offset + i;
     float g = grad[o] * grad_scale;
@@ -176,17 +177,26 @@ extern "C" {
 
 /* Fused Adam over a flat parameter buffer.  `tensors` / `block_tensor` are DEVICE arrays: descriptor t covers
  * elements [offset, offset+numel) and owns blocks [first_block, first_block + ceil(numel/1024)); block_tensor maps
- * each launched block to its descriptor.  `step` in the descriptor is the number of updates already applied to
+ * each block to its descriptor.  `step` in the descriptor is the number of updates already applied to
  * that tensor (torch's state['step']); inactive tensors (grad is None in the reference) are skipped entirely.
- * grad_scale = 1/world_size after the RCCL sum all-reduce. */
+ * grad_scale = 1/world_size after the RCCL sum all-reduce.
+ * dsee_adam_step_range updates blocks [first_block, first_block + nblocks) only: the data-parallel step launches one
+ * range per all-reduced gradient chunk so the update of chunk k overlaps the all-reduce of chunk k+1. */
+int dsee_adam_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                         const dsee_adam_tensor* tensors, const int* block_tensor, int first_block, int nblocks,
+                         float beta1, float beta2, float eps, float grad_scale, float clip, hipStream_t st) {
+  DSEE_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && tensors && block_tensor && first_block >= 0 && nblocks > 0);
+  adam_kernel<<<nblocks, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, tensors, block_tensor, first_block, beta1,
+                                       beta2, eps, grad_scale, clip);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
 int dsee_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks, float beta1, float beta2,
                    float eps, float grad_scale, float clip, hipStream_t st) {
-  DSEE_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && tensors && block_tensor && nblocks > 0);
-  adam_kernel<<<nblocks, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, tensors, block_tensor, beta1, beta2, eps,
-                                       grad_scale, clip);
-  DSEE_LAUNCH_CHECK();
-  return DSEE_OK;
+  return dsee_adam_step_range(param, grad, exp_avg, exp_avg_sq, tensors, block_tensor, 0, nblocks, beta1, beta2, eps,
+                              grad_scale, clip, st);
 }
 
 }  // extern "C"

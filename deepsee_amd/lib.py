@@ -6,6 +6,7 @@ current HIP stream handle.
 """
 import ctypes as C
 import os
+import re
 
 import torch
 
@@ -28,6 +29,31 @@ class DseeError(RuntimeError):
 
 
 _lib = None
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "deepsee_hip.h")
+
+_CTYPES = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "size_t": C.c_size_t, "uint64_t": C.c_uint64,
+           "int32_t": C.c_int32, "int64_t": C.c_int64, "hipStream_t": C.c_void_p, "const char*": C.c_char_p}
+
+
+def header_prototypes(path=HEADER_PATH):
+    """{name: (restype, [argtypes])} parsed from the declarations of include/deepsee_hip.h, so that every call is
+    checked against the header: arity, and the width of every scalar (int / long / size_t / uint64_t / float)."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(dsee_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+        args = []
+        for a in m.group(3).split(","):
+            a = a.strip()
+            if a == "void":
+                continue
+            ty = a.rsplit(None, 1)[0] if not a.endswith("*") else a      # drop the parameter name
+            ty = ty.strip()
+            if ty.endswith("*"):
+                args.append(C.c_void_p)                                  # every pointer is a raw (device) address
+            else:
+                args.append(_CTYPES[ty.replace("const ", "")])
+        protos[m.group(2)] = (_CTYPES[m.group(1)], args)
+    return protos
 
 
 def lib():
@@ -37,11 +63,9 @@ def lib():
             raise DseeError("libdeepsee_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
                             % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
-        _lib.dsee_last_error.restype = C.c_char_p
-        for fn in ("conv2d_wgrad_workspace", "conv2d_wgrad_table_workspace", "norm_workspace", "channel_dot_workspace",
-                   "onehot_conv3x3_wgrad_workspace", "label_segsum_workspace", "loss_workspace",
-                   "wino43_wgrad_workspace", "wino43_wgrad_table_workspace", "conv3x3_thin_wgrad_workspace"):
-            getattr(_lib, "dsee_" + fn).restype = C.c_size_t
+        for name, (res, args) in header_prototypes().items():
+            fn = getattr(_lib, name)            # AttributeError: the library lacks a symbol the header declares
+            fn.restype, fn.argtypes = res, args
     return _lib
 
 
@@ -59,19 +83,24 @@ def ptr(t):
 def _conv(v):
     if isinstance(v, torch.Tensor) or v is None:
         return ptr(v)
-    if isinstance(v, float):
-        return C.c_float(v)
+    if isinstance(v, (C._SimpleCData,)):
+        return v.value                 # explicit C.c_long(...) etc. from older call sites: the argtypes decide the width
     if isinstance(v, bool):
-        return C.c_int(int(v))
-    if isinstance(v, int):
-        return C.c_int(v)
+        return int(v)
     return v
 
 
 def call(name, *args):
-    """Invoke ``dsee_<name>`` on the current stream (appended as the last argument)."""
+    """Invoke ``dsee_<name>`` on the current stream (appended as the last argument).  Arguments are converted by the
+    argtypes parsed from include/deepsee_hip.h: a wrong arity or a float where the header says int raises."""
     fn = getattr(lib(), "dsee_" + name)
-    rc = fn(*[_conv(a) for a in args], stream())
+    if len(args) + 1 != len(fn.argtypes):
+        raise DseeError("dsee_%s takes %d arguments + stream (include/deepsee_hip.h), got %d"
+                        % (name, len(fn.argtypes) - 1, len(args)))
+    try:
+        rc = fn(*[_conv(a) for a in args], stream())
+    except (C.ArgumentError, TypeError) as e:
+        raise DseeError("dsee_%s: call does not match include/deepsee_hip.h: %s" % (name, e)) from None
     if rc != 0:
         raise DseeError("dsee_%s failed (%d): %s" % (name, rc, lib().dsee_last_error().decode()))
 

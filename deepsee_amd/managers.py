@@ -25,6 +25,11 @@ class BaseManager:
     def preprocess(self, data, from_dataloader=False):
         """base_manager.py:28-66 + data/preprocessor.py: label -> integer map (kept as uint8 instead of a one-hot
         tensor), HR -> LR bicubic + clamp, everything NHWC on the device."""
+        if isinstance(data.get("input_semantics"), ops.Labels):
+            return data        # already native: a batch of deepsee_amd.data.DeviceLoader (SURVEY 8 f3)
+        if from_dataloader and data["image"].dtype == torch.uint8:
+            from .data import device_preprocess      # uint8 wire format: [N,H,W] labels, [N,H,W,3] images
+            return device_preprocess(self.opt, data)
         out = dict(data)
         for k, v in data.items():
             if isinstance(v, torch.Tensor) and not v.is_cuda:

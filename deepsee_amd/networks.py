@@ -85,11 +85,16 @@ class Conv1dP(nn.Module):
 # ------------------------------------------------------------------------------------ noise / randomness
 class DeviceNoise:
     """Production source of the path's random draws: Philox counter RNG on the device for N(0,1)/U(0,1)
-    tensors, python ``random`` for the two per-forward branch coins (sr_model.py:616,643)."""
+    tensors; the two per-forward branch coins (sr_model.py:616,643: python ``random`` in the reference) come from
+    this object's OWN ``random.Random(coin_seed)``.  Under data-parallel training every rank must take the same
+    encoder branch (the unused branch gets no gradient): `coin_seed` is therefore the same on all ranks
+    (it never depends on the rank, unlike `seed`, which parallel.attach offsets per rank for the noise tensors), and
+    nothing else in the process -- a dataset drawing from the global ``random``, say -- can desynchronise it."""
 
-    def __init__(self, seed=0):
+    def __init__(self, seed=0, coin_seed=None):
         import random as _r
-        self.seed, self.offset, self._r = int(seed), 0, _r
+        self.seed, self.offset = int(seed), 0
+        self._r = _r.Random(int(seed) if coin_seed is None else int(coin_seed))
 
     def coin(self, tag):
         return self._r.random()

@@ -122,6 +122,7 @@ def to_nhwc(x_nchw, cs=None):
     cs = cs or L.pad4(c)
     y = new(n, h, w, cs)
     L.call("nchw_to_nhwc", x_nchw.contiguous().float(), y, n, c, h, w, cs)
+    y.dsee_layout = "nhwc"
     return y
 
 
@@ -155,6 +156,7 @@ def bicubic_down(img_nhwc, size):
     n, h, w, cs = img_nhwc.shape
     y = new(n, size, size, 4)
     L.call("bicubic_down", img_nhwc, y, n, h, w, size, cs, 4)
+    y.dsee_layout = "nhwc"
     return y
 
 
@@ -675,6 +677,59 @@ def pack_gamma_beta(w_gamma, w_beta, b_gamma, b_beta):
     return w2, b2
 
 
+class SyncBNConfig:
+    """SyncBN-over-RCCL option: BatchNorm statistics over the GLOBAL batch of all data-parallel ranks, the
+    reference's DataParallel branch (sync_batchnorm/batchnorm.py:70-145) with its clamp(var, eps).  Off by default:
+    north_star's sync-free BN uses the shard's statistics (= the reference's single-device branch per shard)."""
+
+    def __init__(self, world, group=None, clamp=True):
+        self.world, self.group, self.clamp = int(world), group, bool(clamp)
+
+
+SYNC_BN = None   # set by SRModel / parallel.attach when opt.sync_bn
+
+
+def bn_stats(x, running_mean, running_var, training):
+    """(mean, invstd, synced) of the param-free BatchNorm inside SPADE/SEAN."""
+    n, h, w, c = x.shape
+    mean, invstd = new(c), new(c)
+    if not training:
+        L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
+        return mean, invstd, None
+    ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
+    cfg = SYNC_BN
+    if cfg is None:
+        L.call("norm_stats", x, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var, ws)
+        return mean, invstd, None
+    from . import parallel
+    local = new(2, c)
+    L.call("norm_stats_local", x, n, h * w, c, local, ws)
+    rows = parallel.gather_stats(local, cfg.world, cfg.group)      # [world, 2, C]: 8*C bytes per rank
+    L.call("norm_stats_merge", rows, cfg.world, n * h * w, c, BN_EPS, BN_MOMENTUM, int(cfg.clamp), mean, invstd,
+           running_mean, running_var)
+    return mean, invstd, cfg
+
+
+def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg):
+    """Backward of BN + modulate + LeakyReLU: (dx, dgb, col_sums [2][C]).  With SyncBN (`cfg`) the two per-channel sums
+    of the BN backward are all-reduced over the ranks between the reduce and the apply pass."""
+    n, h, w, c = x.shape
+    dgb = (torch.zeros if c % 64 else torch.empty)(n, h, w, rows, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    sums = new(4, c)
+    ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
+    L.call("modulate_bwd_reduce", dh.contiguous(), out, x, scale, mean, invstd, dgb, rows, sums, n, h * w, c,
+           LRELU_SLOPE, ws)
+    count = n * h * w
+    if cfg is not None:
+        from . import parallel
+        parallel.allreduce_sums(sums[0:2], cfg.world, cfg.group)
+        count *= cfg.world
+    L.call("modulate_bwd_apply", dh.contiguous(), out, x, scale, mean, invstd, sums, None, dx, n, h * w, c, 1.0 / count,
+           LRELU_SLOPE)
+    return dx, dgb, sums[2:4]
+
+
 class SpadeNormAct(torch.autograd.Function):
     """h = lrelu(BN(x) * (conv_gamma(cat) + add_one) + conv_beta(cat)) with gamma/beta formed inside the GEMM
     epilogue; BN = sync-free batch statistics in training, running statistics in eval."""
@@ -684,12 +739,7 @@ class SpadeNormAct(torch.autograd.Function):
         n, h, w, c = x.shape
         rows, kin = w2.shape[0], w2.shape[1]
         assert cat.shape[3] == kin and kin % 4 == 0
-        mean, invstd = new(c), new(c)
-        if training:
-            ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
-            L.call("norm_stats", x, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var, ws)
-        else:
-            L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
+        mean, invstd, ctx.sync = bn_stats(x, running_mean, running_var, training)
         geom = L.geom_fwd(n, cat.shape[1], cat.shape[2], kin, rows, 3, 1, 1, cat_ups)
         assert geom.Ho == h and geom.Wo == w
         w2 = w2.contiguous()
@@ -708,12 +758,7 @@ class SpadeNormAct(torch.autograd.Function):
         geom = ctx.geom
         n, h, w, c = x.shape
         rows, kin = w2.shape[0], w2.shape[1]
-        dgb = (torch.zeros if c % 64 else torch.empty)(n, h, w, rows, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
-        cs = new(2, c)
-        ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
-        L.call("modulate_bwd", dh.contiguous(), out, x, scale, mean, invstd, None, dx, dgb, rows, cs, n, h * w, c,
-               LRELU_SLOPE, ws)
+        dx, dgb, cs = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync)
         dcat = dw2 = db2 = None
         if ctx.needs_input_grad[1]:
             gd = L.geom_dgrad(geom)
@@ -755,12 +800,7 @@ class SeanNormTable(torch.autograd.Function):
             L.call("onehot_conv3x3_fwd", labels.t, tab, b_sh, cat, n, labels.h, labels.w, shift, nc, NHIDDEN, ld, 0, 1)
         if has_t:
             L.call("label_onehot", labels.t, cat, n, labels.h, labels.w, shift, ld, ca)
-        mean, invstd = new(c), new(c)
-        if training:
-            ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
-            L.call("norm_stats", x, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var, ws)
-        else:
-            L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
+        mean, invstd, ctx.sync = bn_stats(x, running_mean, running_var, training)
         geom = L.geom_fwd(n, h, w, ld, rows, 3, 1, 1, 0)
         assert geom.korder == 1
         if has_a:
@@ -802,12 +842,7 @@ class SeanNormTable(torch.autograd.Function):
         geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
         n, h, w, c = x.shape
         ld = cat.shape[3]
-        dgb = (torch.zeros if c % 64 else torch.empty)(n, h, w, rows, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
-        cs = new(2, c)
-        ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
-        L.call("modulate_bwd", dh.contiguous(), out, x, scale, mean, invstd, None, dx, dgb, rows, cs, n, h * w, c,
-               LRELU_SLOPE, ws)
+        dx, dgb, cs = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync)
         dw_sh = db_sh = dw2a = dtable = db2 = None
         nb = ctx.wino_nb
         wino_w = bool(nb) and (ctx.has_t or ctx.needs_input_grad[3])
@@ -1008,29 +1043,32 @@ MODE_L1, MODE_NEG, MODE_HINGE_REAL, MODE_HINGE_FAKE = 0, 1, 2, 3
 
 
 class MeanLoss(torch.autograd.Function):
-    """weight * mean(l(a[lo:hi][, b])) with the gradient w.r.t. `a` produced in the same pass (zero outside
-    [lo,hi)).  The backward returns the stored gradient unscaled: the train step calls backward() on
-    sum(losses).mean(), i.e. with unit upstream gradient (trainer_manager.py:36-37,53-54)."""
+    """weight * mean(l(a[lo:hi][, b])); the gradient w.r.t. `a` (zero outside [lo,hi)) is formed in the backward pass
+    from the upstream gradient (a device scalar), so re-weighted terms / loss scaling / 1/k accumulation are exact.
+    The train step itself backpropagates sum(losses).mean() (trainer_manager.py:36-37,53-54)."""
 
     @staticmethod
     def forward(ctx, a, b, mode, weight, valid_c, lo, hi):
         a = a.contiguous()
+        b = b.contiguous() if b is not None else None
         ld = a.shape[-1]
         sub = a[lo:hi]
-        rows = sub.numel() // ld
         loss = torch.zeros(1, dtype=torch.float32, device=a.device)
-        grad = gsub = None
-        if ctx.needs_input_grad[0]:
-            grad = torch.empty_like(a) if (lo == 0 and hi == a.shape[0]) else torch.zeros_like(a)
-            gsub = grad[lo:hi]
-        L.call("loss_fwd_bwd", mode, sub, b.contiguous() if b is not None else None, gsub, C.c_long(rows), ld,
-               valid_c, float(weight), loss, scratch(L.lib().dsee_loss_workspace(), "loss"))
-        ctx.save_for_backward(grad)
+        L.call("loss_fwd_bwd", mode, sub, b, None, sub.numel() // ld, ld, valid_c, float(weight), loss,
+               scratch(L.lib().dsee_loss_workspace(), "loss"))
+        ctx.args = (mode, float(weight), valid_c, lo, hi)
+        ctx.save_for_backward(a, b)
         return loss
 
     @staticmethod
     def backward(ctx, dl):
-        (grad,) = ctx.saved_tensors
+        a, b = ctx.saved_tensors
+        mode, weight, valid_c, lo, hi = ctx.args
+        ld = a.shape[-1]
+        grad = torch.empty_like(a) if (lo == 0 and hi == a.shape[0]) else torch.zeros_like(a)
+        sub = grad[lo:hi]
+        L.call("loss_bwd", mode, a[lo:hi], b, sub, sub.numel() // ld, ld, valid_c, weight,
+               dl.reshape(-1)[:1].contiguous().float())
         return grad, None, None, None, None, None, None
 
 

@@ -1,8 +1,13 @@
-"""Fused multi-tensor Adam over flat fp32 buffers (C ABI: dsee_adam_step) with torch.optim.Adam semantics
+"""Fused multi-tensor Adam over flat fp32 buffers (C ABI: dsee_adam_step_range) with torch.optim.Adam semantics
 (sr_model.py:488-493: betas (beta1, beta2), eps 1e-8, no weight decay) including "a parameter whose .grad is
-None is skipped" per tensor, and the hook for the data-parallel gradient all-reduce."""
-import ctypes as C
+None is skipped" per tensor, and the data-parallel gradient exchange overlapped with the update: the flat gradient
+is all-reduced in chunks (deepsee_amd.parallel.GradAllReduce) and the Adam launch of chunk k runs while RCCL is
+still reducing chunk k+1 (north_star).
 
+The per-tensor descriptors (offset, numel, first block, step count, lr, active flag: dsee_adam_tensor in
+include/deepsee_hip.h) live on the DEVICE for good: a step uploads only the `touched` flags (pinned, asynchronous),
+optionally MAX-reduces them over the ranks, and bumps the step counters with a device-side add -- no blocking
+host-to-device copy per optimizer step."""
 import numpy as np
 import torch
 
@@ -10,6 +15,9 @@ from . import lib as L
 
 ADAM_DT = np.dtype([("offset", "<i8"), ("numel", "<i8"), ("first_block", "<i4"), ("step", "<i4"), ("lr", "<f4"),
                     ("active", "<i4")])
+_W = ADAM_DT.itemsize // 4          # 32-bit words per descriptor
+_STEP, _LR, _ACTIVE = 5, 6, 7       # word index of the dynamic fields
+BLOCK = 1024                        # elements per Adam block (a block never straddles two tensors)
 
 
 class FlatAdam:
@@ -38,25 +46,38 @@ class FlatAdam:
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.desc = np.zeros(len(self.params), dtype=ADAM_DT)
-        blocks, fb = [], 0
+        desc = np.zeros(len(self.params), dtype=ADAM_DT)
+        blocks, block_start, fb = [], [], 0
         for i, (p, o) in enumerate(zip(self.params, offs)):
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
-            nb = (n + 1023) // 1024
-            self.desc[i] = (o, n, fb, 0, 0.0, 1)
+            nb = (n + BLOCK - 1) // BLOCK
+            desc[i] = (o, n, fb, 0, self.param_groups[self.group_of[i]]["lr"], 1)
             blocks += [i] * nb
+            block_start += [o + j * BLOCK for j in range(nb)]
             fb += nb
         self.nblocks = fb
+        self.block_start = block_start                      # first element of every block (host copy, for the chunking)
         self.block_tensor = torch.tensor(blocks, dtype=torch.int32, device=dev)
-        self.desc_dev = torch.zeros(self.desc.nbytes, dtype=torch.uint8, device=dev)
+        self.desc_dev = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self._d32 = self.desc_dev.view(torch.int32).view(len(self.params), _W)
+        self._dlr = self.desc_dev.view(torch.float32).view(len(self.params), _W)[:, _LR]
+        self._lr_sent = [self.param_groups[g]["lr"] for g in self.group_of]
         self.offsets = offs
-        self.reduce_hook = None   # callable(flat_grad) -> grad_scale, installed by parallel.DataParallel
+        self.reduce_hook = None   # parallel.GradAllReduce, installed by parallel.attach
         # "p.grad is None -> skipped" (torch.optim.Adam after zero_grad(set_to_none=True)): a tensor is active in
         # a step iff autograd delivered a gradient for it since the last zero_grad().
         self.touched = np.zeros(len(self.params), dtype=np.int32)
+        # ring of pinned staging buffers for the asynchronous upload of `touched` (the host runs ahead of the GPU: a
+        # buffer is reused only after the copy that read it has executed)
+        self._ring, self._ring_pos = [], 0
+        for _ in range(4 if dev.type == "cuda" else 1):
+            t = torch.zeros(len(self.params), dtype=torch.int32)
+            self._ring.append([t.pin_memory() if dev.type == "cuda" else t, None])
+        self._active_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
+        self._ranges = {}
         for i, p in enumerate(self.params):
             p.register_hook(self._make_hook(i))
 
@@ -73,19 +94,62 @@ class FlatAdam:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
+    def chunk_ranges(self, chunk_elems):
+        """[(first_block, end_block, lo, hi)]: block ranges of about chunk_elems elements whose element spans [lo, hi)
+        tile the flat buffer exactly (tensor padding included), so 'all-reduce [lo,hi) then Adam on its blocks' covers
+        every gradient element once."""
+        if chunk_elems not in self._ranges:
+            out, b0 = [], 0
+            while b0 < self.nblocks:
+                b1 = b0 + 1
+                while b1 < self.nblocks and self.block_start[b1] - self.block_start[b0] < chunk_elems:
+                    b1 += 1
+                lo = 0 if b0 == 0 else self.block_start[b0]
+                hi = self.total if b1 == self.nblocks else self.block_start[b1]
+                out.append((b0, b1, lo, hi))
+                b0 = b1
+            self._ranges[chunk_elems] = out
+        return self._ranges[chunk_elems]
+
+    def _launch(self, b0, b1, grad_scale, clip):
+        L.call("adam_step_range", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.desc_dev, self.block_tensor,
+               b0, b1 - b0, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale), float(clip))
+
     def step(self, clip=-1.0):
-        grad_scale = 1.0
-        if self.reduce_hook is not None:
-            grad_scale = self.reduce_hook(self.grad)
-        self.desc["active"] = self.touched
-        for i in range(len(self.names)):
-            self.desc["lr"][i] = self.param_groups[self.group_of[i]]["lr"]
-        host = torch.from_numpy(self.desc.view(np.uint8).copy())
-        self.desc_dev.copy_(host, non_blocking=False)
-        L.call("adam_step", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, C.c_void_p(self.desc_dev.data_ptr()),
-               C.c_void_p(self.block_tensor.data_ptr()), self.nblocks, float(self.betas[0]), float(self.betas[1]),
-               float(self.eps), float(grad_scale), float(clip))
-        self.desc["step"] += self.desc["active"]
+        hook = self.reduce_hook
+        multi = hook is not None and hook.active
+        # learning rates: uploaded only when a param_group's lr changed (TrainerManager.update_learning_rate)
+        lrs = [self.param_groups[g]["lr"] for g in self.group_of]
+        if lrs != self._lr_sent:
+            self._dlr.copy_(torch.tensor(lrs, dtype=torch.float32))
+            self._lr_sent = lrs
+        # active flags: this rank's `touched`, MAX over the ranks (a rank whose encoder coin differed would otherwise
+        # update a different parameter subset with a different step count -- parameters would silently diverge)
+        slot = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].copy_(torch.from_numpy(self.touched))
+        self._active_dev.copy_(slot[0], non_blocking=True)
+        if self._active_dev.is_cuda:
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        if multi:
+            hook.reduce_active(self._active_dev)
+        self._d32[:, _ACTIVE].copy_(self._active_dev)
+        if multi:
+            ranges = self.chunk_ranges(hook.chunk_elems)
+            works = hook.start(self.grad, [(lo, hi) for _, _, lo, hi in ranges])
+            for (b0, b1, _, _), w in zip(ranges, works):
+                w.wait()      # the compute stream waits for THIS chunk only; RCCL keeps reducing the later ones
+                self._launch(b0, b1, hook.scale, clip)
+        else:
+            self._launch(0, self.nblocks, 1.0, clip)
+        self._d32[:, _STEP] += self._d32[:, _ACTIVE]
+
+    def steps(self):
+        """Per-tensor update counts (torch's state['step']), read back from the device."""
+        return self._d32[:, _STEP].cpu().numpy().copy()
 
     def state_dict(self):
-        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.desc["step"].copy()}
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.steps()}

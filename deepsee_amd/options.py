@@ -20,6 +20,11 @@ DEFAULTS = dict(
     gan_mode="hinge", gradient_clip=-1.0, num_upsampling_layers="normal",
     niter=50, niter_decay=25, gpu_info=False, checkpoints_dir="./checkpoints",
     seed=0,
+    # build-only options (no counterpart in the reference's parser)
+    vgg_weights=None,        # path of torchvision's vgg19 state dict (the reference downloads it, architecture.py:154)
+    sync_bn=False,           # data-parallel: BatchNorm statistics over the global batch; default sync-free
+    sync_bn_clamp=True,      # ... with the reference DP branch's clamp(var, eps) (batchnorm.py:145) instead of var + eps
+    preprocess_mode="resize_and_crop", no_flip=False,
 )
 
 PRESETS = {

@@ -1,16 +1,25 @@
 """Data-parallel training: one process per GPU, RCCL (torch.distributed backend "nccl" on ROCm) sum all-reduce of
-the flat G / D gradient buffers over xGMI, chunked so the fused Adam of chunk k overlaps the all-reduce of
-chunk k+1 (north_star).
+the flat G / D gradient buffers over xGMI, issued as chunks on RCCL's stream; the fused Adam launch of chunk k runs
+on the compute stream while RCCL is still reducing chunk k+1 (deepsee_amd.optim.FlatAdam.step; north_star,
+SURVEY 2.3, 8e).
 
 Replaces torch.nn.DataParallel + DataParallelWithCallback (sync_batchnorm/replicate.py:50-94,
 base_manager.py:15-23): no per-iteration parameter broadcast, no scatter/gather, BatchNorm statistics are
-shard-local (sync-free, identical to the reference's single-device branch on each shard), and the gradient
-exchange is one collective per optimizer step instead of a reduce-to-GPU0.
+shard-local by default (sync-free, identical to the reference's single-device branch on each shard; `opt.sync_bn`
+switches to statistics over the global batch, the reference's DP branch, sync_batchnorm/batchnorm.py:70-145), and the
+gradient exchange is one chunked collective per optimizer step instead of a reduce-to-GPU0.
+
+Rank consistency: parameters and spectral-norm buffers start identical (broadcast from rank 0) and stay
+identical because every rank applies the same all-reduced gradient; the encoder-branch coins come from
+networks.DeviceNoise's own rank-independent RNG; the per-tensor "has a gradient" flags are MAX-reduced before every
+optimizer step so no rank can update a different parameter subset; the device noise seed is offset per rank.
 """
 import os
 
 import torch
 import torch.distributed as dist
+
+NOISE_SEED_STRIDE = 1000003   # per-rank offset of the Philox noise seed (different noise per shard)
 
 
 def init_distributed(backend=None):
@@ -38,33 +47,85 @@ def chunk_bounds(total, chunk_elems):
 
 
 class GradAllReduce:
-    """Callable installed as FlatAdam.reduce_hook: launches the chunked async all-reduces on RCCL's stream and makes
-    the compute stream wait for them in order; returns the 1/world scale the Adam kernel folds into the gradient
-    (== reference DP's mean of per-replica mean losses, trainer_manager.py:36)."""
+    """Installed as FlatAdam.reduce_hook.  `start` launches the asynchronous sum all-reduce of every chunk on RCCL's
+    stream and returns the work handles; FlatAdam waits for chunk k (stream-level on NCCL/RCCL, host-level on gloo),
+    launches the Adam blocks of chunk k and moves on, so the update overlaps the remaining all-reduces.  `scale` is
+    the 1/world the Adam kernel folds into the gradient (== reference DP's mean of per-replica mean losses,
+    trainer_manager.py:36)."""
 
-    def __init__(self, world, chunk_mb=24.0, group=None):
-        self.world, self.group = world, group
-        self.chunk_elems = int(chunk_mb * (1 << 20) / 4)
+    def __init__(self, world, chunk_mb=24.0, group=None, force=False):
+        self.world, self.group = int(world), group
+        self.chunk_elems = max(4, int(chunk_mb * (1 << 20) / 4))
+        self.scale = 1.0 / max(1, self.world)
+        # `force`: run the collectives even in a 1-rank process group (exercises the RCCL path on a single GPU)
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+
+    def reduce_active(self, active):
+        """MAX over the ranks of the per-tensor "autograd delivered a gradient" flags (int32, in place)."""
+        if self.active:
+            dist.all_reduce(active, op=dist.ReduceOp.MAX, group=self.group)
+        return active
+
+    def start(self, flat_grad, bounds):
+        if not self.active:
+            return [None] * len(bounds)
+        return [dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                for lo, hi in bounds]
 
     def __call__(self, flat_grad):
-        if self.world <= 1:
-            return 1.0
-        works = [dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for lo, hi in chunk_bounds(flat_grad.numel(), self.chunk_elems)]
-        for w in works:
-            w.wait()   # stream-level wait on NCCL/RCCL; host-level on gloo
-        return 1.0 / self.world
+        """Blocking form (whole buffer in chunks): returns the gradient scale."""
+        for w in self.start(flat_grad, chunk_bounds(flat_grad.numel(), self.chunk_elems)):
+            if w is not None:
+                w.wait()
+        return self.scale
 
 
-def attach(trainer, world, chunk_mb=24.0):
-    """Hook a TrainerManager's optimizers up for data-parallel training and check rank consistency of the init."""
-    hook = GradAllReduce(world, chunk_mb)
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
+def gather_stats(local, world, group=None):
+    """SyncBN forward exchange: every rank contributes its shard's (mean, M2) rows [2, C]; returns [world, 2, C] in rank
+    order (the merge kernel folds them with Chan's update in that fixed order, so every rank computes bit-identical
+    statistics).  Replaces the master's ReduceAddCoalesced + Broadcast of (sum, ssum) through Python queue pipes
+    (sync_batchnorm/batchnorm.py:105-126, comm.py:46-133): 8*C bytes per rank per BN layer."""
+    if world <= 1 and not _dist_on():
+        return local.unsqueeze(0)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=group)
+    return out
+
+
+def allreduce_sums(sums, world, group=None):
+    """SyncBN backward exchange: the per-channel sums (sum d, sum d*xhat) of the BN backward over the GLOBAL batch
+    (the reference gets them through autograd of its ReduceAddCoalesced / Broadcast nodes)."""
+    if world > 1 or _dist_on():
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+def attach(trainer, world, chunk_mb=24.0, rank=None, force=False):
+    """Hook a TrainerManager's optimizers up for data-parallel training, make the start state identical on every
+    rank, give every rank its own noise stream, switch SyncBN on if opt.sync_bn.  `force` keeps the collectives in the
+    path even with one rank (a 1-rank NCCL group: the -m gpu test that runs this code on the MI355X)."""
+    from . import ops
+    hook = GradAllReduce(world, chunk_mb, force=force)
     trainer.optimizer_G.reduce_hook = hook
-    trainer.optimizer_D.reduce_hook = hook
+    if trainer.optimizer_D is not None:
+        trainer.optimizer_D.reduce_hook = hook
+    model = trainer.sr_model_on_one_gpu
+    if rank is None:
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    model.noise.seed += NOISE_SEED_STRIDE * rank
+    model.dp_world, model.dp_rank = int(world), int(rank)
+    opt = trainer.opt
+    ops.SYNC_BN = (ops.SyncBNConfig(world, None, getattr(opt, "sync_bn_clamp", True))
+                   if getattr(opt, "sync_bn", False) and (world > 1 or force) else None)
     if world > 1:
         for opt in (trainer.optimizer_G, trainer.optimizer_D):
-            dist.broadcast(opt.flat, src=0)   # identical start on every rank (also true by seed)
-        for net in (trainer.sr_model.netSR, trainer.sr_model.netD, trainer.sr_model.netE):
+            if opt is not None:
+                dist.broadcast(opt.flat, src=0)   # identical start on every rank (also true by seed)
+        for net in (model.netSR, model.netD, model.netE):
             if net is not None:
                 for b in net.buffers():
                     if b.is_floating_point():

@@ -7,6 +7,7 @@ save(epoch) / load_weights().  All activation-space compute runs in libdeepsee_h
 import math
 import os
 import sys
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -74,7 +75,7 @@ class SRModel(nn.Module):
         L.lib()  # fail loudly if libdeepsee_hip.so is missing
         self.opt = opt
         self.use_E = opt.netE is not None and len(opt.netE) > 0
-        self.model_variant = "guided" if "full" in opt.netE else "independent"
+        self.model_variant = "guided" if (self.use_E and "full" in opt.netE) else "independent"   # sr_model.py:26-30
         gen = torch.Generator().manual_seed(int(getattr(opt, "seed", 0)))
         self.netSR = N.DeepSEESR(opt, block_plan(opt))
         init_weights(self.netSR, opt.init_type, opt.init_variance, gen)
@@ -88,10 +89,20 @@ class SRModel(nn.Module):
             init_weights(self.netE, opt.init_type, opt.init_variance, gen)
         self.vgg = None
         if opt.isTrain and not opt.no_vgg_loss:
-            # the reference downloads torchvision's pretrained VGG19 (architecture.py:154); without network access
-            # the weights are He-initialised here and can be replaced with load_vgg_state().
+            # the reference downloads torchvision's pretrained VGG19 (architecture.py:154).  opt.vgg_weights names a
+            # local copy of that state dict (torchvision keys 'features.N.weight/bias', or the bare 'N.weight/bias' of
+            # vgg19().features); without it the taps are He-initialised random features, NOT a perceptual loss.
             self.vgg = N.VGG19Taps()
             init_weights(self.vgg, "kaiming", 1.0, gen)
+            self.vgg_pretrained = False
+            path = getattr(opt, "vgg_weights", None)
+            if path:
+                self.load_vgg_state(torch.load(path, map_location="cpu"))
+            else:
+                warnings.warn("deepsee_amd: no pretrained VGG19 weights (opt.vgg_weights is unset): the VGG loss term "
+                              "(lambda_vgg=%g) runs on randomly initialised features.  Fine for benchmarks and parity "
+                              "tests; for real training pass opt.vgg_weights=<torchvision vgg19 state dict> or call "
+                              "SRModel.load_vgg_state()." % opt.lambda_vgg, RuntimeWarning, stacklevel=2)
         self.cuda()
         self.noise = N.DeviceNoise(seed=int(getattr(opt, "seed", 0)) * 7919 + 17)
         self.logs = OrderedDict()
@@ -133,9 +144,25 @@ class SRModel(nn.Module):
         else:
             raise ValueError("|mode| is invalid")
 
+    def load_vgg_state(self, state):
+        """Load torchvision's vgg19 weights into the frozen perceptual taps (architecture.py:151-181).  Accepts the
+        full model's state dict ('features.N.*', classifier keys ignored) or that of vgg19().features ('N.*')."""
+        own = self.vgg.state_dict()
+        picked = {}
+        for k in own:
+            bare = k[len("features."):]
+            if k in state:
+                picked[k] = state[k]
+            elif bare in state:
+                picked[k] = state[bare]
+            else:
+                raise RuntimeError("VGG19 state dict lacks %s" % k)
+        self.load_net_state(self.vgg, picked)
+        self.vgg_pretrained = True
+
     def create_optimizers(self, opt):
         """sr_model.py:469-495: G = SR params + non-'mini' E params @ lr/2 (group 0), 'mini' E params @ lr/8
-        (group 1); D @ 2*lr; betas (beta1, beta2)."""
+        (group 1); D @ 2*lr; betas (beta1, beta2).  Without a discriminator (isTrain False) opt_D is None."""
         g_main = [("SR." + k, p) for k, p in self.netSR.named_parameters()]
         g_low = []
         if self.use_E:
@@ -147,20 +174,31 @@ class SRModel(nn.Module):
         if g_low:
             groups.append({"params": g_low, "lr": lr_g / 4})
         opt_g = FlatAdam(groups, betas=(opt.beta1, opt.beta2))
-        opt_d = FlatAdam([{"params": [("D." + k, p) for k, p in self.netD.named_parameters()], "lr": lr_d}],
-                         betas=(opt.beta1, opt.beta2))
+        opt_d = None
+        if self.netD is not None:
+            opt_d = FlatAdam([{"params": [("D." + k, p) for k, p in self.netD.named_parameters()], "lr": lr_d}],
+                             betas=(opt.beta1, opt.beta2))
         return opt_g, opt_d
 
     def _ckpt(self, label, epoch):
         return os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_net_%s.pth" % (epoch, label))
 
     def save(self, epoch):
-        """util/util.py:217-226: {epoch}_net_{SR,D,E}.pth = {"model": state_dict} with the reference's keys."""
+        """util/util.py:217-226: {epoch}_net_{SR,D,E}.pth = {"model": state_dict} with the reference's keys.
+        Data-parallel: only rank 0 writes (parameters and spectral-norm buffers are identical on every rank; the
+        sync-free BatchNorm running statistics saved are rank 0's shard's, as in the reference DP where only the master
+        replica keeps them, sync_batchnorm/batchnorm.py:128-145).  Files are written to a temporary name and renamed,
+        so a reader never sees a torn checkpoint."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return
         os.makedirs(os.path.join(self.opt.checkpoints_dir, self.opt.name), exist_ok=True)
         for label, net in (("SR", self.netSR), ("D", self.netD), ("E", self.netE)):
             if net is not None:
-                torch.save({"model": OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())},
-                           self._ckpt(label, epoch))
+                path = self._ckpt(label, epoch)
+                tmp = "%s.tmp.%d" % (path, os.getpid())
+                torch.save({"model": OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())}, tmp)
+                os.replace(tmp, path)
 
     def load_weights(self):
         opt = self.opt
@@ -203,7 +241,10 @@ class SRModel(nn.Module):
         d["guiding_labels"] = gl
         for k in ("image_lr", "image_hr", "guiding_image"):
             v = data.get(k)
-            if isinstance(v, torch.Tensor) and v.dim() == 4 and v.shape[1] == 3 and v.shape[3] != 4:
+            # the layout is tagged by whoever produced the tensor (ops.to_nhwc / bicubic_down / the device input
+            # pipeline set .dsee_layout), never guessed from the shape: [N,3,H,4] is a legal NCHW image at start_size 4
+            if isinstance(v, torch.Tensor) and getattr(v, "dsee_layout", None) != "nhwc":
+                assert v.dim() == 4 and v.shape[1] == 3, "%s: expected an NCHW RGB tensor, got %s" % (k, tuple(v.shape))
                 v = ops.to_nhwc(v.cuda())
             d[k] = v
         return d

@@ -182,6 +182,17 @@ int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const floa
 size_t dsee_norm_workspace(int N, int HW, int C, int groups);
 int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps, float momentum, float* mean,
                     float* invstd, float* running_mean, float* running_var, float* workspace, hipStream_t stream);
+/* SyncBN over RCCL (option `sync_bn`; reference: the DataParallel branch of SynchronizedBatchNorm2d,
+ * sync_batchnorm/batchnorm.py:70-145, which sends (sum, ssum) through Python queue pipes to a master GPU and broadcasts
+ * mean / inv_std back).  Here every rank reduces its shard to local[2][C] = (mean, M2) (dsee_norm_stats_local), the
+ * rows are all-gathered (2*C floats per rank), and dsee_norm_stats_merge folds them in rank order with Chan's update:
+ * statistics of the GLOBAL batch, bit-identical on every rank.  clamp != 0: inv_std = max(var, eps)^-1/2 as
+ * batchnorm.py:145; clamp == 0: (var + eps)^-1/2 as F.batch_norm.  Running statistics: momentum update with the
+ * unbiased global variance (batchnorm.py:134-143). */
+int dsee_norm_stats_local(const float* x, int N, int HW, int C, float* local, float* workspace, hipStream_t stream);
+int dsee_norm_stats_merge(const float* gathered, int world, long count_per_rank, int C, float eps, float momentum,
+                          int clamp, float* mean, float* invstd, float* running_mean, float* running_var,
+                          hipStream_t stream);
 /* eval-mode BN: mean = running_mean, invstd = 1/sqrt(running_var + eps) (sr_model.py:85-91 inference) */
 int dsee_norm_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
                          float* invstd, hipStream_t stream);
@@ -198,6 +209,17 @@ int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const flo
 int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                       const float* invstd, const float* add, float* dx, float* dgb, int dgb_ld, float* col_sums, int N,
                       int HW, int C, float slope, float* workspace, hipStream_t stream);
+
+/* The two halves of dsee_modulate_bwd, so that SyncBN can all-reduce the per-channel sums of the BN backward over the
+ * global batch in between: reduce writes dgb and sums[4][C] = (sum d, sum d*xhat, sum g*xhat, sum g) of THIS rank's
+ * pixels (d = g*scale; rows 2..3 are the bias gradients = col_sums); apply reads sums[0..1] and inv_count =
+ * 1 / (number of pixels behind them). */
+int dsee_modulate_bwd_reduce(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                             const float* invstd, float* dgb, int dgb_ld, float* sums, int N, int HW, int C, float slope,
+                             float* workspace, hipStream_t stream);
+int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                            const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
+                            float inv_count, float slope, hipStream_t stream);
 
 /* ------------------------------------------------------------------ label-map kernels (uint8 [N][H][W])
  * mlp_shared = ReLU(conv3x3(one-hot)) (normalization.py:98-101) as a 9-tap gather-sum of weight columns. */
@@ -249,6 +271,13 @@ int dsee_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int 
 int dsee_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cs, hipStream_t stream);
 int dsee_label_to_u8(const float* label, uint8_t* out, long n, hipStream_t stream);
 int dsee_bicubic_down(const float* x, float* y, int N, int H, int W, int S, int cs_in, int cs_out, hipStream_t stream);
+/* Device input pipeline (replaces the PIL -> float CPU tensors of data/base_dataset.py:87-116,171-201):
+ * uint8 HWC images -> NHWC RGB0 fp32 with ToTensor + Normalize((.5,.5,.5),(.5,.5,.5)) and the per-sample horizontal
+ * flip (flip[n] != 0; NULL = none); uint8 label maps flipped the same way with 255 ('unknown') -> unknown_to. */
+int dsee_image_u8_to_nhwc(const uint8_t* img, const uint8_t* flip, float* out, int N, int H, int W, int cs_out,
+                          hipStream_t stream);
+int dsee_label_u8_prepare(const uint8_t* lab, const uint8_t* flip, uint8_t* out, int N, int H, int W, int unknown_to,
+                          hipStream_t stream);
 /* cat([input_semantics, image], dim=1) of sr_model.py:655-668 in NHWC, and the image part of its gradient */
 int dsee_build_d_input(const uint8_t* lab, const float* img, float* out, long pixels, int L, int Cs, int img_cs,
                        hipStream_t stream);
@@ -262,6 +291,10 @@ int dsee_rng_fill(float* out, long n, uint64_t seed, uint64_t offset, int normal
 size_t dsee_loss_workspace(void);
 int dsee_loss_fwd_bwd(int mode, const float* a, const float* b, float* grad, long rows, int ld, int valid_c,
                       float weight, float* loss_out, float* workspace, hipStream_t stream);
+/* backward alone for an arbitrary upstream gradient (device scalar, NULL = 1): grad = *upstream * weight * d mean / d a
+ * (the train step backpropagates sum(losses).mean(), trainer_manager.py:36-37, but a caller may re-weight a term) */
+int dsee_loss_bwd(int mode, const float* a, const float* b, float* grad, long rows, int ld, int valid_c, float weight,
+                  const float* upstream, hipStream_t stream);
 
 /* ------------------------------------------------------------------ spectral norm + Adam */
 int dsee_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* sigma, float* w_sn, int R, int K,
@@ -280,6 +313,12 @@ typedef struct dsee_adam_tensor {
 int dsee_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks, float beta1, float beta2,
                    float eps, float grad_scale, float clip, hipStream_t stream);
+/* the same on blocks [first_block, first_block + nblocks) only: one launch per all-reduced gradient chunk, so the
+ * update of chunk k overlaps the RCCL all-reduce of chunk k+1 (replaces the reduce-to-GPU0 + optimizer.step() of
+ * torch.nn.DataParallel, sync_batchnorm/replicate.py:50-94, trainer_manager.py:37-42) */
+int dsee_adam_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                         const dsee_adam_tensor* tensors, const int* block_tensor, int first_block, int nblocks,
+                         float beta1, float beta2, float eps, float grad_scale, float clip, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -373,6 +373,23 @@ def bicubic_down(img, size):
     return F.interpolate(img, (size, size), mode="bicubic").clamp(min=-1, max=1)
 
 
+def device_pipeline_reference(image_u8, label_u8, flip, label_nc):
+    """What the reference's loader hands the model for one uint8 sample pair (data/base_dataset.py:87-116,171-201 after
+    the PIL resize/crop): __flip(img, params['flip']) on both, transforms.ToTensor() (v / 255 as float32, HWC -> CHW),
+    transforms.Normalize((.5,.5,.5),(.5,.5,.5)) on the image; label = ToTensor(label) * 255.0 with 255 -> label_nc.
+    torchvision is absent from this image, so these three transforms are restated from their published definitions:
+    parity unpinned for this piece (the arithmetic is (v/255 - 0.5)/0.5 and a horizontal mirror).
+    image_u8 [N,H,W,3], label_u8 [N,H,W], flip [N] -> (image [N,3,H,W] f32, label [N,1,H,W] f32)."""
+    img = image_u8.float().div(255.0)
+    img = (img - 0.5) / 0.5
+    lab = label_u8.float().div(255.0) * 255.0
+    lab = torch.where(lab == 255, torch.full_like(lab, float(label_nc)), lab)
+    f = flip.bool()
+    img = torch.where(f[:, None, None, None], img.flip(2), img)
+    lab = torch.where(f[:, None, None], lab.flip(2), lab)
+    return img.permute(0, 3, 1, 2).contiguous(), lab[:, None].contiguous()
+
+
 def nearest_resize(x, size):
     """F.interpolate(mode='nearest'): src = floor(dst * in / out) (SURVEY B-3)."""
     return F.interpolate(x, size=size, mode="nearest")
@@ -391,6 +408,26 @@ def batch_norm_train(x, st, prefix, training):
         rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
         rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var.detach() * (m / max(m - 1, 1)))
     return (x - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS)
+
+
+def sync_bn_master(shards, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """The DataParallel branch of SynchronizedBatchNorm2d (sync_batchnorm/batchnorm.py:70-145) on a list of replica
+    inputs [n_r, C, H, W]: every replica sends (sum, ssum) to the master (:77-85), the master adds them
+    (ReduceAddCoalesced, :117) and computes mean = sum/size, sumvar = ssum - sum*mean, biased / unbiased variance,
+    running-stat momentum update with the UNBIASED variance, inv_std = clamp(bias_var, eps)^-1/2 (:128-145) --
+    clamp, not `+ eps` as F.batch_norm.  Returns (mean, inv_std, new_running_mean, new_running_var, outputs)."""
+    c = shards[0].shape[1]
+    size = sum(s.shape[0] * s.shape[2] * s.shape[3] for s in shards)
+    sum_ = sum(s.transpose(0, 1).reshape(c, -1).sum(1) for s in shards)
+    ssum = sum((s ** 2).transpose(0, 1).reshape(c, -1).sum(1) for s in shards)
+    mean = sum_ / size
+    sumvar = ssum - sum_ * mean
+    unbias_var, bias_var = sumvar / (size - 1), sumvar / size
+    rm = (1 - momentum) * running_mean + momentum * mean
+    rv = (1 - momentum) * running_var + momentum * unbias_var
+    inv_std = bias_var.clamp(eps) ** -0.5
+    outs = [(s - mean[None, :, None, None]) * inv_std[None, :, None, None] for s in shards]
+    return mean, inv_std, rm, rv, outs
 
 
 def instance_norm(x):
@@ -758,6 +795,24 @@ class Oracle:
         self.opt_D.step()
         self.d_losses = losses
         return losses
+
+    def update_learning_rate(self, epoch):
+        """trainer_manager.py:76-96: linear decay of lr after opt.niter epochs (one step of lr/niter_decay per call),
+        TTUR split lr_G = lr/2, lr_D = 2*lr unless no_TTUR; EVERY param group of both optimizers gets the new value
+        (the 'mini' encoder group loses its /4 at the first decay, as in the reference)."""
+        opt = self.opt
+        if self.opt_G is None:
+            self.create_optimizers()
+        if not hasattr(self, "old_lr"):
+            self.old_lr = opt.lr
+        new_lr = self.old_lr - opt.lr / opt.niter_decay if epoch > opt.niter else self.old_lr
+        if new_lr != self.old_lr:
+            lr_g, lr_d = (new_lr, new_lr) if opt.no_TTUR else (new_lr / 2, new_lr * 2)
+            for g in self.opt_D.param_groups:
+                g["lr"] = lr_d
+            for g in self.opt_G.param_groups:
+                g["lr"] = lr_g
+            self.old_lr = new_lr
 
     def inference(self, batch):
         """sr_model.py:85-91 — eval mode: running-stat BN, no SN iteration, no noise."""

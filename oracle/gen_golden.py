@@ -330,6 +330,63 @@ def layer_kats():
     print("layer_kats                       written")
 
 
+def host_logic():
+    """Pins of the host-side rows straight from the reference: (a15) per-tensor statistics of a freshly initialised
+    model (base_network.py:28-59 via networks/__init__.py:37-43), (a2) the learning-rate schedule of
+    TrainerManager.update_learning_rate (trainer_manager.py:76-96), (f4) the statistics the DataParallel branch of
+    SynchronizedBatchNorm2d computes from the replicas' (sum, ssum) (batchnorm.py:128-145, callable on the CPU)."""
+    from managers.trainer_manager import TrainerManager
+    from deepsee_models.networks.sync_batchnorm import SynchronizedBatchNorm2d
+    out = {"torch": torch.__version__}
+    # ---- init statistics
+    init = {}
+    for tag, over in (("indep_ngf8", dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8)),
+                      ("guided_kaiming_ngf8", dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8,
+                                                   netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True,
+                                                   init_type="kaiming"))):
+        torch.manual_seed(123)
+        opt = O.make_opt(**over)
+        tm = TrainerManager(ref_namespace(opt))
+        m = tm.sr_model_on_one_gpu
+        rec = {}
+        for net, mod in (("SR", m.netSR), ("D", m.netD), ("E", m.netE)):
+            for k, v in mod.state_dict().items():
+                v = v.detach().float()
+                rec["%s/%s" % (net, k)] = {"numel": v.numel(), "std": float(v.std()) if v.numel() > 1 else 0.0,
+                                           "mean": float(v.mean()), "norm": float(v.norm()),
+                                           "min": float(v.min()), "max": float(v.max())}
+        init[tag] = {"opt": over, "stats": rec}
+    out["init"] = init
+    # ---- learning-rate schedule
+    sched = {}
+    for tag, over in (("ttur", dict(niter=3, niter_decay=4)), ("no_ttur", dict(niter=2, niter_decay=2, no_TTUR=True))):
+        opt = O.make_opt(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=2, nef=4, ndf=4, **over)
+        tm = TrainerManager(ref_namespace(opt))
+        rows = []
+        for epoch in range(1, over["niter"] + over["niter_decay"] + 1):
+            tm.update_learning_rate(epoch)
+            rows.append({"epoch": epoch, "G": [g["lr"] for g in tm.optimizer_G.param_groups],
+                         "D": [g["lr"] for g in tm.optimizer_D.param_groups], "old_lr": tm.old_lr})
+        sched[tag] = {"opt": dict(over, lr=opt.lr), "rows": rows}
+    out["lr_schedule"] = sched
+    # ---- SyncBN master arithmetic on two replicas' sums (8 channels)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 8, 6, 6, generator=g) * torch.rand(1, 8, 1, 1, generator=g) * 3 + torch.randn(1, 8, 1, 1, generator=g)
+    x[:, 7] = 0.25                                    # constant channel: var 0 -> the clamp(var, eps) case
+    bn = SynchronizedBatchNorm2d(8, affine=False)
+    shards = [x[:2], x[2:]]
+    sum_ = sum(s.transpose(0, 1).reshape(8, -1).sum(1) for s in shards)
+    ssum = sum((s ** 2).transpose(0, 1).reshape(8, -1).sum(1) for s in shards)
+    mean, inv_std = bn._compute_mean_std(sum_, ssum, 4 * 36)
+    out["syncbn"] = {"x_seed": 77, "shards": 2, "mean": [float(v) for v in mean], "inv_std": [float(v) for v in inv_std],
+                     "running_mean": [float(v) for v in bn.running_mean],
+                     "running_var": [float(v) for v in bn.running_var],
+                     "x": [float(v) for v in x.reshape(-1)], "shape": list(x.shape)}
+    with open(os.path.join(ROOT, "tests", "golden", "host_logic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("host_logic                       written")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*")
@@ -345,6 +402,8 @@ def main():
         run_case(name, spec)
     if not a.cases or "layer_kats" in a.cases:
         layer_kats()
+    if not a.cases or "host_logic" in a.cases:
+        host_logic()
 
 
 if __name__ == "__main__":

@@ -37,6 +37,30 @@ def test_capi_library_loads_and_exports_header_symbols():
     assert rc == -1 and b"argument check failed" in so.dsee_last_error()
 
 
+def test_ctypes_prototypes_come_from_the_header():
+    """deepsee_amd.lib binds every entry point with the argtypes / restype parsed from include/deepsee_hip.h: a call with
+    the wrong arity, or a float where the header says int, raises instead of corrupting the stack; long / size_t /
+    uint64_t arguments are passed at their declared width."""
+    import ctypes as C
+    from deepsee_amd import lib as L
+    protos = L.header_prototypes()
+    so = L.lib()
+    assert len(protos) >= 75 and all(getattr(so, n).argtypes == a for n, (_, a) in protos.items())
+    assert protos["dsee_gemm_bf16x3_af32"][1][3] is C.c_long and protos["dsee_rng_fill"][1][2] is C.c_uint64
+    assert protos["dsee_conv2d_wgrad_workspace"][0] is C.c_size_t and protos["dsee_last_error"][0] is C.c_char_p
+    # a long that does not fit an int: truncated to 32 bits it would be M = 100 -> 2 partial rows instead of 1024
+    assert so.dsee_channel_dot_workspace(100, 512) == 2 * 512 * 4
+    assert so.dsee_channel_dot_workspace((1 << 33) + 100, 512) == 1024 * 512 * 4
+    with pytest.raises(TypeError):
+        so.dsee_conv_kpad(3, 3)
+    with pytest.raises(C.ArgumentError):
+        so.dsee_conv_kpad(3, 3, 1.5)
+    if not torch.cuda.is_available():
+        return
+    with pytest.raises(L.DseeError):
+        L.call("act_fwd", None, None, 4)                                          # arity checked before the call
+
+
 def test_product_refuses_to_run_without_gpu():
     from deepsee_amd.options import make_opt
     from deepsee_amd.sr_model import SRModel
@@ -101,6 +125,57 @@ def test_conv_geometry_and_packing_helpers():
                 assert idx[p + 32] == idx[p] + c
 
 
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_init_weights_statistics_match_reference():
+    """deepsee_amd.sr_model.init_weights on the build's parameter holders vs the per-tensor statistics of a
+    freshly initialised REFERENCE model (tests/golden/host_logic.json, written by oracle/gen_golden.py): xavier /
+    kaiming std of every conv weight incl. spectral-norm weight_orig, biases / noise weights / running_mean exactly 0,
+    running_var 1, alpha in [0,1), ||u|| = ||v|| = 1."""
+    import json
+    from deepsee_amd import networks as N
+    from deepsee_amd.options import make_opt
+    from deepsee_amd.sr_model import block_plan, init_weights
+    from tests.test_oracle_golden import check_init_stats
+    host = json.load(open(os.path.join(GOLD, "host_logic.json")))
+    for tag, rec in host["init"].items():
+        opt = make_opt(**rec["opt"])
+        gen = torch.Generator().manual_seed(17)
+        nets = {"SR": N.DeepSEESR(opt, block_plan(opt)), "D": N.MultiscaleDiscriminator(opt), "E": N.StyleEncoder(opt)}
+        for net in nets.values():
+            init_weights(net, opt.init_type, opt.init_variance, gen)
+        check_init_stats({"%s/%s" % (n, k): v for n, net in nets.items() for k, v in net.state_dict().items()},
+                         rec["stats"])
+
+
+def test_update_learning_rate_matches_reference_schedule():
+    """TrainerManager.update_learning_rate against the learning rates the REAL reference's TrainerManager set
+    on every param group at every epoch (tests/golden/host_logic.json; trainer_manager.py:76-96)."""
+    import json
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt
+    host = json.load(open(os.path.join(GOLD, "host_logic.json")))
+
+    class Opt:   # optimizer stand-in with the surface update_learning_rate touches
+        def __init__(self, lrs):
+            self.param_groups = [{"lr": lr} for lr in lrs]
+
+    for tag, rec in host["lr_schedule"].items():
+        over = {k: v for k, v in rec["opt"].items() if k != "lr"}
+        opt = make_opt(**over)
+        assert opt.lr == rec["opt"]["lr"]
+        tm = object.__new__(TrainerManager)
+        tm.opt, tm.old_lr = opt, opt.lr
+        lr_g, lr_d = (opt.lr, opt.lr) if opt.no_TTUR else (opt.lr / 2, opt.lr * 2)
+        tm.optimizer_G, tm.optimizer_D = Opt([lr_g, lr_g / 4]), Opt([lr_d])
+        for row in rec["rows"]:
+            tm.update_learning_rate(row["epoch"])
+            assert [g["lr"] for g in tm.optimizer_G.param_groups] == pytest.approx(row["G"], rel=1e-12, abs=1e-18)
+            assert [g["lr"] for g in tm.optimizer_D.param_groups] == pytest.approx(row["D"], rel=1e-12, abs=1e-18)
+            assert tm.old_lr == pytest.approx(row["old_lr"], rel=1e-12, abs=1e-18)
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -131,16 +206,209 @@ def test_data_parallel_grad_allreduce_gloo_world2():
     from deepsee_amd import parallel
     assert parallel.chunk_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
     assert parallel.chunk_bounds(8, 3)[0] == (0, 4)        # chunk sizes stay 16-byte aligned
+    assert _spawn(_dp_worker) == [(0, True), (1, True)]
+
+
+def _spawn(fn, world=2, timeout=180):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + ((os.getpid() * 7 + hash(fn.__name__)) % 2000)
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    return sorted(res)
+
+
+def _init_gloo(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    from deepsee_amd import parallel
+    r, _, w = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    return parallel
+
+
+def _flat_adam_worker(rank, world, port, q):
+    """Drives the REAL FlatAdam.step host logic (descriptor upload, `touched` MAX-reduce, block-aligned chunking,
+    per-chunk wait -> update, step bump, lr change) under gloo; only the Adam kernel launch itself is replaced by a torch
+    emulation reading the same device descriptors (the HIP kernel cannot run without a GPU)."""
+    import numpy as np
+    import torch.distributed as dist
+    parallel = _init_gloo(rank, world, port)
+    from deepsee_amd.optim import ADAM_DT, BLOCK, FlatAdam
+
+    class CpuAdam(FlatAdam):
+        launches = 0
+
+        def _launch(self, b0, b1, grad_scale, clip):
+            CpuAdam.launches += 1
+            desc = np.frombuffer(self.desc_dev.numpy().tobytes(), dtype=ADAM_DT)
+            bt = self.block_tensor.numpy()
+            b1_, b2_ = self.betas
+            for blk in range(b0, b1):
+                d = desc[bt[blk]]
+                if not d["active"]:
+                    continue
+                lo = int(d["offset"]) + (blk - int(d["first_block"])) * BLOCK
+                hi = min(int(d["offset"] + d["numel"]), lo + BLOCK)
+                step = int(d["step"]) + 1
+                g = self.grad[lo:hi] * grad_scale
+                if clip > 0:
+                    g = g.clamp(-clip, clip)
+                self.exp_avg[lo:hi].mul_(b1_).add_(g, alpha=1 - b1_)
+                self.exp_avg_sq[lo:hi].mul_(b2_).addcmul_(g, g, value=1 - b2_)
+                denom = self.exp_avg_sq[lo:hi].sqrt() / (1 - b2_ ** step) ** 0.5 + self.eps
+                self.flat[lo:hi].sub_(float(d["lr"]) / (1 - b1_ ** step) * self.exp_avg[lo:hi] / denom)
+
+    sizes = [(3000,), (5,), (32, 32), (2500,), (7,), (1100,)]
+    gen = torch.Generator().manual_seed(5)
+    init = [torch.randn(s, generator=gen) for s in sizes]
+    params = [torch.nn.Parameter(t.clone()) for t in init]
+    named = [("p%d" % i, p) for i, p in enumerate(params)]
+    opt = CpuAdam([{"params": named[:4], "lr": 1e-2}, {"params": named[4:], "lr": 2.5e-3}], betas=(0.5, 0.9))
+    opt.reduce_hook = parallel.GradAllReduce(world, chunk_mb=2000 * 4 / (1 << 20))       # ~2000 floats per chunk
+    ranges = opt.chunk_ranges(opt.reduce_hook.chunk_elems)
+    ok = len(ranges) >= 3 and ranges[0][2] == 0 and ranges[-1][3] == opt.total
+    ok = ok and all(a[3] == b[2] and a[1] == b[0] for a, b in zip(ranges, ranges[1:]))      # tile blocks and elements
+    # reference: plain torch Adam on the rank-averaged gradients, every tensor that ANY rank touched is active
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    ropt = torch.optim.Adam([{"params": ref[:4], "lr": 1e-2}, {"params": ref[4:], "lr": 2.5e-3}], betas=(0.5, 0.9))
+    for it in range(3):
+        coef = [[torch.randn(s, generator=torch.Generator().manual_seed(1000 * it + 10 * r + i))
+                 for i, s in enumerate(sizes)] for r in range(world)]
+        # tensor 3 gets a gradient on rank 0 only, tensor 4 on no rank in iteration 1 (skipped: its step must not advance)
+        def touched(r, i):
+            return not (i == 3 and r == 1) and not (i == 4 and it == 1)
+        opt.zero_grad()
+        sum((p * coef[rank][i]).sum() for i, p in enumerate(params) if touched(rank, i)).backward()
+        if it == 2:
+            opt.param_groups[0]["lr"] = 5e-3                                                   # update_learning_rate
+            ropt.param_groups[0]["lr"] = 5e-3
+        opt.step()
+        ropt.zero_grad()
+        for i, p in enumerate(ref):
+            gs = [coef[r][i] for r in range(world) if touched(r, i)]
+            p.grad = sum(gs) / world if gs else None
+        ropt.step()
+    err = max(float((p.detach() - r.detach()).abs().max()) for p, r in zip(params, ref))
+    steps = opt.steps().tolist()
+    ok = ok and err < 2e-6 and steps == [3, 3, 3, 3, 2, 3] and CpuAdam.launches == 3 * len(ranges)
+    # every rank ends with the same parameters
+    t = opt.flat.clone()
+    dist.all_reduce(t)
+    ok = ok and torch.allclose(t / world, opt.flat, atol=0, rtol=0)
+    q.put((rank, bool(ok), err, steps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adam_chunked_allreduce_gloo_world2():
+    res = _spawn(_flat_adam_worker)
+    assert [r[:2] for r in res] == [(0, True), (1, True)], res
+
+
+def _syncbn_worker(rank, world, port, q):
+    """SyncBN-over-RCCL protocol under gloo: the product's exchange functions (parallel.gather_stats,
+    parallel.allreduce_sums) around torch emulations of the three kernels (dsee_norm_stats_local, dsee_norm_stats_merge,
+    the dsee_modulate_bwd reduce/apply halves), against the oracle's restatement of the reference's DataParallel branch
+    on the concatenated batch (pinned to the reference by tests/golden/host_logic.json)."""
+    import torch.distributed as dist
+    parallel = _init_gloo(rank, world, port)
+    from oracle import deepsee_oracle as O
+    c, eps, mom = 8, 1e-5, 0.1
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(4, c, 6, 6, generator=g) * 3 + 1).double()
+    x[:, 7] = 0.25
+    shards = [x[:2], x[2:]]
+    mine = shards[rank]
+    # dsee_norm_stats_local: (mean, M2) of this rank's shard
+    flat = mine.transpose(0, 1).reshape(c, -1)
+    local = torch.stack([flat.mean(1), ((flat - flat.mean(1, keepdim=True)) ** 2).sum(1)])
+    rows = parallel.gather_stats(local, world)
+    ok = tuple(rows.shape) == (world, 2, c)
+    # dsee_norm_stats_merge: Chan's update in rank order, clamp(var, eps)
+    n = mean = m2 = 0.0
+    cnt = flat.shape[1]
+    for r in range(world):
+        d = rows[r, 0] - mean
+        nt = n + cnt
+        mean = mean + d * cnt / nt
+        m2 = m2 + rows[r, 1] + d * d * n * cnt / nt
+        n = nt
+    var = m2 / n
+    inv_std = var.clamp(min=eps) ** -0.5
+    rm, rv = mom * mean, (1 - mom) * 1.0 + mom * var * n / (n - 1)
+    xs = [s.clone().requires_grad_(True) for s in shards]
+    omean, oinv, orm, orv, outs = O.sync_bn_master(xs, torch.zeros(c).double(), torch.ones(c).double(), eps, mom)
+    for a, b in ((mean, omean), (inv_std, oinv), (rm, orm), (rv, orv)):
+        ok = ok and torch.allclose(a, b.detach(), rtol=1e-9, atol=1e-12)
+    # backward: sum d, sum d*xhat over the GLOBAL batch (allreduce_sums), dx = inv_std (d - S0/M - xhat S1/M)
+    R = [torch.randn(s.shape, generator=torch.Generator().manual_seed(9 + i)).double() for i, s in enumerate(shards)]
+    sum((o * r).sum() for o, r in zip(outs, R)).backward()
+    xhat = (mine - mean[None, :, None, None]) * inv_std[None, :, None, None]
+    d = R[rank]
+    sums = torch.stack([d.transpose(0, 1).reshape(c, -1).sum(1), (d * xhat).transpose(0, 1).reshape(c, -1).sum(1)])
+    parallel.allreduce_sums(sums, world)
+    m_tot = world * cnt
+    dx = inv_std[None, :, None, None] * (d - sums[0][None, :, None, None] / m_tot
+                                         - xhat * sums[1][None, :, None, None] / m_tot)
+    live = [ch for ch in range(c) if ch != 7]          # the clamped channel has no variance gradient in the reference
+    ok = ok and torch.allclose(dx[:, live], xs[rank].grad[:, live], rtol=1e-8, atol=1e-10)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_exchange_protocol_gloo_world2():
+    assert _spawn(_syncbn_worker) == [(0, True), (1, True)]
+
+
+def test_device_input_pipeline_host_side(tmp_path):
+    """SURVEY 8 f3, host half: datasets yield the uint8 wire format, FolderDataset pairs files by stem and applies the
+    reference's resize + crop (base_dataset.py:87-116,171-201), DeviceLoader shards an epoch disjointly over the ranks;
+    the oracle's restatement of ToTensor + Normalize + flip is what the HIP kernels are checked against on the GPU."""
+    import numpy as np
+    from PIL import Image
+    from deepsee_amd import data as D
+    from deepsee_amd.options import make_opt
+    opt = make_opt(start_size=4, crop_size=32, load_size=40, batchSize=2)
+    ds = D.SyntheticDataset(opt, length=10, seed=3)
+    s = ds[4]
+    assert s["label"].dtype == np.uint8 and s["label"].shape == (32, 32) and int(s["label"].max()) < opt.label_nc
+    assert s["image"].dtype == np.uint8 and s["image"].shape == (32, 32, 3) and s["flip"] in (0, 1)
+    assert np.array_equal(ds[4]["image"], s["image"])                      # deterministic per index
+    for d_ in ("lab", "img"):
+        os.makedirs(str(tmp_path / d_))
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        lab = rng.integers(0, 19, size=(48, 48), dtype=np.uint8)
+        lab[0, 0] = 255
+        Image.fromarray(lab).save(str(tmp_path / "lab" / ("%d.png" % k)))
+        Image.fromarray(rng.integers(0, 256, size=(48, 48, 3), dtype=np.uint8)).save(str(tmp_path / "img" / ("%d.png" % k)))
+    fd = D.FolderDataset(opt, str(tmp_path / "lab"), str(tmp_path / "img"), seed=1)
+    assert len(fd) == 3
+    it = fd[1]
+    assert it["label"].shape == (32, 32) and it["image"].shape == (32, 32, 3) and it["path"].endswith("1.png")
+    # the crop is the same window of the NEAREST-resized label and the BICUBIC-resized image
+    full = np.asarray(Image.open(str(tmp_path / "lab" / "1.png")).resize((40, 40), Image.NEAREST))
+    assert any(np.array_equal(it["label"], full[y:y + 32, x:x + 32]) for y in range(9) for x in range(9))
+    # sharding: two ranks, disjoint and equally long
+    l0 = D.DeviceLoader(ds, opt, shard=(0, 2), seed=5)
+    l1 = D.DeviceLoader(ds, opt, shard=(1, 2), seed=5)
+    i0, i1 = l0.indices(), l1.indices()
+    assert len(i0) == len(i1) == 5 and not set(i0) & set(i1) and len(l0) == 2
+    b = l0.collate([ds[i] for i in i0[:2]])
+    assert b["label"].dtype == torch.uint8 and tuple(b["image"].shape) == (2, 32, 32, 3) and b["flip"].dtype == torch.uint8
+    # oracle restatement of the device half (the GPU test compares the HIP kernels with exactly this)
+    img, lab = O.device_pipeline_reference(b["image"], b["label"], b["flip"], opt.label_nc)
+    assert tuple(img.shape) == (2, 3, 32, 32) and float(img.min()) >= -1.0 and float(img.max()) <= 1.0
+    k = int(torch.nonzero(b["flip"])[0]) if int(b["flip"].sum()) else None
+    if k is not None:
+        assert torch.equal(lab[k, 0], b["label"][k].flip(-1).float())
 
 
 def test_bf16x3_split_arithmetic_emulated_on_cpu():

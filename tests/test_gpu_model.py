@@ -25,10 +25,21 @@ CASES = {
                                  max_fm_size=64),
     "clip_nottur_4to32": dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8, add_noise=False,
                               no_TTUR=True, gradient_clip=0.01),
+    # the benchmark's geometry (32 -> 256, 5 resolutions) AND its batch size 8 -- BatchNorm over 8 images, per-image
+    # style-table groups x 8, the Winograd chunking of 8-image batches -- at 128 channels so the CPU oracle stays cheap
+    "indep_32to256_bs8_ngf8": dict(batchSize=8, ngf=8),
 }
 
 
-def run_case(over, seed, iters=1):
+def load_oracle_state(tm, orc):
+    """Copy the oracle's current parameters and buffers into the HIP model (same keys: checkpoint layout)."""
+    tm.sr_model.load_states({net: {k: v.detach().clone() for k, v in orc.S[net].items()} for net in ("SR", "D", "E")})
+
+
+def run_case(over, seed, iters=1, sync_before_d=True):
+    """One or more G+D iterations on both sides.  `sync_before_d`: after the G step the oracle's post-step state is
+    loaded into the HIP model, so the D step starts from IDENTICAL weights/buffers on both sides and its gradients can
+    be held tight (without it they inherit the +-lr sign-noise of the beta1 = 0 Adam step in between: 2e-2 .. 2e-1)."""
     from deepsee_amd import networks as N
     from deepsee_amd.managers import TrainerManager
     from deepsee_amd.options import make_opt
@@ -49,6 +60,10 @@ def run_case(over, seed, iters=1):
         gl, fake = orc.run_generator_one_step({k: v.clone() for k, v in batch.items()})
         ggrads = {"%s.%s" % (net, k): p.grad.clone() for net in ("SR", "E") for k, p in orc.params(net)
                   if p.grad is not None}
+
+        class _Snap:   # the oracle's state right after its G step (what load_oracle_state copies)
+            S = {net: {k: v.detach().clone() for k, v in orc.S[net].items()} for net in ("SR", "D", "E")}
+        orc_state_after_g = _Snap
         dl = orc.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
         dgrads = {"D." + k: p.grad.clone() for k, p in orc.params("D") if p.grad is not None}
         tm.sr_model.noise = N.ReplayNoise(ctl.tape[start:])
@@ -58,6 +73,10 @@ def run_case(over, seed, iters=1):
         touched_g = {nm for nm, t in zip(tm.optimizer_G.names, tm.optimizer_G.touched) if t}
         hgl = {k: float(v) for k, v in tm.g_losses.items()}
         hfake = tm.get_latest_generated().detach().cpu()
+        post_g = {net: {k: v.detach().cpu().clone() for k, v in getattr(tm.sr_model, "net" + net).state_dict().items()}
+                  for net in ("SR", "E")}
+        if sync_before_d:
+            load_oracle_state(tm, orc_state_after_g)
         tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
         torch.cuda.synchronize()
         hd = {nm: p.grad.detach().cpu().clone() for nm, p in zip(tm.optimizer_D.names, tm.optimizer_D.params)}
@@ -65,7 +84,7 @@ def run_case(over, seed, iters=1):
         assert tm.sr_model.noise.pos == len(tm.sr_model.noise.tape)
         out.append(dict(gl={k: float(v.detach()) for k, v in gl.items()}, fake=fake.detach(), ggrads=ggrads,
                         dl={k: float(v.detach()) for k, v in dl.items()}, dgrads=dgrads, hgl=hgl, hfake=hfake, hg=hg,
-                        hd=hd, hdl=hdl, touched_g=touched_g))
+                        hd=hd, hdl=hdl, touched_g=touched_g, post_g=post_g, orc_after_g=orc_state_after_g.S))
     return orc, tm, out
 
 
@@ -92,13 +111,15 @@ def test_train_step_matches_oracle(name):
     errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
                   for k, v in r["ggrads"].items())
     assert errs[len(errs) // 2] < 2e-2 and errs[-1] < 1e-1, (errs[len(errs) // 2], errs[-1])
+    # the D step started from the oracle's post-G-step state on both sides: losses and gradients are tight
     for k, v in r["dl"].items():
-        assert abs(r["hdl"][k] - v) <= 2e-3 * abs(v), (k, r["hdl"][k], v)
+        assert abs(r["hdl"][k] - v) <= 1e-4 * abs(v), (k, r["hdl"][k], v)
     dmax = max(float(v.norm()) for v in r["dgrads"].values())
     derrs = sorted(float((r["hd"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-2 * dmax)
                    for k, v in r["dgrads"].items())
-    assert derrs[-1] < 2e-1, derrs[-1]
-    # post-step state: parameters (Adam) and buffers (BN running stats twice, SN u/v twice)
+    assert derrs[-1] < 5e-3, derrs[-1]
+    # post-step state: parameters (Adam) and buffers (BN running stats twice, SN u/v twice).  G/E parameters are
+    # compared as they were right after the HIP G step (before the state sync), D and all buffers at the end.
     sd = {"SR": tm.sr_model.netSR.state_dict(), "D": tm.sr_model.netD.state_dict(), "E": tm.sr_model.netE.state_dict()}
     zero_grad = {k for k, v in {**r["ggrads"], **r["dgrads"]}.items() if float(v.norm()) < 1e-4 * max(gmax, dmax)}
     for net in ("SR", "D", "E"):
@@ -107,6 +128,8 @@ def test_train_step_matches_oracle(name):
             if not v.is_floating_point():
                 continue
             ref = orc.S[net][k].detach()
+            if net != "D" and not O.is_buffer(k):
+                v, ref = r["post_g"][net][k], r["orc_after_g"][net][k]
             if O.is_buffer(k):
                 assert rel(v.cpu(), ref) < 2e-3, (net, k)
             else:
@@ -141,23 +164,19 @@ def test_full_size_step_matches_oracle():
           % (dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
 
 
-@pytest.mark.parametrize("name", ["indep_8to64_ngf8", "guided_4to32_ngf8", "puresean_4to128_ngf4", "config1_4to32_full"])
-def test_smooth_loss_backward(name):
+def smooth_loss_errors(over, seed=555):
     """Backward parity with the sign-function losses taken out: L_G = <fake, R>, L_D = sum_k <D_k(cat[fake;real]), R_k>,
     L_V = sum_i <VGG_i(fake), R_i> with fixed random R.  Every HIP backward kernel of the path (SPADE/SEAN modulate,
-    BN, convs dgrad/wgrad, SN, noise, upsample, IN, pools, style pool/gather, one-hot conv) is exercised and compared
-    with the oracle in float64: per tensor the HIP error must stay below 2e-3 and its median over all tensors within 20x the CPU-fp32 oracle's own median
-    error (floor 1e-4; the MFMA accumulates each output in one fp32 chain over K, oneDNN in blocked partial sums) and
-    below 2e-3 absolutely."""
+    BN, convs dgrad/wgrad, SN, noise, upsample, IN, pools, style pool/gather, one-hot conv) is exercised.  Returns, per
+    parameter tensor, the relative error against the oracle run in FLOAT64 of: HIP, the fp32 oracle, and the fp32 oracle
+    with its input image scaled by (1 + pert), pert = HIP's own forward deviation (the conditioning yardstick)."""
     from deepsee_amd import networks as N, ops
     from deepsee_amd.managers import TrainerManager
     from deepsee_amd.options import make_opt
-    over = CASES[name]
     n = over["batchSize"]
     oopt = O.make_opt(**over)
     states = O.recipe_state(oopt, gain=1.0)
-    batch = O.synthetic_batch(oopt, n, seed=555)
-    gR = torch.Generator().manual_seed(9)
+    batch = O.synthetic_batch(oopt, n, seed=seed)
 
     def oracle_run(dtype, tape=None, pert=0.0):
         ctl = O.RecordingCtl() if tape is None else O.ReplayCtl(tape)
@@ -222,34 +241,99 @@ def test_smooth_loss_backward(name):
     pert = max(1e-6, dev)
     _, _, _, _, g32p, _ = oracle_run(torch.float32, ctl.tape, pert=pert)
     gmax = max(float(v.norm()) for v in g64.values())
-    worst, ehs, ecs, eps_ = (0.0, ""), [], [], []
+    rows = []
     for kk, v in g64.items():
         # alpha_gamma / alpha_beta (SEAN blend scalars) are differences of two ~1e6-term inner products in both
         # implementations (cancellation): judge them against 1 % of the largest gradient instead of their own size
         den = max(float(v.norm()), (1e-2 if v.numel() == 1 else 1e-3) * gmax)
-        eh = float((hg[kk].double() - v).norm()) / den
-        ehs.append(eh)
-        ecs.append(float((g32[kk].double() - v).norm()) / den)
-        eps_.append(float((g32p[kk].double() - v).norm()) / den)
-        worst = max(worst, (eh, kk))
-    ehs.sort()
-    ecs.sort()
-    eps_.sort()
-    med = lambda t: t[len(t) // 2]
+        rows.append((kk, float((hg[kk].double() - v).norm()) / den, float((g32[kk].double() - v).norm()) / den,
+                     float((g32p[kk].double() - v).norm()) / den))
+    return rows, dev, pert
+
+
+def _summ(rows):
+    med = lambda t: sorted(t)[len(t) // 2]
+    q90 = lambda t: sorted(t)[int(0.9 * (len(t) - 1))]
+    ehs, ecs, eps_ = [r[1] for r in rows], [r[2] for r in rows], [r[3] for r in rows]
+    return med, q90, ehs, ecs, eps_
+
+
+@pytest.mark.parametrize("name", ["indep_8to64_ngf8", "guided_4to32_ngf8", "puresean_4to128_ngf4", "config1_4to32_full"])
+def test_smooth_loss_backward(name):
+    """Small configurations: HIP must deviate from exact (float64) arithmetic no more than 3x what the fp32 oracle does
+    under a forward deviation of HIP's size (or 20x the unperturbed oracle) at the median and at the 90th percentile
+    over parameter tensors; the single worst tensor is decided by individual LeakyReLU/ReLU kink crossings at these
+    tiny resolutions (the perturbed oracle's own maximum moves 5e-4 .. 3e-3 between pert = 1.2e-6 and 1.4e-6), so it
+    only gets a cap of 3e-2 (real kernel bugs are O(1))."""
+    rows, dev, pert = smooth_loss_errors(CASES[name])
+    med, q90, ehs, ecs, eps_ = _summ(rows)
+    worst = max(rows, key=lambda r: r[1])
     print("fake deviation %.1e | HIP-vs-f64 grad error: median %.2e worst %.2e (%s) | oracle-f32: median %.2e max %.2e | "
           "oracle-f32 with %.1e input perturbation: median %.2e max %.2e"
-          % (dev, med(ehs), worst[0], worst[1], med(ecs), ecs[-1], pert, med(eps_), eps_[-1]))
-    # Gradients of this network are ill-conditioned in fp32 (LeakyReLU/ReLU kinks crossed within rounding flip and
-    # move a whole block's gradients together, a sqrt(forward deviation) effect): the fp32 ORACLE itself moves by
-    # median ~5e-4 / max ~2.5e-3 against float64 when its input changes by 1e-6.  HIP must deviate from exact
-    # arithmetic no more than 3x what the oracle does under a forward deviation of HIP's size (or 20x the unperturbed
-    # oracle) at the median and at the 90th percentile over parameter tensors.  The single worst tensor is decided by
-    # individual kink crossings (the perturbed oracle's own maximum moves 5e-4 .. 3e-3 between pert = 1.2e-6 and
-    # 1.4e-6), so it only gets a cap: 3e-2 (real kernel bugs are O(1)).
-    q90 = lambda t: t[int(0.9 * (len(t) - 1))]
-    assert ehs[-1] < 3e-2, (worst, eps_[-1], ecs[-1])
+          % (dev, med(ehs), worst[1], worst[0], med(ecs), max(ecs), pert, med(eps_), max(eps_)))
+    assert worst[1] < 3e-2, (worst, max(eps_), max(ecs))
     assert q90(ehs) <= max(3 * q90(eps_), 20 * q90(ecs), 1e-3), (q90(ehs), q90(eps_), q90(ecs))
     assert med(ehs) <= max(3 * med(eps_), 20 * med(ecs), 3e-4), (med(ehs), med(eps_), med(ecs))
+
+
+@pytest.mark.parametrize("name,over", [
+    ("config1_32to256_bs1", dict(batchSize=1)),                       # BASELINE configs[1] geometry, 512 channels
+    ("indep_32to256_bs8_ngf8", dict(batchSize=8, ngf=8)),             # the benchmark's batch size (128 channels)
+])
+def test_full_size_smooth_loss_backward(name, over):
+    """north_star's "gradients within 1e-3" at the BENCHMARK shapes (512 channels, 32 -> 256: the 256x256 / 256x160
+    bf16x3 GEMM tiles, per-image tables, Winograd transforms at 128^2 / 256^2; and bs = 8 at 128 channels): every
+    parameter-gradient tensor is compared with the oracle run in float64.  A tensor is well conditioned when the fp32
+    ORACLE itself, with its input perturbed by HIP's forward deviation, stays within 3e-4 of float64; every such tensor
+    must be within 1e-3 for HIP.  The others (kink-dominated: the oracle cannot hold them either) are reported and
+    capped at 10x the perturbed oracle's own error."""
+    rows, dev, pert = smooth_loss_errors(over, seed=777)
+    med, q90, ehs, ecs, eps_ = _summ(rows)
+    well = [r for r in rows if r[3] <= 3e-4]
+    ill = [r for r in rows if r[3] > 3e-4]
+    worst = max(well, key=lambda r: r[1])
+    print("%s: fake deviation %.1e | %d/%d tensors well conditioned: HIP median %.2e worst %.2e (%s); oracle-f32 median "
+          "%.2e | ill conditioned: %s"
+          % (name, dev, len(well), len(rows), med([r[1] for r in well]), worst[1], worst[0], med(ecs),
+             [(r[0], "%.1e vs %.1e" % (r[1], r[3])) for r in ill]))
+    assert len(well) >= 0.9 * len(rows), (len(well), len(rows))
+    assert worst[1] <= 1e-3, worst
+    for r in ill:
+        assert r[1] <= max(10 * r[3], 3e-2), r
+
+
+@pytest.mark.parametrize("name,over", [
+    # BASELINE configs[3]: guided 8x 32 -> 256 (full style encoder on a 256^2 guiding image: feature map [N,128,128,128])
+    ("guided_32to256", dict(batchSize=1, netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True)),
+    # BASELINE configs[4]: independent 32x 16 -> 512 (PureSEAN tail, max_fm_size 256 < 512: the capped path at 512^2)
+    ("indep_16to512", dict(batchSize=1, start_size=16, crop_size=512, load_size=512, add_noise=False)),
+])
+def test_full_size_forward_and_losses(name, over):
+    """Full-size forward parity of the two configurations the benchmark does not run: generator + discriminator + VGG
+    forward and the three generator losses at bs = 1 against the CPU oracle (forward only: no backward on the CPU)."""
+    from deepsee_amd import networks as N
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt
+    oopt = O.make_opt(**over)
+    states = O.recipe_state(oopt, gain=1.0)
+    batch = O.synthetic_batch(oopt, 1, seed=31)
+    ctl = O.RecordingCtl()
+    orc = O.Oracle(oopt, states, ctl)
+    random.seed(5)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        gl, fake = orc.generator_losses(orc.preprocess({k: v.clone() for k, v in batch.items()}))
+    tm = TrainerManager(make_opt(**over))
+    tm.sr_model.load_states(states)
+    tm.sr_model.noise = N.ReplayNoise(ctl.tape)
+    with torch.no_grad():
+        hgl, hfake = tm.sr_model(tm.preprocess_input({k: v.clone() for k, v in batch.items()}), mode="generator")
+    torch.cuda.synchronize()
+    dev = rel(hfake.cpu(), fake)
+    print("%s: |fake - oracle| / |oracle| = %.2e, losses %s" % (name, dev, {k: float(v) for k, v in hgl.items()}))
+    assert dev < 1e-4, dev
+    for k, v in gl.items():
+        assert abs(float(hgl[k]) - float(v)) <= 1e-4 * abs(float(v)), (k, float(hgl[k]), float(v))
 
 
 def test_inference_mode_matches_oracle():
@@ -296,3 +380,48 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
     tm2 = TrainerManager(make_opt(**dict(over, continue_train=True, seed=5)))
     for a, b in zip(tm.sr_model.netSR.state_dict().values(), tm2.sr_model.netSR.state_dict().values()):
         assert torch.equal(a, b)
+
+
+def test_data_parallel_path_on_one_gpu_nccl_world1():
+    """The multi-GPU code executed on the MI355X: a 1-rank RCCL process group, parallel.attach with
+    the collectives forced on -- rank-0 broadcast of parameters / buffers, MAX-reduce of the `touched` flags, chunked
+    asynchronous all-reduce of the flat gradient with one Adam launch per chunk, SyncBN's all-gather / all-reduce --
+    must reproduce the plain single-process step (world = 1: every collective is the identity)."""
+    import socket
+    import torch.distributed as dist
+    from deepsee_amd import networks as N, ops, parallel
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt
+    over = dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8)
+    batch = O.synthetic_batch(O.make_opt(**over), 2, seed=91)
+
+    def steps(tm):
+        out = []
+        for _ in range(2):
+            tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
+            tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
+            out.append({k: float(v) for k, v in tm.get_latest_losses().items()})
+        torch.cuda.synchronize()
+        return out, tm.optimizer_G.flat.detach().cpu().clone(), tm.optimizer_G.steps()
+
+    plain = steps(TrainerManager(make_opt(seed=3, **over)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        tm = TrainerManager(make_opt(seed=3, sync_bn=True, sync_bn_clamp=False, **over))
+        parallel.attach(tm, 1, chunk_mb=0.25, force=True)
+        assert tm.optimizer_G.reduce_hook.active and ops.SYNC_BN is not None
+        assert len(tm.optimizer_G.chunk_ranges(tm.optimizer_G.reduce_hook.chunk_elems)) > 4
+        dp = steps(tm)
+    finally:
+        ops.SYNC_BN = None
+        dist.destroy_process_group()
+    for a, b in zip(plain[0], dp[0]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-4 * abs(a[k]), (k, a[k], b[k])
+    assert plain[2].tolist() == dp[2].tolist()
+    # beta1 = 0 Adam: elements whose gradient is rounding noise may step the other way (2 steps x lr 1e-4)
+    assert float((plain[1] - dp[1]).abs().max()) <= 2.5 * 2e-4
+    assert float((plain[1] - dp[1]).abs().mean()) <= 2e-5

@@ -316,3 +316,136 @@ def test_rng_statistics():
     assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3
     z2 = ops.rng_fill((1 << 20,), 1234, 0, normal=True)
     assert torch.equal(z, z2)
+
+
+def test_loss_backward_honours_the_upstream_gradient():
+    """MeanLoss.backward scales with the upstream gradient (loss scaling, 1/k accumulation, re-weighted terms): the
+    gradient of 0.25 * L1 + 3 * hinge equals torch autograd's."""
+    from deepsee_amd import ops
+    g = gen(21)
+    x = torch.randn(2, 32, 5, 5, generator=g).requires_grad_()
+    y = torch.randn(2, 32, 5, 5, generator=g)
+    a = torch.randn(4, 1, 7, 7, generator=g).requires_grad_()
+    want = 0.25 * F.l1_loss(x, y) * 2.5 + 3.0 * O.Oracle.hinge([[a[2:]]], True, True)
+    want.backward()
+    xd, ad = nhwc(x.detach()).requires_grad_(), nhwc(a.detach()).requires_grad_()
+    got = (0.25 * ops.mean_loss(xd, nhwc(y), ops.MODE_L1, 2.5)
+           + 3.0 * ops.mean_loss(ad, None, ops.MODE_HINGE_REAL, 1.0, valid_c=1, lo=2, hi=4))
+    got.backward()
+    assert abs(float(got) - float(want)) < 1e-5
+    assert rel(nchw(xd.grad, 32), x.grad) < 1e-6 and rel(nchw(ad.grad, 1), a.grad) < 1e-6
+
+
+def test_flat_adam_matches_torch_adam_incl_skipped_tensors_and_lr_change():
+    """FlatAdam (device-resident descriptors, dsee_adam_step_range) vs torch.optim.Adam over 3 steps: a tensor without
+    gradient in one step is skipped (its step count does not advance), a param-group lr change reaches the device, clip
+    acts like clip_grad_value_."""
+    from deepsee_amd.optim import FlatAdam
+    sizes = [(3000,), (5,), (32, 32), (2500,), (7,), (1100,)]
+    g = gen(5)
+    init = [torch.randn(s, generator=g) for s in sizes]
+    params = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    named = [("p%d" % i, p) for i, p in enumerate(params)]
+    opt = FlatAdam([{"params": named[:4], "lr": 1e-2}, {"params": named[4:], "lr": 2.5e-3}], betas=(0.5, 0.9))
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    ropt = torch.optim.Adam([{"params": ref[:4], "lr": 1e-2}, {"params": ref[4:], "lr": 2.5e-3}], betas=(0.5, 0.9))
+    for it in range(3):
+        coef = [torch.randn(s, generator=gen(100 * it + i)) for i, s in enumerate(sizes)]
+        skip = {4} if it == 1 else set()
+        opt.zero_grad()
+        sum((p * coef[i].cuda()).sum() for i, p in enumerate(params) if i not in skip).backward()
+        if it == 2:
+            opt.param_groups[0]["lr"] = ropt.param_groups[0]["lr"] = 5e-3
+        # ranges instead of one launch: same result by construction, exercises first_block > 0
+        for b0, b1, _, _ in opt.chunk_ranges(2000):
+            pass
+        opt.step(clip=0.8)
+        ropt.zero_grad()
+        for i, p in enumerate(ref):
+            p.grad = None if i in skip else coef[i].clone().clamp(-0.8, 0.8)
+        ropt.step()
+    torch.cuda.synchronize()
+    for p, r in zip(params, ref):
+        assert float((p.detach().cpu() - r.detach()).abs().max()) < 2e-6
+    assert opt.steps().tolist() == [3, 3, 3, 3, 2, 3]
+
+
+def test_syncbn_kernels_two_shards_match_reference_dp_branch():
+    """SURVEY 8 f4 on the device: dsee_norm_stats_local on two shards -> rows stacked as the all-gather would ->
+    dsee_norm_stats_merge == the oracle's restatement of the reference's DataParallel branch (pinned by
+    tests/golden/host_logic.json) on the concatenated batch, incl. clamp(var, eps) on a constant channel and the
+    running statistics; the split backward (reduce -> summed sums -> apply) == autograd through that branch."""
+    import ctypes as C
+    from deepsee_amd import ops, lib as L
+    g = gen(31)
+    n, c, r = 4, 64, 16
+    x = torch.randn(n, c, r, r, generator=g) * (torch.rand(1, c, 1, 1, generator=g) * 3) + torch.randn(1, c, 1, 1, generator=g)
+    x[:, 5] = 0.25
+    shards = [x[:2], x[2:]]
+    xs = [s.clone().requires_grad_(True) for s in shards]
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    omean, oinv, orm, orv, outs = O.sync_bn_master(xs, rm0.clone(), rv0.clone())
+    rows = []
+    for s in shards:
+        sd = nhwc(s)
+        local = ops.new(2, c)
+        ws = ops.scratch(L.lib().dsee_norm_workspace(2, r * r, c, 1), "norm")
+        L.call("norm_stats_local", sd, 2, r * r, c, local, ws)
+        rows.append(local)
+    rows = torch.stack(rows)
+    mean, invstd, rm, rv = ops.new(c), ops.new(c), rm0.clone().cuda(), rv0.clone().cuda()
+    L.call("norm_stats_merge", rows, 2, 2 * r * r, c, 1e-5, 0.1, 1, mean, invstd, rm, rv)
+    assert rel(mean.cpu(), omean.detach()) < 1e-6 and rel(invstd.cpu(), oinv.detach()) < 1e-5
+    assert abs(float(invstd[5]) - 1e-5 ** -0.5) < 1e-1                      # clamp(var, eps), not var + eps
+    assert rel(rm.cpu(), orm.detach()) < 1e-6 and rel(rv.cpu(), orv.detach()) < 1e-5
+    # the F.batch_norm form on the same rows
+    L.call("norm_stats_merge", rows, 2, 2 * r * r, c, 1e-5, 0.1, 0, mean, invstd, None, None)
+    flat = x.transpose(0, 1).reshape(c, -1)
+    assert rel(invstd.cpu(), (flat.var(1, unbiased=False) + 1e-5) ** -0.5) < 1e-5
+    # ---- backward of h = lrelu(xhat * scale + beta) per shard with GLOBAL statistics
+    L.call("norm_stats_merge", rows, 2, 2 * r * r, c, 1e-5, 0.1, 1, mean, invstd, None, None)
+    scale = [torch.randn(s.shape, generator=g) for s in shards]
+    beta = [torch.randn(s.shape, generator=g) for s in shards]
+    R = [torch.randn(s.shape, generator=g) for s in shards]
+    hs = [F.leaky_relu(o * sc + b, 0.2) for o, sc, b in zip(outs, scale, beta)]
+    sum((h * rr).sum() for h, rr in zip(hs, R)).backward()
+    sums, keep = [], []
+    for s, sc, h, rr in zip(shards, scale, hs, R):
+        args = [nhwc(rr), nhwc(h.detach()), nhwc(s), nhwc(sc)]
+        dgb, sm = ops.new(2, r, r, 2 * c), ops.new(4, c)
+        ws = ops.scratch(L.lib().dsee_norm_workspace(2, r * r, c, 1), "norm")
+        L.call("modulate_bwd_reduce", *args, mean, invstd, dgb, 2 * c, sm, 2, r * r, c, 0.2, ws)
+        sums.append(sm)
+        keep.append(args)
+    tot = sums[0] + sums[1]                                                  # what parallel.allreduce_sums leaves
+    live = [ch for ch in range(c) if ch != 5]
+    for i, args in enumerate(keep):
+        dx = ops.new(2, r, r, c)
+        L.call("modulate_bwd_apply", *args, mean, invstd, tot, None, dx, 2, r * r, c, 1.0 / (4 * r * r), 0.2)
+        assert rel(nchw(dx, c)[:, live], xs[i].grad[:, live]) < 2e-5
+
+
+def test_device_input_pipeline_kernels_bit_exact():
+    """SURVEY 8 f3 on the device: uint8 image / label batches -> NHWC RGB0 fp32 + uint8 labels (ToTensor, Normalize,
+    flip, 255 -> label_nc) bit-exact against the oracle's restatement, then the manager path end to end."""
+    from deepsee_amd import data as D, ops
+    from deepsee_amd.managers import BaseManager
+    from deepsee_amd.options import make_opt
+    opt = make_opt(start_size=4, crop_size=32, load_size=32, batchSize=4)
+    ds = D.SyntheticDataset(opt, length=8, seed=2)
+    ld = D.DeviceLoader(ds, opt, batch_size=4, shuffle=False)
+    host = ld.collate([ds[i] for i in range(4)])
+    host["flip"] = torch.tensor([0, 1, 1, 0], dtype=torch.uint8)
+    host["label"][0, 0, :3] = 255
+    want_img, want_lab = O.device_pipeline_reference(host["image"], host["label"], host["flip"], opt.label_nc)
+    dev = D.device_preprocess(opt, host)
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(dev["image_hr"], 3), want_img)
+    assert torch.equal(dev["input_semantics"].t.cpu().float()[:, None], want_lab)
+    assert rel(nchw(dev["image_lr"], 3), O.bicubic_down(want_img, 4)) < 1e-6
+    mgr = BaseManager(opt, create_model=False)
+    again = mgr.preprocess(host, from_dataloader=True)                       # uint8 wire format through the manager
+    assert torch.equal(again["image_hr"], dev["image_hr"]) and mgr.preprocess(again, True) is again
+    batches = list(ld)                                                       # prefetching iterator: 2 batches of 4
+    assert len(batches) == 2 and tuple(batches[1]["image_hr"].shape) == (4, 32, 32, 4)
+    torch.cuda.synchronize()

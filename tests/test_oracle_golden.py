@@ -14,7 +14,7 @@ from oracle import deepsee_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "*.json"))
-               if not p.endswith("layer_kats.json"))
+               if not p.endswith(("layer_kats.json", "host_logic.json")))
 
 # Bounds: losses / outputs are tight; gradients are bounded by the reference's OWN noise floor
 # (oracle/noise_floor.py: a 1e-7 relative input perturbation moves G-step grads by 2.6e-3 and
@@ -143,3 +143,72 @@ def test_layer_kats():
     assert close(slice_of(O.bicubic_down(img, 4), 48), kats["bicubic"]["slice"], 1e-6)
     ap = F.avg_pool2d(img, 3, 2, [1, 1], count_include_pad=False)
     assert close(slice_of(ap, 32), kats["avgpool"]["slice"], 1e-6)
+
+
+# ------------------------------------------------------------------ host-logic rows pinned by gen_golden.host_logic()
+HOST = json.load(open(os.path.join(GOLD, "host_logic.json")))
+
+
+@pytest.mark.parametrize("tag", sorted(HOST["lr_schedule"]))
+def test_oracle_lr_schedule_matches_reference(tag):
+    """TrainerManager.update_learning_rate (trainer_manager.py:76-96): the reference's per-epoch learning rates of every
+    param group (recorded from the real TrainerManager) vs the oracle's restatement."""
+    rec = HOST["lr_schedule"][tag]
+    over = {k: v for k, v in rec["opt"].items() if k != "lr"}
+    opt = O.make_opt(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=2, nef=4, ndf=4, **over)
+    orc = O.Oracle(opt, O.init_state(opt))
+    orc.create_optimizers()
+    for row in rec["rows"]:
+        orc.update_learning_rate(row["epoch"])
+        assert [g["lr"] for g in orc.opt_G.param_groups] == pytest.approx(row["G"], rel=1e-12, abs=1e-18)
+        assert [g["lr"] for g in orc.opt_D.param_groups] == pytest.approx(row["D"], rel=1e-12, abs=1e-18)
+        assert orc.old_lr == pytest.approx(row["old_lr"], rel=1e-12, abs=1e-18)
+
+
+def test_oracle_syncbn_master_matches_reference():
+    """The DataParallel branch of SynchronizedBatchNorm2d (batchnorm.py:128-145) on two replicas: mean, clamp(var, eps)
+    inv_std (channel 7 is constant: var = 0 -> the clamp, not `+ eps`, decides) and the running statistics."""
+    rec = HOST["syncbn"]
+    x = torch.tensor(rec["x"]).reshape(rec["shape"])
+    c = x.shape[1]
+    mean, inv_std, rm, rv, _ = O.sync_bn_master([x[:2], x[2:]], torch.zeros(c), torch.ones(c))
+    assert close(mean, rec["mean"], 1e-6) and close(inv_std, rec["inv_std"], 1e-6)
+    assert close(rm, rec["running_mean"], 1e-6) and close(rv, rec["running_var"], 1e-6)
+    assert float(inv_std[7]) == pytest.approx(1e-5 ** -0.5, rel=1e-3)          # constant channel: clamp(0, eps)^-1/2
+    # clamp vs `+ eps` differ on small nonzero variances: var = eps/2 -> clamp gives eps^-1/2, `+eps` (1.5 eps)^-1/2
+    half = torch.full((1, 1, 2, 1), 0.0)
+    half[0, 0, 0, 0], half[0, 0, 1, 0] = (0.5e-5) ** 0.5, -((0.5e-5) ** 0.5)
+    _, inv, _, _, _ = O.sync_bn_master([half], torch.zeros(1), torch.ones(1))
+    assert float(inv[0]) == pytest.approx(1e-5 ** -0.5, rel=1e-4)
+
+
+@pytest.mark.parametrize("tag", sorted(HOST["init"]))
+def test_oracle_init_state_statistics_match_reference(tag):
+    """init_weights (base_network.py:28-59): per-tensor std / zero-ness / ranges of a freshly built reference model vs
+    the oracle's init_state (a different RNG stream: statistics, not values)."""
+    rec = HOST["init"][tag]
+    opt = O.make_opt(**rec["opt"])
+    st = O.init_state(opt, seed=5)
+    check_init_stats({"%s/%s" % (n, k): v for n in ("SR", "D", "E") for k, v in st[n].items()}, rec["stats"])
+
+
+def check_init_stats(tensors, stats):
+    assert set(tensors) == set(stats), set(tensors) ^ set(stats)
+    for k, ref in stats.items():
+        v = tensors[k].detach().float()
+        n = ref["numel"]
+        assert v.numel() == n, k
+        if ref["norm"] == 0.0:                                     # biases, noise weights, running_mean
+            assert float(v.abs().max()) == 0.0, k
+        elif k.endswith(("weight_u", "weight_v")):                 # normalised N(0,1) vectors
+            assert abs(float(v.norm()) - 1.0) < 1e-5 and abs(ref["norm"] - 1.0) < 1e-5, k
+        elif k.endswith("running_var"):
+            assert float(v.min()) == 1.0 == float(v.max()), k
+        elif k.endswith(("alpha_beta", "alpha_gamma")):            # U(0,1) scalars
+            assert 0.0 <= float(v) < 1.0 and 0.0 <= ref["min"] < 1.0, k
+        elif n >= 64:                                              # conv weights: N(0, std) with the reference's std
+            tol = 6.0 / (2.0 * n) ** 0.5 + 1e-3                    # 6 sigma of the sampling error of a std estimate, x2 sides
+            assert abs(float(v.std()) - ref["std"]) <= 2 * tol * ref["std"], (k, float(v.std()), ref["std"])
+            assert abs(float(v.mean())) <= 6.0 * ref["std"] / n ** 0.5 + 1e-9, k
+        else:
+            assert float(v.abs().max()) <= 8 * max(ref["std"], abs(ref["max"]), abs(ref["min"])) + 1e-9, k
