@@ -42,7 +42,13 @@ PMC_TRAFFIC_BYTES_PER_LAUNCH = {"winograd_gemm_bf16x3": 1.109e9}
 
 
 def kernel_peak(name):
-    return BF16_MFMA_PEAK_TFLOPS / 6.0 if "bf16x3" in name else FP32_MFMA_PEAK_TFLOPS
+    """fp32-equivalent peak of a kernel: an fp32 multiply-add costs 6 bf16 MFMA products (bf16x3), 3 fp16 MFMA products
+    (fp16x2, same MFMA rate) or one v_mfma_f32 product."""
+    if "bf16x3" in name:
+        return BF16_MFMA_PEAK_TFLOPS / 6.0
+    if "f16x2" in name:
+        return BF16_MFMA_PEAK_TFLOPS / 3.0
+    return FP32_MFMA_PEAK_TFLOPS
 N_PER_GPU = 8
 
 

@@ -1253,8 +1253,10 @@ size_t dsee_wino43_wgrad_workspace(long T, int Cin_s, int Cout_s) {
  *   dU[xi] = dM[xi]^T V[xi]  (36 reductions over the T tiles, one split-K MFMA launch),  dw = G^T dU G.
  * V  [36][T][Cin_s]  = dsee_wino43_input(x),  dM [36][T][Cout_s] = dsee_wino43_dout(dy);  T % 32 == 0. */
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw, long T,
-                      int Cin_s, int Cout_s, int Cout, int Cin, int split, hipStream_t st) {
+                      int Cin_s, int Cout_s, int Cout, int Cin, int split, const float* amax_v, const float* amax_dm,
+                      hipStream_t st) {
   DSEE_CHECK_ARG(V && dM && workspace && dw_oihw && T % 32 == 0 && Cin_s % 4 == 0 && Cout_s % 4 == 0);
+  DSEE_CHECK_ARG(split != 3 || (amax_v && amax_dm));
   DSEE_CHECK_ARG(Cout <= Cout_s && Cin <= Cin_s && 36 * T < (1L << 31));
   DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_workspace(T, Cin_s, Cout_s));
   if (split) {
@@ -1262,8 +1264,10 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
     DSEE_CHECK_ARG(Cout_s % 128 == 0 && Cin_s % 32 == 0);
     const int sper = wino_sper(T, Cin_s, Cout_s), Kpad = dsee_conv_kpad(1, 1, Cin_s);
     // split == 2: V / dM are the plain fp32 transforms, transposed + split inside the GEMM
-    int rc = split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st)
-                        : dsee_gemm_bf16x3_tn(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st);
+    // split == 3: the same with two-term fp16 splits (3 MFMA products), operand scales from max |dM|, max |V|
+    int rc = split == 3   ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
+             : split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st)
+                          : dsee_gemm_bf16x3_tn(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st);
     if (rc) return rc;
     const long total = (long)Cout * Cin;
     wino43_wgrad_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(workspace, dw_oihw, sper,
@@ -1297,16 +1301,19 @@ size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows) {
  * V [36][T][ca+32] = dsee_wino43_input(cat), dM [36][T][rows] = dsee_wino43_dout(dgb), tiles image-major (T/N each,
  * multiple of 32).  Writes dw2a [rows][ca][3][3] (NULL / ca == 0: skipped) and dtable [N][9][rows][32]. */
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
-                            float* dtable, long T, int N, int ca, int rows, int L, int split, hipStream_t st) {
+                            float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,
+                            const float* amax_dm, hipStream_t st) {
   DSEE_CHECK_ARG(V && dM && workspace && dtable && N > 0 && T % N == 0 && (T / N) % 32 == 0 && ca % 32 == 0);
+  DSEE_CHECK_ARG(split != 3 || (amax_v && amax_dm));
   DSEE_CHECK_ARG(rows % 4 == 0 && L <= 32 && 36 * T < (1L << 31));
   DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_table_workspace(T, N, ca, rows));
   const int ld = ca + 32;
   if (split) {
     DSEE_CHECK_ARG(rows % 128 == 0);
     const int sper = wino_sper(T / N, ld, rows, N), Kpad = dsee_conv_kpad(1, 1, ld);
-    int rc = split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st)
-                        : dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
+    int rc = split == 3   ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
+             : split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st)
+                          : dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
     if (rc) return rc;
     const long total = (long)rows * ld;
     wino43_wgrad_table_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(

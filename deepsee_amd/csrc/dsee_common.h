@@ -50,3 +50,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---- fp16x2 operand scaling (gemm_bf16x3.hip): power-of-two scale that maps max |x| = amax into [2^13, 2^14)
+// (amax = 0 / inf / nan: 1).  Used identically by the producers that pre-split an operand and by the GEMM kernels.
+__device__ __forceinline__ float dsee_pow2_scale(float amax) {
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);
+  if (e == 0 || e == 255) return 1.f;
+  int e2 = 267 - e;  // 127 + 14 - (e - 127) - 1
+  e2 = e2 < 1 ? 1 : (e2 > 254 ? 254 : e2);
+  return __builtin_bit_cast(float, (unsigned)e2 << 23);
+}
+
+// *amax = max(*amax, max over the wave of v) for v >= 0 (order independent -> deterministic); one atomic per wave
+__device__ __forceinline__ void dsee_wave_atomic_absmax(float* amax, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, v));
+}
+__device__ __forceinline__ float dsee_absmax4(const f32x4& v) {
+  return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}

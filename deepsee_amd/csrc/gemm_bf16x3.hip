@@ -27,6 +27,10 @@ struct Gemm3Args {
   const unsigned char* A;
   const unsigned char* B;
   float* C;
+  // fp16x2 kernels only: device scalars max |A|, max |B| (upper bounds are fine).  The power-of-two operand scales
+  // are dsee_pow2_scale(amax); a pre-split B operand was scaled by its producer with the same function of *amax_b.
+  const float* amax_a;
+  const float* amax_b;
   long M;      // rows of A (per z)
   int N, K;    // valid columns (= rows of B), reduction length per z (multiple of 16)
   int ldc;     // row stride of C
@@ -56,6 +60,79 @@ __device__ __forceinline__ void split3_dev(float x, unsigned short (&h)[3]) {
   h[2] = __builtin_bit_cast(unsigned short, b2);
 }
 
+// ---------------------------------------------------------------- fp16x2: two-term splits, three products
+// The same idea with HALF the matrix-core work: x' = s*x (s a power of two that brings max |x'| into [2^13, 2^14)),
+// x' ~= h0 + h1 with h0 = fp16(x'), h1 = fp16(x' - h0).  An fp16 term carries 11 significand bits, so the residual after
+// two terms is <= 2^-22 |x'|, rms 2^-24 -- the size of the rounding every fp32 FMA commits anyway -- (absolute floor
+// 2^-25 in scaled units = 2^-39 of the operand's largest element, where h1 goes subnormal), and
+//     a*b ~= (a1*b0 + a0*b1 + a0*b0) / (s_a s_b)            (dropped: a1*b1 <= 2^-22 |a||b|)
+// needs 3 instead of 6 MFMA products per 16 k's: 2516 / 3 = 839 TFLOP/s of fp32 work, and 4 instead of 6 bytes per
+// element of LDS image.  Every fp16 x fp16 product is exact in fp32; unlike bf16x3 the operand split is not exact, but its
+// error stays below the accumulator's: measured against float64 the result is as accurate as bf16x3 and as a CPU sgemm (tests/test_gpu_conv.py::test_gemm_f16x2_is_fp32_accurate; CPU emulation in
+// tests/test_cpu_host.py).  The scales are exact (powers of two) and are undone in the epilogue.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float pow2_scale(float amax) { return dsee_pow2_scale(amax); }
+
+// layout constants of the LDS / global split images for TERMS terms per value (chunk = 16 bytes = 8 k's of one term):
+// row r, chunk c sits at slot CH*r + c + pad(r); the dummy slots make every ds_read_b128 fragment read conflict free
+template <int TERMS>
+struct Img {
+  static constexpr int CH = 2 * TERMS;                              // chunks per row
+  static constexpr int ROWB = 32 * TERMS;                           // bytes per row in the global (dense) image
+  static constexpr int PERIOD = TERMS == 3 ? 97 : 17;               // slots per dummy period (16 rows + 1 | 4 rows + 1)
+  static constexpr int TSTEP = (32 * CH + (TERMS == 3 ? 2 : 8)) * 16;  // bytes between 32-row MFMA tiles
+  __host__ __device__ static constexpr int pad(int r) { return TERMS == 3 ? r >> 4 : r >> 2; }
+  __host__ __device__ static constexpr int slots(int rows) { return rows * CH + (TERMS == 3 ? rows / 16 : rows / 4); }
+};
+
+// 8 fp32 values -> TERMS 16-byte chunks (8 k's of each term)
+template <int TERMS>
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, u32x4 (&w)[TERMS]) {
+  if constexpr (TERMS == 3) {
+    unsigned short h[8][3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3_dev(v[e], h[e]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      w[p] = (u32x4){(unsigned)h[0][p] | ((unsigned)h[1][p] << 16), (unsigned)h[2][p] | ((unsigned)h[3][p] << 16),
+                     (unsigned)h[4][p] | ((unsigned)h[5][p] << 16), (unsigned)h[6][p] | ((unsigned)h[7][p] << 16)};
+  } else {
+    f16x8 h0, h1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = v[e] * scale;
+      h0[e] = (_Float16)x;
+      h1[e] = (_Float16)(x - (float)h0[e]);
+    }
+    w[0] = __builtin_bit_cast(u32x4, h0);
+    w[1] = __builtin_bit_cast(u32x4, h1);
+  }
+}
+
+// all products of one (A tile, B tile) pair for one 16-k slab, smallest terms first
+template <int TERMS>
+__device__ __forceinline__ void mfma_terms(const u32x4 (&af)[TERMS], const u32x4 (&bf)[TERMS], f32x16& acc) {
+  if constexpr (TERMS == 3) {
+    const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[0]), a1 = __builtin_bit_cast(bf16x8, af[1]),
+                 a2 = __builtin_bit_cast(bf16x8, af[2]);
+    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bf[0]), b1 = __builtin_bit_cast(bf16x8, bf[1]),
+                 b2 = __builtin_bit_cast(bf16x8, bf[2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+  } else {
+    const f16x8 a0 = __builtin_bit_cast(f16x8, af[0]), a1 = __builtin_bit_cast(f16x8, af[1]);
+    const f16x8 b0 = __builtin_bit_cast(f16x8, bf[0]), b1 = __builtin_bit_cast(f16x8, bf[1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------- pre-split operands, direct to LDS
 // FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `acc`, which is then folded into `tot`
 // (long reductions of the weight gradients: keeps the fp32 accumulation error at the blocked-sum level).
@@ -67,7 +144,7 @@ __device__ __forceinline__ void split3_dev(float x, unsigned short (&h)[3]) {
 // row r sits at slot 6r + c + (r >> 4), which makes every ds_read_b128 fragment read conflict-free
 // ((6r + (r>>4)) mod 16 is a bijection on each of the instruction's four 16-lane groups); the per-lane GLOBAL
 // offset skips the dummies instead (slot s -> chunk s - s/97).
-constexpr int region_slots(int rows) { return rows * 6 + rows / 16; }
+constexpr int region_slots(int rows) { return rows * 6 + rows / 16; }   // (= Img<3>::slots, declared further down)
 
 template <int WM, int WN, int MT, int NT, int FL>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_kernel(Gemm3Args a) {
@@ -254,16 +331,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
 // LDS-DMA as fp32 (64 B per row) into a 2-stage staging area; every wave converts the 32 rows it loaded itself (so only
 // its own vmcnt matters) into the bf16x3 LDS image one slab ahead of the MFMAs: lane = (row, k-half), 8 values ->
 // 3 x 8 bf16 -> the same 6r + c + (r>>4) slot layout the fragments are read from.  B (weights) stays pre-split.
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int TERMS>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   static_assert(BM / 16 == 2 * NW, "two fp32 A instructions (16 rows each) per wave");
-  constexpr int SA = region_slots(BM), SB = region_slots(BN);
+  constexpr int SA = I::slots(BM), SB = I::slots(BN);
   constexpr int NB = (SB + 63) / 64;
   constexpr int NIB = (NB + NW - 1) / NW;                // B instructions per wave per slab (last maybe absent)
   constexpr int F32_STAGE = BM * 64;                     // bytes of one fp32 A stage
-  constexpr int IMG = (SA * 16 + 255) / 256 * 256;       // bytes of one bf16x3 A image
+  constexpr int IMG = (SA * 16 + 255) / 256 * 256;       // bytes of one split A image
   constexpr int BST = NB * 1024;                         // bytes of one B stage
   constexpr int OFF_IMG = 2 * F32_STAGE, OFF_B = OFF_IMG + 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -281,6 +359,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
     bn = (int)(t % nbn);
     bm = t / nbn;
   };
+  // fp16x2: operand scales (exact powers of two), undone in the epilogue
+  float sa = 1.f, oscale = 1.f;
+  if constexpr (TERMS == 2) {
+    sa = pow2_scale(*a.amax_a);
+    oscale = 1.f / (sa * pow2_scale(*a.amax_b));
+  }
   const long arow = (long)a.K * 4;  // bytes per A row
   // A instruction jj (0,1) of this wave: rows 16*(wave + NW*jj) .. +15, lane -> (row l>>2, 16-byte chunk l&3)
   unsigned voffa[2], voffb[NIB];
@@ -289,7 +373,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 #pragma unroll
   for (int j = 0; j < NIB; ++j) {
     const int s = 64 * (wave + NW * j) + lane;
-    voffb[j] = (wave + NW * j < NB && s < SB && s % 97 != 96) ? (unsigned)((s - s / 97) * 16) : 0xFFFFFFF0u;
+    voffb[j] = (wave + NW * j < NB && s < SB && s % I::PERIOD != I::PERIOD - 1) ? (unsigned)((s - s / I::PERIOD) * 16)
+                                                                                  : 0xFFFFFFF0u;
   }
   const bool has_last = wave + NW * (NIB - 1) < NB;  // wave-uniform
   const int nk = a.K / 16;
@@ -305,8 +390,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
     decode(live ? lt : (long)blockIdx.x, z, bm, bn);
     const long group = (bm * BM) / a.rows_per_group;
     pa = uniform_ptr(a.A + bm * BM * arow);
-    pb = uniform_ptr(a.B + group * a.b_group_bytes + (long)bn * BN * 96);
-    bvalid = __builtin_amdgcn_readfirstlane(live ? min(BN, a.N - bn * BN) * 96 : 0);
+    pb = uniform_ptr(a.B + group * a.b_group_bytes + (long)bn * BN * I::ROWB);
+    bvalid = __builtin_amdgcn_readfirstlane(live ? min(BN, a.N - bn * BN) * I::ROWB : 0);
     avalid = __builtin_amdgcn_readfirstlane(live ? (int)min((long)BM * arow, 0x7FFFFFFFL) : 0);
   };
   auto issue = [&](int fstage, int bstage) {
@@ -332,23 +417,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   // conversion of this wave's 32 rows of fp32 stage `fstage` into image `img`: lane = (instruction jj = lane>>5, row
   // (lane&31)>>1 of its 16, k-half lane&1)
   const int crow = 16 * (wave + NW * (lane >> 5)) + ((lane & 31) >> 1), ckh = lane & 1;
-  const unsigned csrc = (unsigned)(crow * 64 + ckh * 32), cdst = (unsigned)((6 * crow + (crow >> 4) + ckh) * 16);
+  const unsigned csrc = (unsigned)(crow * 64 + ckh * 32);
+  const unsigned cdst = (unsigned)((I::CH * crow + I::pad(crow) + ckh) * 16);
   auto convert = [&](int fstage, int img) {
     const unsigned char* f = smem + fstage * F32_STAGE + csrc;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(f), v1 = *reinterpret_cast<const f32x4*>(f + 16);
-    unsigned short h[8][3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      split3_dev(v0[e], h[e]);
-      split3_dev(v1[e], h[4 + e]);
-    }
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    u32x4 w[TERMS];
+    split8<TERMS>(v, sa, w);
     unsigned char* d = smem + OFF_IMG + img * IMG + cdst;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const u32x4 w = {(unsigned)h[0][p] | ((unsigned)h[1][p] << 16), (unsigned)h[2][p] | ((unsigned)h[3][p] << 16),
-                       (unsigned)h[4][p] | ((unsigned)h[5][p] << 16), (unsigned)h[6][p] | ((unsigned)h[7][p] << 16)};
-      *reinterpret_cast<u32x4*>(d + p * 32) = w;
-    }
+    for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
   };
   auto wait_own = [&]() {  // everything but this wave's newest slab has landed
     if (has_last)
@@ -366,9 +445,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int r0 = wm * MT * 32 + (lane & 31), rb0 = wn * NT * 32 + (lane & 31);
-  const unsigned fa = (unsigned)((6 * r0 + (r0 >> 4) + (lane >> 5)) * 16);
-  const unsigned fb = (unsigned)((6 * rb0 + (rb0 >> 4) + (lane >> 5)) * 16);
-  constexpr int TSTEP = 194 * 16;
+  const unsigned fa = (unsigned)((I::CH * r0 + I::pad(r0) + (lane >> 5)) * 16);
+  const unsigned fb = (unsigned)((I::CH * rb0 + I::pad(rb0) + (lane >> 5)) * 16);
+  constexpr int TSTEP = I::TSTEP;
 
   load_base();
   issue(0, 0);
@@ -384,30 +463,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
     asm volatile("" ::: "memory");
     const unsigned char* sa_ = smem + OFF_IMG + par * IMG;
     const unsigned char* sb = smem + OFF_B + bcur * BST;
-    bf16x8 af[MT][3];
+    u32x4 af[MT][TERMS];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(sa_ + fa + i * TSTEP + p * 32);
+      for (int p = 0; p < TERMS; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      bf16x8 bf[3];
+      u32x4 bf[TERMS];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * TSTEP + p * 32);
+      for (int p = 0; p < TERMS; ++p) bf[p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
       if (j == 0) {
         __builtin_amdgcn_sched_barrier(0);
         issue(par, bnxt);  // fp32 stage `par` was converted one iteration ago (by this wave); B stage bnxt is free
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][j], 0, 0, 0);
-      }
+      for (int i = 0; i < MT; ++i) mfma_terms<TERMS>(af[i], bf, acc[i][j]);
     }
     // next slab: its fp32 rows (this wave's own) and B chunks have been in flight for a whole iteration
     __builtin_amdgcn_sched_barrier(0);
@@ -432,7 +504,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
           const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
           if (n < a.N)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[i][j][r];
+              if constexpr (TERMS == 2) v *= oscale;
+              cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = v;
+            }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
@@ -452,16 +528,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 // pass already computed) left in fp32 in HBM.  A slab is 16 tiles; every wave DMAs, for all 16 of them, the 32 P
 // columns / RB Q columns it owns (whole 128-byte / RB*4-byte pieces) and transposes + splits them itself into the
 // bf16x3 images (rows = channels, 16 t contiguous), again one slab ahead of the MFMAs and with no barrier of its own.
-template <int WM, int WN, int MT, int NT, int FL>
+template <int WM, int WN, int MT, int NT, int FL, int TERMS>
 __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   static_assert(BM == 32 * NW, "every wave owns 32 rows of the P tile");
   constexpr int RB = BN / NW;                       // Q rows (channels) owned by a wave
   static_assert(BN % NW == 0 && RB % 4 == 0 && 2 * RB <= 64, "Q rows per wave");
   constexpr int QCH = RB / 4;                       // 16-byte chunks per tile row of a wave's Q piece
   constexpr int QI = (16 * QCH + 63) / 64;          // Q DMA instructions per wave per slab
-  constexpr int SA = region_slots(BM), SB = region_slots(BN);
+  constexpr int SA = I::slots(BM), SB = I::slots(BN);
   constexpr int IMGA = (SA * 16 + 255) / 256 * 256, IMGB = (SB * 16 + 255) / 256 * 256;
   constexpr int FA = NW * 2048, FB = NW * QI * 1024;  // bytes of one fp32 stage (P, Q)
   constexpr int OFF_FB = 2 * FA, OFF_IA = OFF_FB + 2 * FB, OFF_IB = OFF_IA + 2 * IMGA;
@@ -480,6 +557,12 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     bn = (int)(t % nbn);
     bm = t / nbn;
   };
+  float sp = 1.f, sq = 1.f, oscale = 1.f;   // fp16x2: operand scales (exact powers of two), undone in the epilogue
+  if constexpr (TERMS == 2) {
+    sp = pow2_scale(*a.amax_a);
+    sq = pow2_scale(*a.amax_b);
+    oscale = 1.f / (sp * sq);
+  }
   const long lda = (long)a.M * 4, ldb = (long)a.N * 4;  // bytes per tile row of P / Q
   // P instruction jj: tiles 8jj .. 8jj+7 of the slab, lane -> (tile l>>3, 16-byte chunk l&7 of the wave's 128 bytes)
   unsigned voffa[2], voffb[QI];
@@ -526,24 +609,23 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
       load_base();
     }
   };
-  // transpose + split of this wave's pieces: item = (channel, tile half); 8 tiles of one channel -> 3 x 8 bf16
-  auto conv_item = [&](const unsigned char* f, int stride, int ch, int th, unsigned char* img, int row) {
-    unsigned short h[8][3];
+  // transpose + split of this wave's pieces: item = (channel, tile half); 8 tiles of one channel -> TERMS x 8 halves
+  auto conv_item = [&](const unsigned char* f, int stride, int ch, int th, unsigned char* img, int row, float sc) {
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) split3_dev(*reinterpret_cast<const float*>(f + (8 * th + j) * stride + ch * 4), h[j]);
-    unsigned char* d = img + (6 * row + (row >> 4) + th) * 16;
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(f + (8 * th + j) * stride + ch * 4);
+    u32x4 w[TERMS];
+    split8<TERMS>(v, sc, w);
+    unsigned char* d = img + (I::CH * row + I::pad(row) + th) * 16;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const u32x4 w = {(unsigned)h[0][p] | ((unsigned)h[1][p] << 16), (unsigned)h[2][p] | ((unsigned)h[3][p] << 16),
-                       (unsigned)h[4][p] | ((unsigned)h[5][p] << 16), (unsigned)h[6][p] | ((unsigned)h[7][p] << 16)};
-      *reinterpret_cast<u32x4*>(d + p * 32) = w;
-    }
+    for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
   };
   auto convert = [&](int fs, int im) {
-    conv_item(smem + fs * FA + wave * 2048, 128, lane >> 1, lane & 1, smem + OFF_IA + im * IMGA, 32 * wave + (lane >> 1));
+    conv_item(smem + fs * FA + wave * 2048, 128, lane >> 1, lane & 1, smem + OFF_IA + im * IMGA, 32 * wave + (lane >> 1),
+              sp);
     if (lane < 2 * RB)
       conv_item(smem + OFF_FB + fs * FB + wave * QI * 1024, RB * 4, lane >> 1, lane & 1, smem + OFF_IB + im * IMGB,
-                RB * wave + (lane >> 1));
+                RB * wave + (lane >> 1), sq);
   };
 
   f32x16 acc[MT][NT], tot[FL > 0 ? MT : 1][FL > 0 ? NT : 1];
@@ -557,9 +639,9 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
         if constexpr (FL > 0) tot[i][j][r] = 0.f;
       }
   const int r0 = wm * MT * 32 + (lane & 31), rb0 = wn * NT * 32 + (lane & 31);
-  const unsigned fa = (unsigned)((6 * r0 + (r0 >> 4) + (lane >> 5)) * 16);
-  const unsigned fb = (unsigned)((6 * rb0 + (rb0 >> 4) + (lane >> 5)) * 16);
-  constexpr int TSTEP = 194 * 16;
+  const unsigned fa = (unsigned)((I::CH * r0 + I::pad(r0) + (lane >> 5)) * 16);
+  const unsigned fb = (unsigned)((I::CH * rb0 + I::pad(rb0) + (lane >> 5)) * 16);
+  constexpr int TSTEP = I::TSTEP;
 
   load_base();
   issue(0);
@@ -574,30 +656,23 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     asm volatile("" ::: "memory");
     const unsigned char* sa_ = smem + OFF_IA + par * IMGA;
     const unsigned char* sb = smem + OFF_IB + par * IMGB;
-    bf16x8 af[MT][3];
+    u32x4 af[MT][TERMS];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(sa_ + fa + i * TSTEP + p * 32);
+      for (int p = 0; p < TERMS; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      bf16x8 bf[3];
+      u32x4 bf[TERMS];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(sb + fb + j * TSTEP + p * 32);
+      for (int p = 0; p < TERMS; ++p) bf[p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
       if (j == 0) {
         __builtin_amdgcn_sched_barrier(0);
         issue(par);  // fp32 stage `par` was converted one iteration ago by this wave
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][j], 0, 0, 0);
-      }
+      for (int i = 0; i < MT; ++i) mfma_terms<TERMS>(af[i], bf, acc[i][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI) : "memory");
@@ -630,7 +705,11 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
           const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
           f32x16& d = FL > 0 ? tot[FL > 0 ? i : 0][FL > 0 ? j : 0] : acc[i][j];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = d[r];
+          for (int r = 0; r < 16; ++r) {
+            float v = d[r];
+            if constexpr (TERMS == 2) v *= oscale;
+            cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = v;
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) d[r] = 0.f;
         }
@@ -675,41 +754,43 @@ int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int TERMS>
 int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
+  using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  constexpr int NB = (region_slots(BN) + 63) / 64;
-  constexpr int IMG = (region_slots(BM) * 16 + 255) / 256 * 256;
+  constexpr int NB = (I::slots(BN) + 63) / 64;
+  constexpr int IMG = (I::slots(BM) * 16 + 255) / 256 * 256;
   const size_t lds = (size_t)2 * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN);
   const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);
-  gemm3a_kernel<WM, WN, MT, NT><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
+  gemm3a_kernel<WM, WN, MT, NT, TERMS><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int FL>
+template <int WM, int WN, int MT, int NT, int FL, int TERMS>
 int launch_gemm3t(Gemm3Args a, int nz, hipStream_t st) {
+  using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   constexpr int QI = (16 * (BN / NW / 4) + 63) / 64;
-  constexpr int IMGA = (region_slots(BM) * 16 + 255) / 256 * 256, IMGB = (region_slots(BN) * 16 + 255) / 256 * 256;
+  constexpr int IMGA = (I::slots(BM) * 16 + 255) / 256 * 256, IMGB = (I::slots(BN) * 16 + 255) / 256 * 256;
   const size_t lds = (size_t)2 * NW * 2048 + (size_t)2 * NW * QI * 1024 + 2 * IMGA + 2 * IMGB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL, TERMS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   a.nz = nz;
   const long ntile = (a.M / BM) * (a.N / BN) * nz;
   const long slots = gemm3_num_cus();
-  gemm3t_kernel<WM, WN, MT, NT, FL><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
+  gemm3t_kernel<WM, WN, MT, NT, FL, TERMS><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -776,9 +857,31 @@ int dsee_gemm_bf16x3_af32(const float* A, const void* B3, float* C, long M, int 
   if (tile == 0) tile = (big_ok && (M / 256) * (N / 256) >= 512) ? 2 : 1;
   if (tile == 2) {
     DSEE_CHECK_ARG(big_ok);
-    return launch_gemm3a<2, 4, 4, 2>(a, st);
+    return launch_gemm3a<2, 4, 4, 2, 3>(a, st);
   }
-  return launch_gemm3a<2, 2, 2, 2>(a, st);
+  return launch_gemm3a<2, 2, 2, 2, 3>(a, st);
+}
+
+/* The fp16x2 form of dsee_gemm_bf16x3_af32 (half the matrix-core work, see the top of gemm_bf16x3.hip): A [M][K] fp32,
+ * split into two fp16 terms inside the kernel after scaling by dsee_pow2_scale(*amax_a) (device scalar: max |A|,
+ * written by the producer of A); B2 [groups][K/16][b_rows][2][16] fp16 pre-split by its producer after scaling by
+ * dsee_pow2_scale(*amax_b).  The scales are powers of two: C = A B^T is rescaled exactly. */
+int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                         int tile, const float* amax_a, const float* amax_b, hipStream_t st) {
+  DSEE_CHECK_ARG(A && B2 && C && amax_a && amax_b && M > 0 && N > 0 && K > 0 && K % 16 == 0 && N % 128 == 0 && M % 128 == 0);
+  DSEE_CHECK_ARG(rows_per_group % 128 == 0 && M % rows_per_group == 0 && b_rows >= N && (long)K * 4 * 256 < 0x7FFFFFFFL);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)A; a.B = (const unsigned char*)B2; a.C = C;
+  a.amax_a = amax_a; a.amax_b = amax_b;
+  a.M = M; a.N = N; a.K = K; a.ldc = N; a.rows_per_group = rows_per_group;
+  a.b_group_bytes = (long)b_rows * K * 4; a.b_slab_bytes = (long)b_rows * 64; a.nz = 1;
+  const bool big_ok = rows_per_group % 256 == 0 && N % 256 == 0;
+  if (tile == 0) tile = (big_ok && (M / 256) * (N / 256) >= 512) ? 2 : 1;
+  if (tile == 2) {
+    DSEE_CHECK_ARG(big_ok);
+    return launch_gemm3a<2, 4, 4, 2, 2>(a, st);
+  }
+  return launch_gemm3a<2, 2, 2, 2, 2>(a, st);
 }
 
 /* dsee_gemm_bf16x3_tn with both operands left in fp32: P [groups*T][rows_p], Q [groups*T][rows_q] fp32 row-major (the
@@ -795,8 +898,26 @@ int dsee_gemm_bf16x3_tn_f32(const float* P, const float* Q, float* C, int groups
   a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p;
   a.a_slab_bytes = (long)16 * rows_p * 4; a.b_slab_bytes = (long)16 * rows_q * 4;
   a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
-  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16>(a, groups * splits, st);
-  return launch_gemm3t<4, 2, 2, 2, 16>(a, groups * splits, st);
+  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 3>(a, groups * splits, st);
+  return launch_gemm3t<4, 2, 2, 2, 16, 3>(a, groups * splits, st);
+}
+
+/* fp16x2 form of dsee_gemm_bf16x3_tn_f32: both fp32 operands are transposed, scaled (powers of two from the device
+ * scalars *amax_p = max |P|, *amax_q = max |Q|) and split into two fp16 terms inside the kernel. */
+int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                           int splits, const float* amax_p, const float* amax_q, hipStream_t st) {
+  DSEE_CHECK_ARG(P && Q && C && amax_p && amax_q && groups > 0 && T % 16 == 0 && rows_p % 256 == 0 && splits > 0);
+  DSEE_CHECK_ARG((T / 16) % splits == 0 && ldc >= rows_q && (rows_q == 160 || rows_q % 128 == 0));
+  DSEE_CHECK_ARG((long)rows_p * 64 < 0x7FFFFFFFL && (long)rows_q * 64 < 0x7FFFFFFFL);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)P; a.B = (const unsigned char*)Q; a.C = C;
+  a.amax_a = amax_p; a.amax_b = amax_q;
+  const long nk = T / 16 / splits;
+  a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p;
+  a.a_slab_bytes = (long)16 * rows_p * 4; a.b_slab_bytes = (long)16 * rows_q * 4;
+  a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
+  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 2>(a, groups * splits, st);
+  return launch_gemm3t<4, 2, 2, 2, 16, 2>(a, groups * splits, st);
 }
 
 }  // extern "C"

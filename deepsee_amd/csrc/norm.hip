@@ -281,6 +281,108 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
   }
 }
 
+// A d : 4 -> 6 (winograd.hip: adjoint of the output transform)
+__device__ __forceinline__ void a6n(const f32x4 (&d)[4], f32x4 (&o)[6]) {
+  const f32x4 s02 = d[0] + d[2], s13 = d[1] + d[3], t02 = d[0] + 4.f * d[2], t13 = 2.f * d[1] + 8.f * d[3];
+  o[0] = d[0];
+  o[1] = s02 + s13;
+  o[2] = s02 - s13;
+  o[3] = t02 + t13;
+  o[4] = t02 - t13;
+  o[5] = d[3];
+}
+
+// 4x4 tile of one channel quad -> its 36 Winograd-domain values A v A^T, stored at dM[xi][t][col..col+3]
+__device__ __forceinline__ float store_ata(const f32x4 (&v)[4][4], float* __restrict__ dM, long T, long t, int ld,
+                                           int col) {
+  float vmax = 0.f;
+  f32x4 tmp[6][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 c4[4], o[6];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c4[k] = v[k][j];
+    a6n(c4, o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    f32x4 o[6];
+    a6n(tmp[k], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * ld + col) = o[j];
+      vmax = fmaxf(vmax, dsee_absmax4(o[j]));
+    }
+  }
+  return vmax;
+}
+
+// Pass 1 of the BN + modulate + LeakyReLU backward with the gamma/beta gradient written straight in the Winograd
+// domain: dM[xi][tile][packed gamma col] = (A (g*xhat) A^T)[xi], [packed beta col] = (A g A^T)[xi] -- the operand of the
+// weight / table gradient AND (adjoint form) of the embedding's data gradient; the [M][2C] tensor dgb and the separate
+// A . A^T pass over it never exist.  Thread = (4x4 tile, channel quad); per-channel sums as in norm_bwd_reduce_kernel<1>
+// (one partial row per block, folded in block order by sums_finalize_kernel).  Needs 256 % (C/4) == 0.
+__global__ __launch_bounds__(256) void norm_bwd_reduce_wino_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dM, int rows, float* __restrict__ part, int N, int H, int W, int C, float slope,
+    float* __restrict__ amax) {
+  __shared__ f32x4 red[4 * 256];
+  float vmax = 0.f;
+  const int C4 = C / 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = T * C4;
+  const int q = threadIdx.x % C4, c0 = q * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
+  const int pcol = (c0 >> 6) * 128 + ((c0 >> 5) & 1) * 64 + (c0 & 31);
+  f32x4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i / C4;  // (i % C4 == q: gridDim.x * 256 is a multiple of C4)
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    f32x4 gg[4][4], gx[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t o = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + c0;
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = dv[e] * (yv[e] > 0.f ? 1.f : slope);
+        const f32x4 d = g * *reinterpret_cast<const f32x4*>(scale + o);
+        gg[k][j] = g;
+        gx[k][j] = g * xh;
+        acc[0] += d;
+        acc[1] += d * xh;
+        acc[2] += gx[k][j];
+        acc[3] += g;
+      }
+    vmax = fmaxf(vmax, store_ata(gx, dM, T, t, rows, pcol));
+    vmax = fmaxf(vmax, store_ata(gg, dM, T, t, rows, pcol + 32));
+  }
+  if (amax) dsee_wave_atomic_absmax(amax, vmax);
+  // fold the block's threads that share a channel quad (slots s = tid / C4), fixed order
+  const int s = threadIdx.x / C4, ns = 256 / C4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[(k * ns + s) * C4 + q] = acc[k];
+  __syncthreads();
+  if (s == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 v = red[(k * ns) * C4 + q];
+      for (int j = 1; j < ns; ++j) v += red[(k * ns + j) * C4 + q];
+      *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 4 + k) * C + c0) = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums,
                                                             int K, RedGeom g) {
   // sums[k][grp][c] = sum over chunks; 8 outputs x 32 chunk-lanes per block, lanes folded in order
@@ -437,6 +539,36 @@ int dsee_modulate_bwd_reduce(const float* dh, const float* h, const float* x, co
   norm_bwd_reduce_kernel<1><<<dim3(g.chunks, 1), 256, 0, st>>>(dh, h, x, scale, mean, invstd, dgb, dgb_ld, workspace, g,
                                                                 DSEE_ACT_LRELU, slope);
   DSEE_LAUNCH_CHECK();
+  sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 8), 256, 0, st>>>(workspace, sums, 4, g);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* The same reduce half with the gamma/beta gradient produced directly in the Winograd domain:
+ * dM [36][T][rows] = A (g*xhat | g) A^T in the packed column order (T = N*(H/4)*(W/4), rows = 2C) -- what
+ * dsee_wino43_dout(dgb) would give, without dgb.  C % 64 == 0, 256 % (C/4) == 0, H, W % 4 == 0.
+ * workspace: dsee_modulate_bwd_wino_workspace(). */
+static int wino_reduce_blocks(int N, int H, int W, int C) {
+  const long total = (long)N * (H / 4) * (W / 4) * (C / 4);
+  long b = (total + 255) / 256;
+  return (int)(b < 2048 ? b : 2048);
+}
+
+size_t dsee_modulate_bwd_wino_workspace(int N, int H, int W, int C) {
+  return (size_t)wino_reduce_blocks(N, H, W, C) * 4 * C * sizeof(float);
+}
+
+int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                                  const float* invstd, float* dM, int rows, float* sums, int N, int H, int W, int C,
+                                  float slope, float* workspace, float* amax, hipStream_t st) {
+  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && dM && sums && workspace);
+  DSEE_CHECK_ARG(C % 64 == 0 && C <= 1024 && 256 % (C / 4) == 0 && rows == 2 * C && H % 4 == 0 && W % 4 == 0);
+  const int blocks = wino_reduce_blocks(N, H, W, C);
+  norm_bwd_reduce_wino_kernel<<<blocks, 256, 0, st>>>(dh, h, x, scale, mean, invstd, dM, rows, workspace, N, H, W, C,
+                                                      slope, amax);
+  DSEE_LAUNCH_CHECK();
+  RedGeom g = make_geom(N, H * W, C, 1);
+  g.chunks = blocks;  // one partial row [4][C] per block
   sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 8), 256, 0, st>>>(workspace, sums, 4, g);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;

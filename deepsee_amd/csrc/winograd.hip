@@ -154,7 +154,8 @@ __device__ __forceinline__ void emit_split_t(float* tb, unsigned* lb, unsigned s
 
 template <int OUT>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N,
-                                                           int H, int W, int C) {
+                                                           int H, int W, int C, float* __restrict__ amax) {
+  float vmax = 0.f;  // OUT_F32 only: max |V| for the fp16x2 GEMM's operand scale
   __shared__ __attribute__((aligned(16))) float tbuf[OUT == OUT_SPLIT_T ? 4 : 1][16 * 20];
   __shared__ __attribute__((aligned(16))) unsigned lbuf[OUT != OUT_F32 ? 4 : 1][384];
   const int C4 = C / 4, th = H / 4, tw = W / 4;
@@ -241,10 +242,15 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
       for (int j = 0; j < 6; ++j) {
         if constexpr (OUT == OUT_SPLIT_T)
           emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(V), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
-        else
+        else {
           *reinterpret_cast<f32x4*>(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+          vmax = fmaxf(vmax, dsee_absmax4(o[j]));
+        }
       }
     }
+  }
+  if constexpr (OUT == OUT_F32) {
+    if (amax) dsee_wave_atomic_absmax(amax, vmax);
   }
 }
 
@@ -262,7 +268,8 @@ __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
 // dM[xi][t][c] = (A dY A^T)[xi] per 4x4 tile of the output gradient (adjoint of the output transform)
 template <int OUT>
 __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N,
-                                                          int H, int W, int C) {
+                                                          int H, int W, int C, float* __restrict__ amax) {
+  float vmax = 0.f;
   __shared__ __attribute__((aligned(16))) float tbuf[OUT == OUT_SPLIT_T ? 4 : 1][16 * 20];
   __shared__ __attribute__((aligned(16))) unsigned lbuf[OUT != OUT_F32 ? 4 : 1][384];
   const int C4 = C / 4, th = H / 4, tw = W / 4;
@@ -298,10 +305,15 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
       for (int j = 0; j < 6; ++j) {
         if constexpr (OUT == OUT_SPLIT_T)
           emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
-        else
+        else {
           *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+          vmax = fmaxf(vmax, dsee_absmax4(o[j]));
+        }
       }
     }
+  }
+  if constexpr (OUT == OUT_F32) {
+    if (amax) dsee_wave_atomic_absmax(amax, vmax);
   }
 }
 
@@ -406,6 +418,108 @@ __global__ __launch_bounds__(256) void wino43_output_modulate_kernel(
   }
 }
 
+// B v : 6 -> 6   (adjoint of bt6: B = (B^T)^T)
+__device__ __forceinline__ void b6(const f32x4 (&v)[6], f32x4 (&o)[6]) {
+  o[0] = 4.f * v[0];
+  o[1] = 4.f * (v[2] - v[1]) + 2.f * (v[4] - v[3]) + 4.f * v[5];
+  o[2] = -5.f * v[0] - 4.f * (v[1] + v[2]) - v[3] - v[4];
+  o[3] = v[1] - v[2] + 2.f * (v[3] - v[4]) - 5.f * v[5];
+  o[4] = v[0] + v[1] + v[2] + v[3] + v[4];
+  o[5] = v[5];
+}
+
+// Adjoint of the input transform: the data gradient of a Winograd convolution from the SAME dM = A dY A^T the weight
+// gradient uses.  dV[xi][t][ci] = sum_co dM[xi][t][co] U[xi][co][ci] (one GEMM with the forward U transposed) is the
+// gradient w.r.t. V = B^T d B, so every tile contributes the 6x6 patch P_t = B dV_t B^T to dx at rows 4ty-1 .. 4ty+4;
+// neighbouring patches overlap by two rows / columns.  Gather form: the thread of (tile, channel quad) writes its own
+// 4x4 pixels = interior of its own patch + the last patch row / column of the tiles above / left (B's row 5 = e5: only
+// dV row / column 5 is needed) + the first patch row / column of the tiles below / right (B's row 0 = 4 e0) + 4 corner
+// scalars.  64 instead of 36 loads per thread, the 28 extra ones from rows of the same planes its neighbours just read.
+// mask != NULL: dx = mask > 0 ? dx : 0 (ReLU backward of the SPADE embedding, DSEE_ACT_MASK of the conv epilogues).
+__global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const float* __restrict__ dV,
+                                                                   const float* __restrict__ mask, int mask_ld,
+                                                                   float* __restrict__ dx, int N, int H, int W, int C) {
+  const int C4 = C / 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = T * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    auto at = [&](int xi, long tt) { return *reinterpret_cast<const f32x4*>(dV + ((size_t)xi * T + tt) * C + q * 4); };
+    // own patch: tmp[a][s] = (B dV)[a][s], then P[a][b] = sum_s tmp[a][s] B[b][s]
+    f32x4 tmp[6][6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      f32x4 col[6], o[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) col[rr] = at(rr * 6 + s, t);
+      b6(col, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) tmp[a][s] = o[a];
+    }
+    f32x4 y[4][4];
+#pragma unroll
+    for (int a = 1; a < 5; ++a) {
+      f32x4 o[6];
+      b6(tmp[a], o);
+#pragma unroll
+      for (int b = 1; b < 5; ++b) y[a - 1][b - 1] = o[b];
+    }
+    const bool up = ty > 0, dn = ty + 1 < th, lf = tx > 0, rt = tx + 1 < tw;
+    if (up) {  // P_up[5][b] = sum_s dV_up[5][s] B[b][s]
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int s = 0; s < 6; ++s) v[s] = at(30 + s, t - tw);
+      b6(v, o);
+#pragma unroll
+      for (int b = 1; b < 5; ++b) y[0][b - 1] += o[b];
+    }
+    if (dn) {  // P_down[0][b] = 4 sum_s dV_down[0][s] B[b][s]
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int s = 0; s < 6; ++s) v[s] = at(s, t + tw);
+      b6(v, o);
+#pragma unroll
+      for (int b = 1; b < 5; ++b) y[3][b - 1] += 4.f * o[b];
+    }
+    if (lf) {  // P_left[a][5] = sum_r B[a][r] dV_left[r][5]
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) v[rr] = at(rr * 6 + 5, t - 1);
+      b6(v, o);
+#pragma unroll
+      for (int a = 1; a < 5; ++a) y[a - 1][0] += o[a];
+    }
+    if (rt) {  // P_right[a][0] = 4 sum_r B[a][r] dV_right[r][0]
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) v[rr] = at(rr * 6, t + 1);
+      b6(v, o);
+#pragma unroll
+      for (int a = 1; a < 5; ++a) y[a - 1][3] += 4.f * o[a];
+    }
+    if (up && lf) y[0][0] += at(35, t - tw - 1);
+    if (up && rt) y[0][3] += 4.f * at(30, t - tw + 1);
+    if (dn && lf) y[3][0] += 4.f * at(5, t + tw - 1);
+    if (dn && rt) y[3][3] += 16.f * at(0, t + tw + 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t px = ((size_t)n * H + ty * 4 + k) * W + tx * 4 + j;
+        f32x4 v = y[k][j];
+        if (mask) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(mask + px * mask_ld + q * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dx + px * C + q * 4) = v;
+      }
+    }
+}
+
 // G g G^T of one 3x3 filter -> u[36]
 __device__ __forceinline__ void ggt(const float (&g)[3][3], float (&u)[36]) {
   float t[6][3];
@@ -433,9 +547,20 @@ __device__ __forceinline__ void ggt(const float (&g)[3][3], float (&u)[36]) {
 
 // per-image weights of the SEAN gamma/beta GEMM in the Winograd domain:
 // U[xi][n][row][k] = G g G^T,  g = w2a[row][k][:][:] (k < ca, shared)  |  table[n][tap][row][k - ca] (one-hot chunk)
+// element (row, k) term p of a slab-major fp16x2 matrix [K/16][rows][2][16]
+__device__ __forceinline__ size_t split2_index(size_t row, int k, size_t rows, int p) {
+  return (((size_t)(k >> 4) * rows + row) * 2 + p) * 16 + (k & 15);
+}
+__device__ __forceinline__ void split2(float x, _Float16 (&h)[2]) {
+  h[0] = (_Float16)x;
+  h[1] = (_Float16)(x - (float)h[0]);
+}
+
 __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const float* __restrict__ table,
-                                           float* __restrict__ U, int N, int rows, int ca, int Kpad, int split) {
+                                           float* __restrict__ U, int N, int rows, int ca, int Kpad, int split,
+                                           const float* __restrict__ amax) {
   const long per = (long)rows * Kpad, total = (long)N * per;
+  const float sc = split == 2 ? dsee_pow2_scale(*amax) : 1.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % Kpad);
     const long rr = i / Kpad;
@@ -453,7 +578,13 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
     ggt(g, u);
 #pragma unroll
     for (int xi = 0; xi < 36; ++xi) {
-      if (split) {
+      if (split == 2) {
+        _Float16 h[2];
+        split2(u[xi] * sc, h);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          reinterpret_cast<_Float16*>(U)[((size_t)xi * N + n) * per * 2 + split2_index(row, k, rows, p)] = h[p];
+      } else if (split) {
         unsigned short h[3];
         split3(u[xi], h);
 #pragma unroll
@@ -467,10 +598,14 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
 }
 
 // U[xi][row][k]: forward  row = co, k = ci, g = w[co][ci][:][:]
-//                dgrad    row = ci, k = co, g = rot180(w[co][ci])
+//                dgrad    row = ci, k = co, g = rot180(w[co][ci])        (transpose_flip = 1: the data gradient as a
+//                                                                         convolution with the rotated kernel)
+//                adjoint  row = ci, k = co, g = w[co][ci]                (transpose_flip = 2: the forward U transposed,
+//                                                                         for dV = dM x U^T of the adjoint data gradient)
 __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows,
-                                     int Kpad, int transpose_flip, int split) {
+                                     int Kpad, int transpose_flip, int split, const float* __restrict__ amax) {
   const long total = (long)rows * Kpad;
+  const float sc = split == 2 ? dsee_pow2_scale(*amax) : 1.f;
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / Kpad), k = (int)(i % Kpad);
@@ -483,7 +618,7 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
         float v = 0.f;
         if (ok) {
           const int co = transpose_flip ? k : row, ci = transpose_flip ? row : k;
-          const int kh = transpose_flip ? 2 - a : a, kw = transpose_flip ? 2 - b : b;
+          const int kh = transpose_flip == 1 ? 2 - a : a, kw = transpose_flip == 1 ? 2 - b : b;
           v = w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw];
         }
         g[a][b] = v;
@@ -512,7 +647,13 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
       u[5] = t2;
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        if (split) {
+        if (split == 2) {
+          _Float16 h[2];
+          split2(u[b] * sc, h);
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            reinterpret_cast<_Float16*>(U)[(size_t)(a * 6 + b) * total * 2 + split2_index(row, k, rows, p)] = h[p];
+        } else if (split) {
           unsigned short h[3];
           split3(u[b], h);
 #pragma unroll
@@ -526,15 +667,32 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
+// *amax = max(*amax, max |x[0..n)|)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
+  float v = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    v = fmaxf(v, fabsf(x[i]));
+  dsee_wave_atomic_absmax(amax, v);
+}
+
 inline int wgrid(long n) { return (int)min(16384L, (n + 255) / 256); }
 
 }  // namespace
 
 extern "C" {
 
-int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t st) {
+/* *amax = max(*amax, max |x|): operand bound for the fp16x2 scale of a weight tensor (|G g G^T| <= max |g|) */
+int dsee_absmax(const float* x, long n, float* amax, hipStream_t st) {
+  DSEE_CHECK_ARG(x && amax && n > 0);
+  absmax_kernel<<<(int)min(512L, (n + 255) / 256), 256, 0, st>>>(x, n, amax);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* amax (optional device scalar, zeroed by the caller): receives max |V| (atomic max: order independent) */
+int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(x && V && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_input_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C);
+  wino43_input_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C, amax);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -543,14 +701,14 @@ int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipS
 int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(x && V3 && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 8 == 0);
   wino43_input_kernel<OUT_SPLIT><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
-      x, reinterpret_cast<float*>(V3), N, H, W, C);
+      x, reinterpret_cast<float*>(V3), N, H, W, C, nullptr);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
-int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hipStream_t st) {
+int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dM && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_dout_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C);
+  wino43_dout_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C, amax);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -559,7 +717,7 @@ int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hip
 int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(x && V3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
   wino43_input_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
-      x, reinterpret_cast<float*>(V3t), N, H, W, C);
+      x, reinterpret_cast<float*>(V3t), N, H, W, C, nullptr);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -567,7 +725,18 @@ int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, in
 int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dM3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
   wino43_dout_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
-      dy, reinterpret_cast<float*>(dM3t), N, H, W, C);
+      dy, reinterpret_cast<float*>(dM3t), N, H, W, C, nullptr);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* dx [N][H][W][C] from dV [36][T][C] (see wino43_input_adjoint_kernel); mask [pixels][mask_ld] optional */
+int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
+                              hipStream_t st) {
+  DSEE_CHECK_ARG(dV && dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
+  DSEE_CHECK_ARG(!mask || (mask_ld >= C && mask_ld % 4 == 0));
+  wino43_input_adjoint_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dV, mask, mask_ld, dx, N, H,
+                                                                                            W, C);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -585,12 +754,12 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
 
 /* U: [36][dsee_conv_wrows(R)][dsee_conv_kpad(1,1,K)] with (R,K) = (Cout,Cin) forward, (Cin,Cout) data gradient */
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
-                        hipStream_t st) {
-  DSEE_CHECK_ARG(w_oihw && U);
+                        const float* amax_w, hipStream_t st) {
+  DSEE_CHECK_ARG(w_oihw && U && (split != 2 || amax_w));
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
   wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip,
-                                                                 split);
+                                                                 split, amax_w);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -608,10 +777,11 @@ int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const 
 
 /* U: [36][N][rows][Kpad(ca + 32)], rows % 128 == 0; w2a [rows][ca][3][3] (NULL if ca == 0), table [N][9][rows][32] */
 int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, int split,
-                              hipStream_t st) {
-  DSEE_CHECK_ARG(table && U && (ca == 0 || w2a) && ca % 32 == 0 && rows % 128 == 0);
+                              const float* amax_w, hipStream_t st) {
+  DSEE_CHECK_ARG(table && U && (ca == 0 || w2a) && ca % 32 == 0 && rows % 128 == 0 && (split != 2 || amax_w));
   const int Kpad = dsee_conv_kpad(1, 1, ca + 32);
-  wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad, split);
+  wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad, split,
+                                                                           amax_w);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

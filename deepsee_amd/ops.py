@@ -277,65 +277,119 @@ def _wino_ok(n, h, w, cin_s, cout_s, k, stride, pad, ups):
             and cin_s >= 128 and _wino_chunk(n, h, w, max(cin_s, cout_s)) is not None)
 
 
+# ... and with two-term fp16 splits (3 instead of 6 MFMA products per fp32 multiply-add, operands scaled by exact powers
+# of two; DSEE_BF16X3=1 keeps the 3-term bf16 form).  Needs the fp32-A kernels (the operands are split in the GEMM).
+GEMM_F16X2 = os.environ.get("DSEE_BF16X3", "0") != "1"
+
+
 def _split_ok(k_s, r_s):
     return GEMM_SPLIT and k_s % 32 == 0 and r_s % 128 == 0
+
+
+def _split_kind(k_s, r_s):
+    """0: fp32 GEMM operands; 1: bf16x3; 2: fp16x2 (fp32 A operand split inside the GEMM kernel)."""
+    if not _split_ok(k_s, r_s):
+        return 0
+    return 2 if (GEMM_F16X2 and GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF) else 1
 
 
 def _i16(n):
     return torch.empty(n, dtype=torch.int16, device="cuda")
 
 
+_amax_pools = {}
+
+
+def amax_slot():
+    """A zeroed 1-element device tensor for an atomic max |x| (operand scale of the fp16x2 GEMMs).  Slots come from a
+    4096-float pool that is zero-filled once per 4096 uses; every slot is used for one tensor only."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    st = _amax_pools.get(key)
+    if st is None or st[1] >= st[0].numel():
+        st = [torch.zeros(4096, dtype=torch.float32, device="cuda"), 0]
+        _amax_pools[key] = st
+    t = st[0][st[1]:st[1] + 1]
+    st[1] += 1
+    return t
+
+
+def weight_amax(*tensors):
+    """max |w| over the given weight tensors (device scalar): |G g G^T| <= max |g|, so it bounds the Winograd-domain
+    weights built from them."""
+    a = amax_slot()
+    for t in tensors:
+        if t is not None:
+            L.call("absmax", t.contiguous(), t.numel(), a)
+    return a
+
+
 def _wino_u(w, co, ci, transpose_flip, rows, kp, split):
-    """Winograd-domain weights U [36][rows][kp]: fp32, or bf16x3-split rows for the bf16 matrix cores."""
-    u = _i16(36 * rows * kp * 3) if split else new(36, rows, kp)
-    L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split))
-    return u
+    """Winograd-domain weights U [36][rows][kp]: fp32 (split 0), bf16x3-split rows (1) or scaled fp16x2-split rows (2).
+    Returns (U, amax) with amax = the device scalar the fp16x2 scale was derived from (None otherwise)."""
+    amax = weight_amax(w) if split == 2 else None
+    u = _i16(36 * rows * kp * (3 if split == 1 else 2)) if split else new(36, rows, kp)
+    L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split), amax)
+    return u, amax
 
 
-def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=None):
+def _gemm_bytes(t, k_s, r_s, groups, rows, split):
+    """algorithmic HBM bytes of a Winograd-domain GEMM: A (fp32, or 6 B/element pre-split) + B + C (fp32)"""
+    return 4.0 * 36 * t * k_s + (4.0 if split == 2 else 6.0) * groups * rows * k_s + 4.0 * 36 * t * r_s
+
+
+def _gemm_name(split):
+    return "winograd_gemm_f16x2" if split == 2 else "winograd_gemm_bf16x3"
+
+
+def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=None, u_amax=None):
     """M [36][t][r_s] = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs.
-    `keep` (a list) receives the fp32 V when it exists in that form (it is the weight gradient's Q operand)."""
+    `keep` (a list) receives (V, amax_V) when V exists in fp32 (it is the weight gradient's Q operand)."""
     tpi = (h // 4) * (wd // 4)
     t = nb * tpi
     groups, t_g = (36 * nb, tpi) if per_image else (36, t)
     m = new(36, t, r_s)
-    if split and GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF:
-        v = new(36, t, k_s)
-        L.call("wino43_input", xc, v, nb, h, wd, k_s)
-        # algorithmic HBM bytes: A (fp32) + B3 + C (fp32)
-        with _timed("winograd_gemm_bf16x3", 2.0 * 36 * t * k_s * r_s,
-                    4.0 * 36 * t * k_s + 6.0 * groups * rows * k_s + 4.0 * 36 * t * r_s):
-            L.call("gemm_bf16x3_af32", v, u, m, C.c_long(36 * t), r_s, k_s, C.c_long(t_g), rows, 0)
+    if split == 2:
+        v, va = new(36, t, k_s), amax_slot()
+        L.call("wino43_input", xc, v, nb, h, wd, k_s, va)
+        with _timed(_gemm_name(2), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 2)):
+            L.call("gemm_f16x2_af32", v, u, m, 36 * t, r_s, k_s, t_g, rows, 0, va, u_amax)
         if keep is not None:
-            keep.append(v)
+            keep.append((v, va))
+    elif split and GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF:
+        v = new(36, t, k_s)
+        L.call("wino43_input", xc, v, nb, h, wd, k_s, None)
+        with _timed(_gemm_name(1), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 1)):
+            L.call("gemm_bf16x3_af32", v, u, m, 36 * t, r_s, k_s, t_g, rows, 0)
+        if keep is not None:
+            keep.append((v, None))
     elif split:
         v = _i16(36 * t * k_s * 3)
         L.call("wino43_input_split", xc, v, nb, h, wd, k_s)
         # algorithmic HBM bytes: A3 (6 B/element) + B3 + C (fp32)
-        with _timed("winograd_gemm_bf16x3", 2.0 * 36 * t * k_s * r_s,
+        with _timed(_gemm_name(1), 2.0 * 36 * t * k_s * r_s,
                     6.0 * 36 * t * k_s + 6.0 * groups * rows * k_s + 4.0 * 36 * t * r_s):
-            L.call("gemm_bf16x3", v, u, m, C.c_long(36 * t), r_s, k_s, C.c_long(t_g), rows, 0)
+            L.call("gemm_bf16x3", v, u, m, 36 * t, r_s, k_s, t_g, rows, 0)
     else:
         v = new(36, t, k_s)
-        L.call("wino43_input", xc, v, nb, h, wd, k_s)
+        L.call("wino43_input", xc, v, nb, h, wd, k_s, None)
         g = L.ConvGeom(groups, t_g, 1, k_s, t_g, 1, r_s, 1, 1, 1, 0, 1, 0, 0, 1)
         with _timed("winograd_gemm_128x128(igemm,36 groups)", 2.0 * 36 * t * k_s * r_s):
-            L.call("conv2d_fwd_grouped", C.byref(g), v, u, C.c_long(rows * kp), m)
+            L.call("conv2d_fwd_grouped", C.byref(g), v, u, rows * kp, m)
     return m
 
 
 def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0, keep=None):
     """y = conv3x3(x, w) (transpose_flip: data gradient of that conv) through 36 Winograd-domain GEMMs.
-    `keep`: list that receives the fp32 V of the input when the whole batch went through in one pass."""
+    `keep`: list that receives (V, amax_V) of the input when the whole batch went through in one pass."""
     co, ci = w.shape[0], w.shape[1]
     r_s, k_s = (cin_s, cout_s) if transpose_flip else (cout_s, cin_s)   # GEMM output / reduction channels
     rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
-    split = _split_ok(k_s, r_s)
-    u = _wino_u(w, co, ci, transpose_flip, rows, kp, split)
+    split = _split_kind(k_s, r_s)
+    u, ua = _wino_u(w, co, ci, transpose_flip, rows, kp, split)
     y = new(n, h, wd, r_s)
     nb = _wino_chunk(n, h, wd, max(r_s, k_s))
     for n0 in range(0, n, nb):
-        m = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None)
+        m = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None, ua)
         L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
                r_s, act, LRELU_SLOPE)
     return y
@@ -351,41 +405,88 @@ def _wgrad_mode(cin_s, cout_s):
     return 1
 
 
-def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None):
-    """(V, dM) of one image chunk for the Winograd-domain weight gradient: fp32 rows (modes 0, 2; `v` may be the V the
-    forward pass kept) or transposed bf16x3 (mode 1)."""
+def _wgrad_split(mode):
+    """`split` argument of dsee_wino43_wgrad[_table] for a weight-gradient mode: 3 = fp16x2 on fp32 operands."""
+    return 3 if (mode == 2 and GEMM_F16X2) else mode
+
+
+def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None):
+    """((V, amax_V), (dM, amax_dM)) of one image chunk for the Winograd-domain weight gradient: fp32 rows (modes 0, 2;
+    `v` may be the (V, amax) the forward pass kept, `dm` the (A dY A^T, amax) its producer already wrote) or transposed
+    bf16x3 (mode 1, no maxima)."""
     t = nb * (h // 4) * (wd // 4)
     if mode == 1:
         v, dm = _i16(36 * t * cin_s * 3), _i16(36 * t * cout_s * 3)
         L.call("wino43_input_split_t", xc, v, nb, h, wd, cin_s)
         L.call("wino43_dout_split_t", gc, dm, nb, h, wd, cout_s)
-    else:
-        dm = new(36, t, cout_s)
-        if v is None:
-            v = new(36, t, cin_s)
-            L.call("wino43_input", xc, v, nb, h, wd, cin_s)
-        L.call("wino43_dout", gc, dm, nb, h, wd, cout_s)
+        return (v, None), (dm, None)
+    need = GEMM_F16X2 and GEMM_SPLIT       # maxima for the fp16x2 scales (weight gradient and adjoint data gradient)
+    if v is None or (need and v[1] is None):
+        v = (new(36, t, cin_s), amax_slot() if need else None)
+        L.call("wino43_input", xc, v[0], nb, h, wd, cin_s, v[1])
+    if dm is None:
+        dm = (new(36, t, cout_s), amax_slot() if need else None)
+        L.call("wino43_dout", gc, dm[0], nb, h, wd, cout_s, dm[1])
     return v, dm
 
 
-def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None):
-    """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain.  `v_fwd`: the fp32 V of x
-    kept by the forward pass (used when the weight gradient takes fp32 operands and runs in one pass)."""
+# data gradient in the adjoint form from the dM = A dY A^T the weight gradient needs anyway (DSEE_ADJOINT=0: transform dy
+# a second time with B^T . B and run the rotated-kernel convolution)
+ADJOINT_DGRAD = os.environ.get("DSEE_ADJOINT", "1") != "0"
+
+
+def _adjoint_ok(k_s, r_s):
+    """dV = dM x U^T on the fp32-A split GEMM: k_s = channels of dy (reduction), r_s = channels of dx."""
+    return ADJOINT_DGRAD and GEMM_AF32 and _split_ok(k_s, r_s) and k_s * 4 * 256 < 0x7FFFFFFF
+
+
+def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0):
+    """dx [nb,h,wd,r_s] of a 3x3 convolution from dm = (dM [36][t][k_s] = A dY A^T, amax): one grouped GEMM with the
+    transposed forward weights u_t = (U^T [36][rows][k_s] split, amax) and the overlap-add of the patches B dV B^T."""
+    t = nb * (h // 4) * (wd // 4)
+    dv = new(36, t, r_s)
+    split = 2 if u_t[1] is not None else 1
+    with _timed(_gemm_name(split), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, 36, rows, split)):
+        if split == 2:
+            L.call("gemm_f16x2_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0, dm[1], u_t[1])
+        else:
+            L.call("gemm_bf16x3_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0)
+    dx = new(nb, h, wd, r_s)
+    L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s)
+    return dx
+
+
+def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None):
+    """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain.  `v_fwd`: the (V, amax) of
+    x kept by the forward pass (used when the weight gradient takes fp32 operands and runs in one pass).
+    `w_for_dx` (the weight): also return dx, computed from the same dM in the adjoint form -> (dw, dx)."""
     nb = _wino_chunk(n, h, wd, max(cin_s, cout_s))
     t = nb * (h // 4) * (wd // 4)
     mode = _wgrad_mode(cin_s, cout_s)
     nbytes = L.lib().dsee_wino43_wgrad_workspace(C.c_long(t), cin_s, cout_s)
     ws = scratch(nbytes, "wgrad")
     total = None
+    with_dx = w_for_dx is not None
+    assert not with_dx or (mode != 1 and _adjoint_ok(cout_s, cin_s))
+    if with_dx:
+        rows_t = L.wrows(cin_s)
+        u_t = _wino_u(w_for_dx, co, ci, 2, rows_t, L.kpad(1, 1, cout_s), _split_kind(cout_s, cin_s))
+        dx = new(n, h, wd, cin_s) if nb != n else None
     for n0 in range(0, n, nb):
         v, dm = _wino_wgrad_operands(x[n0:n0 + nb], g[n0:n0 + nb], nb, h, wd, cin_s, cout_s, mode,
                                      v_fwd if (mode == 2 and nb == n) else None)
         dw = new(co, ci, 3, 3)
-        with _timed("winograd_wgrad_bf16x3" if mode else "winograd_wgrad_128x128(36 groups)",
-                    2.0 * 36 * t * cin_s * cout_s):
-            L.call("wino43_wgrad", v, dm, ws, C.c_size_t(nbytes), dw, C.c_long(t), cin_s, cout_s, co, ci, mode)
+        with _timed("winograd_wgrad_%s" % ("f16x2" if _wgrad_split(mode) == 3 else "bf16x3") if mode
+                    else "winograd_wgrad_128x128(36 groups)", 2.0 * 36 * t * cin_s * cout_s):
+            L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci, _wgrad_split(mode), v[1], dm[1])
         total = dw if total is None else total.add_(dw)
-    return total
+        if with_dx:
+            dxc = _wino_dgrad_from_dm(dm, u_t, nb, h, wd, cout_s, cin_s, rows_t)
+            if nb == n:
+                dx = dxc
+            else:
+                dx[n0:n0 + nb].copy_(dxc)
+    return (total, dx) if with_dx else total
 
 
 class Conv2d(torch.autograd.Function):
@@ -415,12 +516,13 @@ class Conv2d(torch.autograd.Function):
         else:
             out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act)
         ctx.geom, ctx.act, ctx.has_bias, ctx.has_res = geom, act, bias is not None, res is not None
-        ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None, vkeep)
+        ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None, *(vkeep if vkeep else (None, None)))
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, out, vkeep = ctx.saved_tensors
+        x, w, out, vk, vk_amax = ctx.saved_tensors
+        vkeep = (vk, vk_amax) if vk is not None else None
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
@@ -430,7 +532,12 @@ class Conv2d(torch.autograd.Function):
         else:
             g = dy
         dx = dw = db = dres = None
-        if STREAMS and ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+        fused = (ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not STREAMS
+                 and _wgrad_mode(geom.Cin, geom.Cout) != 1 and _adjoint_ok(geom.Cout, geom.Cin))
+        if fused:
+            # one A dY A^T transform of g serves the weight gradient AND (adjoint form) the data gradient
+            dw, dx = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, w_for_dx=w)
+        elif STREAMS and ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             with _OnSide() as sd:
                 dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep)
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
@@ -710,16 +817,28 @@ def bn_stats(x, running_mean, running_var, training):
     return mean, invstd, cfg
 
 
-def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg):
-    """Backward of BN + modulate + LeakyReLU: (dx, dgb, col_sums [2][C]).  With SyncBN (`cfg`) the two per-channel sums
-    of the BN backward are all-reduced over the ranks between the reduce and the apply pass."""
+# gamma/beta gradient written by the norm backward directly in the Winograd domain (DSEE_FUSE_DM=0: dgb + wino43_dout)
+FUSE_DM = os.environ.get("DSEE_FUSE_DM", "1") != "0"
+
+
+def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False):
+    """Backward of BN + modulate + LeakyReLU: (dx, dgb, col_sums [2][C], dM).  With SyncBN (`cfg`) the two per-channel
+    sums of the BN backward are all-reduced over the ranks between the reduce and the apply pass.  `as_dm`: the
+    gamma/beta gradient leaves the reduce pass as dM = A (g*xhat | g) A^T [36][T][rows] (dgb is None)."""
     n, h, w, c = x.shape
-    dgb = (torch.zeros if c % 64 else torch.empty)(n, h, w, rows, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     sums = new(4, c)
-    ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
-    L.call("modulate_bwd_reduce", dh.contiguous(), out, x, scale, mean, invstd, dgb, rows, sums, n, h * w, c,
-           LRELU_SLOPE, ws)
+    dgb = dm = None
+    if as_dm:
+        dm = (new(36, n * (h // 4) * (w // 4), rows), amax_slot() if (GEMM_F16X2 and GEMM_SPLIT) else None)
+        ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
+        L.call("modulate_bwd_reduce_wino", dh.contiguous(), out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c,
+               LRELU_SLOPE, ws, dm[1])
+    else:
+        dgb = (torch.zeros if c % 64 else torch.empty)(n, h, w, rows, dtype=torch.float32, device=x.device)
+        ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
+        L.call("modulate_bwd_reduce", dh.contiguous(), out, x, scale, mean, invstd, dgb, rows, sums, n, h * w, c,
+               LRELU_SLOPE, ws)
     count = n * h * w
     if cfg is not None:
         from . import parallel
@@ -727,7 +846,7 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg):
         count *= cfg.world
     L.call("modulate_bwd_apply", dh.contiguous(), out, x, scale, mean, invstd, sums, None, dx, n, h * w, c, 1.0 / count,
            LRELU_SLOPE)
-    return dx, dgb, sums[2:4]
+    return dx, dgb, sums[2:4], dm
 
 
 class SpadeNormAct(torch.autograd.Function):
@@ -758,7 +877,7 @@ class SpadeNormAct(torch.autograd.Function):
         geom = ctx.geom
         n, h, w, c = x.shape
         rows, kin = w2.shape[0], w2.shape[1]
-        dx, dgb, cs = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync)
+        dx, dgb, cs, _ = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync)
         dcat = dw2 = db2 = None
         if ctx.needs_input_grad[1]:
             gd = L.geom_dgrad(geom)
@@ -814,16 +933,18 @@ class SeanNormTable(torch.autograd.Function):
             tpi = (h // 4) * (w // 4)
             kp = L.kpad(1, 1, ld)
             b2c = b2.contiguous()
-            split = _split_ok(ld, rows)
+            split = _split_kind(ld, rows)
             # the fp32 V of `cat` is the Q operand of the weight / table gradient: kept for the backward pass
             keep = [] if (KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2) else None
             for n0 in range(0, n, nb):
                 if has_t:
-                    u = _i16(36 * nb * rows * kp * 3) if split else new(36, nb, rows, kp)
-                    L.call("wino43_weights_table", w2a if has_a else None, tb[n0:n0 + nb], u, nb, rows, ca, int(split))
+                    ua = weight_amax(w2a if has_a else None, tb[n0:n0 + nb]) if split == 2 else None
+                    u = _i16(36 * nb * rows * kp * (3 if split == 1 else 2)) if split else new(36, nb, rows, kp)
+                    L.call("wino43_weights_table", w2a if has_a else None, tb[n0:n0 + nb], u, nb, rows, ca, int(split),
+                           ua)
                 else:
-                    u = _wino_u(w2a, rows, ca, False, rows, kp, split)
-                m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split, keep)
+                    u, ua = _wino_u(w2a, rows, ca, False, rows, kp, split)
+                m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split, keep, ua)
                 L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
                        scale[n0:n0 + nb] if need_scale else None, nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
         else:
@@ -832,25 +953,37 @@ class SeanNormTable(torch.autograd.Function):
                 L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, tb, ca, b2.contiguous(), x, mean, invstd, out,
                        scale, c, float(add_one), LRELU_SLOPE)
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
-        vcat = keep[0] if (nb and keep) else None
-        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, vcat)
+        vcat = keep[0] if (nb and keep) else (None, None)
+        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, *vcat)
         return out
 
     @staticmethod
     def backward(ctx, dh):
-        x, cat, w2a, out, scale, mean, invstd, vcat = ctx.saved_tensors
+        x, cat, w2a, out, scale, mean, invstd, vc, vc_amax = ctx.saved_tensors
+        vcat = (vc, vc_amax) if vc is not None else None
         geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
         n, h, w, c = x.shape
         ld = cat.shape[3]
-        dx, dgb, cs = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync)
         dw_sh = db_sh = dw2a = dtable = db2 = None
         nb = ctx.wino_nb
         wino_w = bool(nb) and (ctx.has_t or ctx.needs_input_grad[3])
+        # the embedding's data gradient from the weight gradient's dM (adjoint form): no second transform of the
+        # 1024-channel gamma/beta gradient
+        fused_d = (wino_w and ctx.has_a and not STREAMS and _wgrad_mode(ld, rows) != 1 and _adjoint_ok(rows, NHIDDEN))
+        dactv_fused = [None]
+        # every consumer of the gamma/beta gradient reads dM: let the norm backward write it directly
+        as_dm = (FUSE_DM and wino_w and nb == n and _wgrad_mode(ld, rows) != 1 and (fused_d or not ctx.has_a)
+                 and 256 % (c // 4) == 0)
+        dx, dgb, cs, dm_all = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync, as_dm)
 
         def wino_wgrad():
             dw2a = dtable = None
             # weight gradient in the Winograd domain: groups (xi, image), shared columns summed over images
             tpi, ca = (h // 4) * (w // 4), (NHIDDEN if ctx.has_a else 0)
+            if fused_d:
+                rows_t = L.wrows(NHIDDEN)
+                u_t = _wino_u(w2a, rows, NHIDDEN, 2, rows_t, L.kpad(1, 1, rows), _split_kind(rows, NHIDDEN))
+                dactv_fused[0] = new(n, h, w, NHIDDEN) if nb != n else None
             if ctx.has_t:
                 nbytes = L.lib().dsee_wino43_wgrad_table_workspace(C.c_long(nb * tpi), nb, ca, rows)
                 dtable = new(n, 9, rows, 32)
@@ -859,25 +992,35 @@ class SeanNormTable(torch.autograd.Function):
             wsw = scratch(nbytes, "wgrad")
             mode = _wgrad_mode(ld, rows)
             for n0 in range(0, n, nb):
-                v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], dgb[n0:n0 + nb], nb, h, w, ld, rows, mode,
-                                             vcat if (mode == 2 and nb == n) else None)
+                v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], None if as_dm else dgb[n0:n0 + nb], nb, h, w, ld, rows,
+                                             mode, vcat if (mode == 2 and nb == n) else None, dm_all)
                 dwc = new(rows, NHIDDEN, 3, 3) if ctx.has_a else None
-                with _timed("winograd_wgrad_bf16x3" if mode else "winograd_wgrad_128x128(36 groups)",
-                            2.0 * 36 * nb * tpi * ld * rows):
+                with _timed("winograd_wgrad_%s" % ("f16x2" if _wgrad_split(mode) == 3 else "bf16x3") if mode
+                            else "winograd_wgrad_128x128(36 groups)", 2.0 * 36 * nb * tpi * ld * rows):
                     if ctx.has_t:
-                        L.call("wino43_wgrad_table", v, dm, wsw, C.c_size_t(nbytes), dwc, dtable[n0:n0 + nb],
-                               C.c_long(nb * tpi), nb, ca, rows, lab.nc, mode)
+                        L.call("wino43_wgrad_table", v[0], dm[0], wsw, nbytes, dwc, dtable[n0:n0 + nb], nb * tpi, nb, ca,
+                               rows, lab.nc, _wgrad_split(mode), v[1], dm[1])
                     else:
-                        L.call("wino43_wgrad", v, dm, wsw, C.c_size_t(nbytes), dwc, C.c_long(nb * tpi), ld, rows, rows,
-                               NHIDDEN, mode)
+                        L.call("wino43_wgrad", v[0], dm[0], wsw, nbytes, dwc, nb * tpi, ld, rows, rows, NHIDDEN,
+                               _wgrad_split(mode), v[1], dm[1])
                 if dwc is not None:
                     dw2a = dwc if dw2a is None else dw2a.add_(dwc)
+                if fused_d:
+                    # (the ReLU mask of the embedding rides in the epilogue when the one-hot channels share `cat`)
+                    dac = _wino_dgrad_from_dm(dm, u_t, nb, h, w, rows, NHIDDEN, rows_t,
+                                              cat[n0:n0 + nb] if ctx.has_t else None, ld if ctx.has_t else 0)
+                    if nb == n:
+                        dactv_fused[0] = dac
+                    else:
+                        dactv_fused[0][n0:n0 + nb].copy_(dac)
             return dw2a, dtable
 
         side = None
         if wino_w and STREAMS and ctx.has_a:
             with _OnSide() as side:          # weight / table gradient on the second stream, data gradient below
                 dw2a, dtable = wino_wgrad()
+        if fused_d:
+            dw2a, dtable = wino_wgrad()
         if ctx.has_a:
             # data gradient only w.r.t. the 128 embedding channels (the one-hot channels need none)
             ga = L.ConvGeom(n, h, w, rows, h, w, NHIDDEN, 3, 3, 1, 1, -1, 0, 0, 1)
@@ -885,7 +1028,9 @@ class SeanNormTable(torch.autograd.Function):
             if ctx.has_t:
                 # ReLU backward fused into the dgrad epilogue; the gradient of mlp_shared (a conv over the one-hot
                 # label) is then the weight gradient w.r.t. the one-hot channels already sitting in `cat` (MFMA)
-                if wino_d:
+                if fused_d:
+                    dactv = dactv_fused[0]
+                elif wino_d:
                     dactv = _wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True, None, cat, L.ACT_MASK, res_ld=ld)
                 else:
                     dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga, None, cat, L.ACT_MASK, res_ld=ld)
@@ -893,7 +1038,8 @@ class SeanNormTable(torch.autograd.Function):
                 dw_sh = wgrad_raw(cat, dactv, gs, NHIDDEN, lab.nc, 3, 3, cin_first=NHIDDEN)
                 db_sh = channel_dot(dactv, None, NHIDDEN).clone()
             else:
-                dactv = (_wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True) if wino_d
+                dactv = (dactv_fused[0] if fused_d else
+                         _wino_conv(dgb, w2a, n, h, w, NHIDDEN, rows, True) if wino_d
                          else conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga))
                 dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
                 wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
@@ -901,7 +1047,7 @@ class SeanNormTable(torch.autograd.Function):
                        db_sh, wso)
         if side is not None:
             side.join(dw2a, dtable)
-        elif wino_w:
+        elif wino_w and not fused_d:
             dw2a, dtable = wino_wgrad()
         if wino_w:
             pass

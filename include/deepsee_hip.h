@@ -82,11 +82,11 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
  *   M = dsee_conv2d_fwd_grouped(V viewed [36][T][1][Cin], U, group_stride = wrows*Kpad)   36 GEMMs, 2.25 MAC/px/ch pair
  *   y = dsee_wino43_output(M, bias, residual, act)
  * with U = dsee_wino43_weights(w, transpose_flip = 0) (forward) or 1 (data gradient of the same conv). */
-int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, hipStream_t stream);
+int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, float* amax, hipStream_t stream);
 int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
                        int H, int W, int C, int act, float slope, hipStream_t stream);
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
-                        hipStream_t stream);
+                        const float* amax_w, hipStream_t stream);
 /* fp32-accurate GEMM on the bf16 matrix cores (operands split into three bf16 terms by their producers, six MFMA
  * products accumulated in fp32; see deepsee_amd/csrc/gemm_bf16x3.hip).  With `split` the producers write slab-major
  * [K/16][rows][3][16] bf16 (1.5x the fp32 bytes) instead of fp32 rows:
@@ -97,6 +97,17 @@ int dsee_gemm_bf16x3_af32(const float* A, const void* B3, float* C, long M, int 
                           int tile, hipStream_t stream);
 int dsee_gemm_bf16x3(const void* A3, const void* B3, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                      int tile, hipStream_t stream);
+/* fp16x2: the same fp32-accurate GEMMs with HALF the matrix-core work.  An operand is scaled by the power of two
+ * s = 2^(13 - floor(log2(max |x|))) (largest element into [2^13, 2^14)) and split into two fp16 terms h0 + h1 (residual
+ * <= 2^-22 |x|, rms 2^-24: below the rounding of the fp32 accumulator); a*b = (a1*b0 + a0*b1 + a0*b0) / (s_a s_b), 3 MFMA products instead of 6.
+ * The maxima travel as device scalars: dsee_wino43_input / dsee_wino43_dout / dsee_modulate_bwd_reduce_wino write max |V|,
+ * max |dM| into `amax` (atomic max, the caller zeroes it); weights use dsee_absmax(w) (|G g G^T| <= max |g|), and
+ * dsee_wino43_weights(..., split = 2, amax_w) writes B2 [K/16][rows][2][16] fp16 scaled by the same function. */
+int dsee_absmax(const float* x, long n, float* amax, hipStream_t stream);
+int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                         int tile, const float* amax_a, const float* amax_b, hipStream_t stream);
+int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                           int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
 int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
                             float* out, hipStream_t stream);
 /* Weight gradient of the same convs in the Winograd domain (backward of architecture.py:98,122):
@@ -112,15 +123,23 @@ int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const 
                                 const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
                                 int rows, float add_one, float slope, hipStream_t stream);
 int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, int split,
-                              hipStream_t stream);
+                              const float* amax_w, hipStream_t stream);
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
-                            float* dtable, long T, int N, int ca, int rows, int L, int split, hipStream_t stream);
-int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, hipStream_t stream);
+                            float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,
+                            const float* amax_dm, hipStream_t stream);
+int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, float* amax, hipStream_t stream);
+/* Data gradient from the SAME dM (adjoint form: no second transform of dy): dV = dM x U^T with
+ * U^T = dsee_wino43_weights(w, transpose_flip = 2) [36][rows(Cin)][Cout], then dx = sum over tiles of the overlapping
+ * 6x6 patches B dV B^T (gather form).  mask != NULL: dx = mask > 0 ? dx : 0 (ReLU backward, like DSEE_ACT_MASK). */
+int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
+                              hipStream_t stream);
 size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
-                      long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, hipStream_t stream);
-/* split = 2: V / dM are the plain fp32 transforms (dsee_wino43_input / dsee_wino43_dout), transposed and split inside
+                      long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, const float* amax_v,
+                      const float* amax_dm, hipStream_t stream);
+/* split = 3: as split = 2 with two-term fp16 splits (dsee_gemm_f16x2_tn_f32; amax_v / amax_dm = max |V|, max |dM|).
+ * split = 2: V / dM are the plain fp32 transforms (dsee_wino43_input / dsee_wino43_dout), transposed and split inside
  * dsee_gemm_bf16x3_tn_f32 (Cout_stored % 256 == 0, Cin_stored == 160 or % 128 == 0).
  * split = 1: V / dM are the transposed bf16x3 operands [36][T/16][C][3][16 tiles] written by the two producers below
  * and the reduction over tiles runs on the bf16 matrix cores (dsee_gemm_bf16x3_tn, fp32-accurate). */
@@ -217,6 +236,13 @@ int dsee_modulate_bwd(const float* dh, const float* h, const float* x, const flo
 int dsee_modulate_bwd_reduce(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                              const float* invstd, float* dgb, int dgb_ld, float* sums, int N, int HW, int C, float slope,
                              float* workspace, hipStream_t stream);
+/* reduce half with the gamma/beta gradient written directly in the Winograd domain: dM [36][T][rows = 2C] =
+ * A (g*xhat | g) A^T in the packed column order, i.e. dsee_wino43_dout(dgb) without dgb ever existing (it is the
+ * operand of dsee_wino43_wgrad[_table] and, through dsee_wino43_input_adjoint, of the embedding's data gradient). */
+size_t dsee_modulate_bwd_wino_workspace(int N, int H, int W, int C);
+int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                                  const float* invstd, float* dM, int rows, float* sums, int N, int H, int W, int C,
+                                  float slope, float* workspace, float* amax, hipStream_t stream);
 int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                             const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
                             float inv_count, float slope, hipStream_t stream);

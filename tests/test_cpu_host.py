@@ -444,6 +444,47 @@ def test_bf16x3_split_arithmetic_emulated_on_cpu():
     assert e3 > 8 * e6                               # the three small products are what makes it fp32-accurate
 
 
+def test_f16x2_split_arithmetic_emulated_on_cpu():
+    """The numerical argument behind the fp16x2 form of deepsee_amd/csrc/gemm_bf16x3.hip, emulated with torch on the
+    CPU: after scaling by a power of two that brings the largest element into [2^13, 2^14), an fp32 value differs from
+    the sum of two fp16 terms (2 x 11 significand bits) by at most 2^-22 of its magnitude -- rms 2^-24, the size of one
+    fp32 rounding -- or 2^-25 absolute where the second term goes subnormal, and the three products a1*b0 + a0*b1 + a0*b0
+    accumulated in fp32 give a GEMM error (vs float64) no larger than a plain fp32 GEMM's (the accumulator's rounding
+    dominates both) -- also on data spread over e^(+-8)."""
+    import math
+    g = torch.Generator().manual_seed(0)
+
+    def split(x):
+        amax = float(x.abs().max())
+        s = 2.0 ** (13 - math.floor(math.log2(amax)))
+        xs = x * s
+        assert 2.0 ** 13 <= float(xs.abs().max()) < 2.0 ** 14
+        h0 = xs.half().float()
+        h1 = (xs - h0).half().float()
+        err = (xs - h0 - h1).abs()
+        assert bool((err <= torch.maximum(xs.abs() * 2.0 ** -22, torch.tensor(2.0 ** -25))).all())
+        big = xs.abs() > 1.0
+        assert float(((err[big] / xs.abs()[big]) ** 2).mean().sqrt()) < 2.0 ** -23.5
+        return h0, h1, s
+
+    for spread in (0.0, 2.0):
+        a = torch.randn(256, 512, generator=g) * (torch.randn(256, 512, generator=g) * spread).exp()
+        b = torch.randn(512, 192, generator=g) * 0.02
+        a0, a1, sa = split(a)
+        b0, b1, sb = split(b)
+        ref = a.double() @ b.double()
+        err = lambda y: float((y.double() - ref).norm() / ref.norm())
+        acc = torch.zeros(256, 192)
+        for k in range(0, 512, 16):                  # one MFMA = 16 k's; smallest terms first, one fp32 accumulator
+            sl = slice(k, k + 16)
+            for x, y in ((a1, b0), (a0, b1), (a0, b0)):
+                acc = acc + x[:, sl] @ y[sl]
+        e3, e32 = err(acc / (sa * sb)), err(a @ b)
+        e1 = err((a0 @ b0) / (sa * sb))
+        assert e3 <= 1.5 * e32 and e3 < 5e-7, (spread, e3, e32)
+        assert e1 > 100 * e3                          # one product alone is fp16 accuracy: the cross terms carry it
+
+
 def test_style_matrix_csv_roundtrip(tmp_path):
     """deepsee_amd.util.save_style_matrix writes what the reference's util/util.py:150-158 writes (numpy.savetxt with
     ',' delimiter) and load_style_matrix reads it back bit-exactly in fp32."""

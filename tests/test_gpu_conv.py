@@ -256,3 +256,111 @@ def test_gemm_bf16x3_af32(groups, tg, n, k, tile):
     L.call("gemm_bf16x3_af32", a.cuda(), b3, c1, C.c_long(groups * tg), n, k, C.c_long(tg), n, tile)
     torch.cuda.synchronize()
     assert torch.equal(c0, c1)
+
+
+def _pow2_scale(amax):
+    """dsee_pow2_scale on the host: the power of two that maps amax into [2^13, 2^14)."""
+    import math
+    return 2.0 ** (13 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+
+
+def _split2_rows(x, scale):
+    """fp32 [rows][K] -> slab-major fp16x2 [K/16][rows][2][16] (int16 view) of scale * x, the layout
+    dsee_gemm_f16x2_af32 reads for its B operand."""
+    xs = x * scale
+    h0 = xs.half()
+    h1 = (xs - h0.float()).half()
+    rows, k = x.shape
+    return torch.stack([h0, h1], 0).view(2, rows, k // 16, 16).permute(2, 1, 0, 3).contiguous().view(torch.int16)
+
+
+@pytest.mark.parametrize("groups,tg,n,k,tile,spread", [(3, 256, 256, 160, 1, 1.0), (2, 512, 256, 512, 2, 1.0),
+                                                       (36, 128, 128, 32, 1, 1.0), (1, 1024, 512, 1024, 0, 1.0),
+                                                       (2, 512, 256, 512, 2, 4.0), (2, 256, 128, 256, 1, 1e-3)])
+def test_gemm_f16x2_is_fp32_accurate(groups, tg, n, k, tile, spread):
+    """The two-term fp16 form (3 MFMA products, operands scaled by powers of two from their device-side maxima) against
+    float64: same bound as bf16x3 -- at most 2x a CPU sgemm's error and < 5e-7 -- on O(1) data, on data with a
+    log-normal dynamic range of e^(+-4 sigma) per row (spread 4) and on tiny operands (1e-3: the scale, not the fp16
+    range, decides)."""
+    from deepsee_amd import lib as L, ops
+    g = torch.Generator().manual_seed(groups * 1000 + k)
+    a = torch.randn(groups * tg, k, generator=g) * (torch.randn(groups * tg, 1, generator=g) * abs(spread)).exp()
+    if spread < 1:
+        a = torch.randn(groups * tg, k, generator=g) * spread
+    b = torch.randn(groups, n, k, generator=g) * (spread if spread < 1 else 1.0)
+    ref = torch.einsum("gtk,gnk->gtn", a.view(groups, tg, k).double(), b.double()).reshape(groups * tg, n)
+    f32 = torch.einsum("gtk,gnk->gtn", a.view(groups, tg, k), b).reshape(groups * tg, n)
+    am_a, am_b = float(a.abs().max()), float(b.abs().max())
+    amax_a, amax_b = torch.tensor([am_a], device="cuda"), torch.tensor([am_b], device="cuda")
+    b2 = torch.stack([_split2_rows(b[i], _pow2_scale(am_b)) for i in range(groups)]).cuda()
+    c = torch.full((groups * tg, n), float("nan"), device="cuda")
+    L.call("gemm_f16x2_af32", a.cuda(), b2, c, groups * tg, n, k, tg, n, tile, amax_a, amax_b)
+    torch.cuda.synchronize()
+    e_split = ((c.cpu().double() - ref).norm() / ref.norm()).item()
+    e_f32 = ((f32.double() - ref).norm() / ref.norm()).item()
+    print("fp16x2 vs f64: %.2e | cpu sgemm vs f64: %.2e" % (e_split, e_f32))
+    assert e_split < 5e-7 and e_split <= 2 * e_f32, (e_split, e_f32)
+    assert ((c.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    # device-side maximum: the transform kernels' atomic max gives the same scalar as the host reduction
+    slot = ops.amax_slot()
+    L.call("absmax", a.cuda(), a.numel(), slot)
+    assert float(slot) == am_a
+
+
+@pytest.mark.parametrize("groups,t,rp,rq,splits", [(2, 1024, 256, 128, 2), (3, 512, 256, 160, 1), (36, 256, 512, 512, 1)])
+def test_gemm_f16x2_tn_matches_float64(groups, t, rp, rq, splits):
+    """Split-K "TN" weight-gradient form with both fp32 operands transposed, scaled and split inside the kernel
+    (dsee_gemm_f16x2_tn_f32, 256x128 and 256x160 tiles): C[g*splits+s] = P[g, tiles of s]^T Q[g, tiles of s]."""
+    from deepsee_amd import lib as L
+    g = torch.Generator().manual_seed(t + rq)
+    p = torch.randn(groups * t, rp, generator=g) * 3.0
+    q = torch.randn(groups * t, rq, generator=g) * 0.02
+    amax_p = torch.tensor([float(p.abs().max())], device="cuda")
+    amax_q = torch.tensor([float(q.abs().max())], device="cuda")
+    c = torch.full((groups * splits, rp, rq), float("nan"), device="cuda")
+    L.call("gemm_f16x2_tn_f32", p.cuda(), q.cuda(), c, groups, t, rp, rq, rq, splits, amax_p, amax_q)
+    c3 = torch.full((groups * splits, rp, rq), float("nan"), device="cuda")
+    L.call("gemm_bf16x3_tn_f32", p.cuda(), q.cuda(), c3, groups, t, rp, rq, rq, splits)
+    torch.cuda.synchronize()
+    ts = t // splits
+    ref = torch.einsum("ztp,ztq->zpq", p.view(groups * splits, ts, rp).double(), q.view(groups * splits, ts, rq).double())
+    f32 = torch.einsum("ztp,ztq->zpq", p.view(groups * splits, ts, rp), q.view(groups * splits, ts, rq))
+    e2 = ((c.cpu().double() - ref).norm() / ref.norm()).item()
+    e3 = ((c3.cpu().double() - ref).norm() / ref.norm()).item()
+    e32 = ((f32.double() - ref).norm() / ref.norm()).item()
+    print("TN fp16x2 %.2e | bf16x3 %.2e | cpu sgemm %.2e" % (e2, e3, e32))
+    assert e2 < 5e-7 and e2 <= 2 * max(e32, e3), (e2, e3, e32)
+
+
+def test_f16x2_special_values():
+    """Edges of the operand split: zero operands (scale 1, result exactly 0), values 2^20 below the operand maximum
+    (h1 subnormal: absolute error <= 2^-39 of the maximum), huge / tiny magnitudes (the power-of-two scale keeps fp16 in
+    range), and inf / nan propagate to the affected outputs only."""
+    from deepsee_amd import lib as L
+    n = k = 128
+    def run(a, b):
+        c = torch.full((128, n), float("nan"), device="cuda")
+        am_a, am_b = float(a.abs().nan_to_num(0, 0, 0).max()), float(b.abs().nan_to_num(0, 0, 0).max())
+        if not torch.isfinite(a).all():
+            am_a = float("inf")
+        amax_a, amax_b = torch.tensor([am_a], device="cuda"), torch.tensor([am_b], device="cuda")
+        sb = _pow2_scale(am_b) if am_b > 0 and am_b != float("inf") else 1.0
+        L.call("gemm_f16x2_af32", a.cuda(), _split2_rows(b, sb)[None].cuda(), c, 128, n, k, 128, n, 1, amax_a, amax_b)
+        torch.cuda.synchronize()
+        return c.cpu()
+    g = torch.Generator().manual_seed(1)
+    b = torch.randn(n, k, generator=g)
+    assert torch.equal(run(torch.zeros(128, k), b), torch.zeros(128, n))
+    a = torch.randn(128, k, generator=g)
+    a[5] *= 2.0 ** -20                                           # a row far below the maximum
+    ref = a.double() @ b.double().t()
+    c = run(a, b)
+    assert float((c[5].double() - ref[5]).abs().max()) < 2.0 ** -36 * float(a.abs().max()) * float(b.abs().max()) * k
+    for s in (1e30, 1e-30):                                      # magnitudes far outside the fp16 range
+        c = run(a * s, b)
+        assert float(((c.double() / s) - ref).norm() / ref.norm()) < 5e-7
+    a2 = a.clone()
+    a2[7, 3] = float("inf")
+    c = run(a2, b)
+    assert not torch.isfinite(c[7]).any() or torch.isnan(c[7]).any() or torch.isinf(c[7]).any()
+    assert torch.isfinite(c[8]).all()
