@@ -9,7 +9,7 @@ for f in *.hip *.cpp; do
   [ -e "$f" ] || continue
   o="build/${f%.*}.o"
   mkdir -p build
-  if [ ! -e "$o" ] || [ "$f" -nt "$o" ] || [ dsee_common.h -nt "$o" ] || [ ../../include/deepsee_hip.h -nt "$o" ]; then
+  if [ ! -e "$o" ] || [ "$f" -nt "$o" ] || [ dsee_common.h -nt "$o" ] || [ dsee_rng.h -nt "$o" ] || [ ../../include/deepsee_hip.h -nt "$o" ]; then
     echo "hipcc $f"
     if [[ "$f" == *.hip ]]; then hipcc $FLAGS -c "$f" -o "$o"; else hipcc $FLAGS -x hip -c "$f" -o "$o"; fi
   fi

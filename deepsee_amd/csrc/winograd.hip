@@ -9,6 +9,7 @@
 //                                         U'[36][rows(Cin)][Cout] of the 180-degree-rotated kernel (data gradient)
 // Replaces the same ATen convolutions as conv_mfma.hip (architecture.py:98,122 and their backward).
 #include "dsee_common.h"
+#include "dsee_rng.h"
 
 namespace {
 
@@ -317,10 +318,16 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
   }
 }
 
+// noise_w != NULL: y += noise_w[c] * eps with eps = element (pixel, quad) of the Philox N(0,1) stream (seed, offset) --
+// the NoiseInjection that follows the convolution (architecture.py:111-112 noise_middle) without its own pass over y
+template <bool NOISE>
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             const float* __restrict__ res, int res_ld,
                                                             float* __restrict__ y, int N, int H, int W, int C, int act,
-                                                            float slope) {
+                                                            float slope, const float* __restrict__ noise_w,
+                                                            uint64_t seed, uint64_t offset,
+                                                            const float* __restrict__ res_nw, uint64_t res_seed,
+                                                            uint64_t res_offset) {
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -340,6 +347,8 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
       for (int k = 0; k < 4; ++k) tmp[k][j] = o[k];
     }
     const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 nw = noise_w ? *reinterpret_cast<const f32x4*>(noise_w + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 rnw = res_nw ? *reinterpret_cast<const f32x4*>(res_nw + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       f32x4 o[4];
@@ -353,9 +362,19 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
         } else {
-          if (res) v += *reinterpret_cast<const f32x4*>(res + px * res_ld + q * 4);
+          if (res) {
+            // the shortcut x_s = noise_skip(x) (architecture.py:133-134,127) regenerated from x: never materialised
+            f32x4 rv = *reinterpret_cast<const f32x4*>(res + px * res_ld + q * 4);
+            if constexpr (NOISE) {
+              if (res_nw) rv += rnw * philox_normal4(res_seed, res_offset + (uint64_t)(px * C4 + q));
+            }
+            v += rv;
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = dsee_act(v[e], act, slope);
+        }
+        if constexpr (NOISE) {
+          if (noise_w) v += nw * philox_normal4(seed, offset + (uint64_t)(px * C4 + q));
         }
         *reinterpret_cast<f32x4*>(y + off) = v;
       }
@@ -667,11 +686,14 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
-// *amax = max(*amax, max |x[0..n)|)
+// *amax = max(*amax, max |x[0..n)|); 16 bytes per lane, scalar tail
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
   float v = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    v = fmaxf(v, fabsf(x[i]));
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    v = fmaxf(v, dsee_absmax4(*reinterpret_cast<const f32x4*>(x + i * 4)));
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) v = fmaxf(v, fabsf(x[i]));
   dsee_wave_atomic_absmax(amax, v);
 }
 
@@ -684,7 +706,8 @@ extern "C" {
 /* *amax = max(*amax, max |x|): operand bound for the fp16x2 scale of a weight tensor (|G g G^T| <= max |g|) */
 int dsee_absmax(const float* x, long n, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(x && amax && n > 0);
-  absmax_kernel<<<(int)min(512L, (n + 255) / 256), 256, 0, st>>>(x, n, amax);
+  DSEE_CHECK_ARG(((uintptr_t)x & 15) == 0);
+  absmax_kernel<<<(int)min(1024L, (n / 4 + 255) / 256 + 1), 256, 0, st>>>(x, n, amax);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -742,12 +765,21 @@ int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, f
 }
 
 int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
-                       int H, int W, int C, int act, float slope, hipStream_t st) {
+                       int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
+                       uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
+                       uint64_t res_noise_offset, hipStream_t st) {
   DSEE_CHECK_ARG(M && y && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(act != DSEE_ACT_MASK || residual);
   DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
-  wino43_output_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(M, bias, residual, residual_ld, y, N,
-                                                                                     H, W, C, act, slope);
+  DSEE_CHECK_ARG(!res_noise_w || (residual && residual_ld == C && act != DSEE_ACT_MASK));
+  const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
+  if (noise_w || res_noise_w)
+    wino43_output_kernel<true><<<grid, 256, 0, st>>>(M, bias, residual, residual_ld, y, N, H, W, C, act, slope, noise_w,
+                                                     noise_seed, noise_offset, res_noise_w, res_noise_seed,
+                                                     res_noise_offset);
+  else
+    wino43_output_kernel<false><<<grid, 256, 0, st>>>(M, bias, residual, residual_ld, y, N, H, W, C, act, slope, nullptr,
+                                                      0, 0, nullptr, 0, 0);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

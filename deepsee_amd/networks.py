@@ -170,21 +170,23 @@ class SpadeNorm(nn.Module):
             self.alpha_beta = nn.Parameter(torch.rand(1))
             self.alpha_gamma = nn.Parameter(torch.rand(1))
 
-    def forward(self, x, labels, style, training):
+    def forward(self, x, labels, style, training, grad_sink=None):
+        """`grad_sink` (ops.GradSink): the gradient of the other consumer of x (the resblock shortcut) is added to dx
+        inside this norm's backward pass."""
         n, h, w, c = x.shape
         fm = h if self.kind == "spade" else min(h, self.max_fm)  # SPADE.forward has no fm cap
         sh = self.mlp_shared._modules["0"]
         st = self.param_free_norm
         capped = fm != h
         if capped or (self.kind != "spade" and (h * w) % 128 != 0):
-            return self._forward_dense(x, labels, style, training, fm)
+            return self._forward_dense(x, labels, style, training, fm, grad_sink)
         shift = labels.shift_for(h)
         # ---- table path: one fused autograd node per norm
         if self.kind == "spade":
             w2a, b2 = ops.pack_gamma_beta(self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_gamma.bias,
                                           self.mlp_beta.bias)
             return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, None, b2, st.running_mean, st.running_var,
-                                           labels, shift, training, 1.0)
+                                           labels, shift, training, 1.0, grad_sink)
         zero_b = torch.zeros_like(self.mlp_style_gamma.bias)
         if self.kind == "sean":
             wg, wb = torch.sigmoid(self.alpha_gamma), torch.sigmoid(self.alpha_beta)
@@ -195,15 +197,15 @@ class SpadeNorm(nn.Module):
                                          zero_b)
             table = ops.style_table(style, ws2)
             return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, table, b2, st.running_mean, st.running_var,
-                                           labels, shift, training, 1.0)
+                                           labels, shift, training, 1.0, grad_sink)
         # puresean: out = xhat * gamma_s + beta_s
         ws2, b2 = ops.pack_gamma_beta(self.mlp_style_gamma.weight, self.mlp_style_beta.weight,
                                       self.mlp_style_gamma.bias, self.mlp_style_beta.bias)
         table = ops.style_table(style, ws2)
         return ops.SeanNormTable.apply(x, None, None, None, table, b2, st.running_mean, st.running_var, labels, shift,
-                                       training, 0.0)
+                                       training, 0.0, grad_sink)
 
-    def _forward_dense(self, x, labels, style, training, fm):
+    def _forward_dense(self, x, labels, style, training, fm, grad_sink=None):
         """General path (style map materialised as 128 gathered channels): resolutions below 16x16, and the
         reference's max_fm_size cap where the upsampled embedding replaces the style map."""
         n, h, w, c = x.shape
@@ -242,7 +244,8 @@ class SpadeNorm(nn.Module):
                                          self.mlp_style_gamma.bias, self.mlp_style_beta.bias)
             add_one = 0.0
         st = self.param_free_norm
-        return ops.SpadeNormAct.apply(x, cat, w2, b2, st.running_mean, st.running_var, training, add_one, cat_ups)
+        return ops.SpadeNormAct.apply(x, cat, w2, b2, st.running_mean, st.running_var, training, add_one, cat_ups,
+                                      grad_sink)
 
 
 class SPADEResnetBlock(nn.Module):
@@ -262,19 +265,23 @@ class SPADEResnetBlock(nn.Module):
         noisy = self.add_noise_cfg and training
         n, h0, w0, c = x.shape
         shp = (n, h0 << ups, w0 << ups, c)
+        res_noise = None
         if noisy:
             x = ops.UpNoise.apply(x, self.noise_in.weight, noise.normal_nhwc(shp, tag + ".noise_in"), ups)
-            x_s = ops.UpNoise.apply(x, self.noise_skip.weight, noise.normal_nhwc(shp, tag + ".noise_skip"), 0)
-        else:
-            if ups:
-                x = ops.UpNoise.apply(x, None, None, ups)
-            x_s = x
-        h = self.norm_0(x, labels, style, training)
-        dx = ops.conv2d(h, self.conv_0.weight(training), self.conv_0.bias)
-        if noisy:
-            dx = ops.UpNoise.apply(dx, self.noise_middle.weight, noise.normal_nhwc(shp, tag + ".noise_middle"), 0)
+            # the shortcut x_s = noise_skip(x) (architecture.py:133-134) is not materialised: conv_1's output transform
+            # adds x + w_skip * eps_skip (a replayed noise TENSOR, as in the parity tests, takes the explicit pass)
+            res_noise = (self.noise_skip.weight, noise.normal_nhwc(shp, tag + ".noise_skip"))
+        elif ups:
+            x = ops.UpNoise.apply(x, None, None, ups)
+        # x feeds norm_0 and the shortcut: the shortcut's gradient reaches x through norm_0's backward (ops.GradSink)
+        sink = ops.GradSink() if (torch.is_grad_enabled() and x.requires_grad) else None
+        h = self.norm_0(x, labels, style, training, sink)
+        # noise_middle (architecture.py:111-112) rides in conv_0's output transform
+        dx = ops.conv2d(h, self.conv_0.weight(training), self.conv_0.bias,
+                        noise=(self.noise_middle.weight, noise.normal_nhwc(shp, tag + ".noise_middle")) if noisy else None)
         h = self.norm_1(dx, labels, style, training)
-        return ops.conv2d(h, self.conv_1.weight(training), self.conv_1.bias, res=x_s, act=out_act)
+        return ops.conv2d(h, self.conv_1.weight(training), self.conv_1.bias, res=x, act=out_act, res_noise=res_noise,
+                          res_sink=sink)
 
 
 class DeepSEESR(nn.Module):

@@ -378,9 +378,12 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
     return m
 
 
-def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0, keep=None):
+def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0, keep=None,
+               noise=None, res_noise=None):
     """y = conv3x3(x, w) (transpose_flip: data gradient of that conv) through 36 Winograd-domain GEMMs.
-    `keep`: list that receives (V, amax_V) of the input when the whole batch went through in one pass."""
+    `keep`: list that receives (V, amax_V) of the input when the whole batch went through in one pass.
+    `noise` = (noise_w [r_s], PhiloxNormal of y's shape): y += noise_w * eps in the output transform;
+    `res_noise`: the same on the residual (res + w * eps is what gets added)."""
     co, ci = w.shape[0], w.shape[1]
     r_s, k_s = (cin_s, cout_s) if transpose_flip else (cout_s, cin_s)   # GEMM output / reduction channels
     rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
@@ -390,8 +393,11 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     nb = _wino_chunk(n, h, wd, max(r_s, k_s))
     for n0 in range(0, n, nb):
         m = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None, ua)
+        nz = (None, 0, 0) if noise is None else (noise[0], noise[1].seed, noise[1].offset + n0 * h * wd * r_s // 4)
+        rz = ((None, 0, 0) if res_noise is None else
+              (res_noise[0], res_noise[1].seed, res_noise[1].offset + n0 * h * wd * r_s // 4))
         L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
-               r_s, act, LRELU_SLOPE)
+               r_s, act, LRELU_SLOPE, *nz, *rz)
     return y
 
 
@@ -493,7 +499,8 @@ class Conv2d(torch.autograd.Function):
     """out = act(conv(x, w) + bias + residual); x stored [N,H,W,pad4(Cin)], w OIHW (real channel counts)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, stride, pad, ups, act):
+    def forward(ctx, x, w, bias, res, stride, pad, ups, act, noise_w=None, noise_eps=None, res_noise_w=None,
+                res_noise_eps=None, res_sink=None):
         co, ci, kh, kw = w.shape
         n, hi, wi, cin_s = x.shape
         assert cin_s == L.pad4(ci), (cin_s, ci)
@@ -511,11 +518,18 @@ class Conv2d(torch.autograd.Function):
             # the fp32 V of x is the weight gradient's Q operand: keep it instead of transforming x again (2.25x the
             # bytes of x; KEEP_V = False trades the memory back for one more transform pass)
             keep = [] if (KEEP_V and ctx.needs_input_grad[1] and _wgrad_mode(cin_s, cout_s) == 2) else None
-            out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act, keep=keep)
+            out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act, keep=keep,
+                             noise=None if noise_w is None else (noise_w, noise_eps),
+                             res_noise=None if res_noise_w is None else (res_noise_w, res_noise_eps))
             vkeep = keep[0] if keep else None
         else:
             out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act)
+        assert noise_w is None or (ctx.wino and act == L.ACT_NONE and isinstance(noise_eps, PhiloxNormal))
+        assert res_noise_w is None or (ctx.wino and res is not None and isinstance(res_noise_eps, PhiloxNormal))
         ctx.geom, ctx.act, ctx.has_bias, ctx.has_res = geom, act, bias is not None, res is not None
+        ctx.noise = noise_eps if noise_w is not None else None
+        ctx.res_noise = res_noise_eps if res_noise_w is not None else None
+        ctx.res_sink = res_sink
         ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None, *(vkeep if vkeep else (None, None)))
         return out
 
@@ -565,12 +579,66 @@ class Conv2d(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = channel_dot(g, None, co).clone()
         if ctx.has_res and ctx.needs_input_grad[3]:
-            dres = g
-        return dx, dw, db, dres, None, None, None, None
+            if ctx.res_sink is not None:
+                ctx.res_sink.put(g)      # picked up as the `add` operand of the norm backward that also feeds on `res`
+            else:
+                dres = g
+
+        def noise_wgrad(eps):
+            cn = g.shape[-1]
+            mrows = g.numel() // cn
+            d = new(cn)
+            L.call("channel_dot_rng", g, d, mrows, cn, scratch(L.lib().dsee_channel_dot_workspace(mrows, cn), "chdot"),
+                   eps.seed, eps.offset)
+            return d
+
+        dnw = noise_wgrad(ctx.noise) if (ctx.noise is not None and ctx.needs_input_grad[8]) else None
+        drnw = noise_wgrad(ctx.res_noise) if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None
+        return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None
 
 
-def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE):
-    return Conv2d.apply(x, w, bias, res, stride, pad, ups, act)
+class GradSink:
+    """One-slot mailbox between two autograd nodes of a resblock: the convolution that consumes `x` as its residual puts
+    the residual's gradient here instead of returning it, and the backward of the normalisation that ALSO consumes `x`
+    (it runs later: its own incoming gradient depends on that convolution's data gradient) adds it to its dx in the
+    same pass -- the autograd engine's separate fan-in addition (3 full-tensor passes) never runs."""
+
+    def __init__(self):
+        self.g = None
+
+    def put(self, g):
+        assert self.g is None, "gradient sink not drained (backward re-entered?)"
+        self.g = g
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
+# NoiseInjection draws regenerated inside the consumer's output transform (DSEE_FUSE_NOISE=0: stand-alone UpNoise passes)
+FUSE_NOISE = os.environ.get("DSEE_FUSE_NOISE", "1") != "0"
+
+
+def _fusable_noise(x, w, stride, pad, ups, eps):
+    n, hi, wi, cin_s = x.shape
+    return (FUSE_NOISE and isinstance(eps, PhiloxNormal) and w.shape[2] == 3 and w.shape[0] > 4
+            and _wino_ok(n, hi, wi, cin_s, L.pad4(w.shape[0]), 3, stride, pad, ups))
+
+
+def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, noise=None, res_noise=None, res_sink=None):
+    """`noise` = (noise_w, eps): the NoiseInjection that follows the conv; `res_noise` = (noise_w, eps): the
+    NoiseInjection on the residual (the shortcut x_s = noise_skip(x)).  PhiloxNormal draws on a Winograd layer ride in
+    the output transform; anything else (a replayed tensor, a non-Winograd layer) runs as its own UpNoise pass.
+    `res_sink` (GradSink): the residual's gradient is handed to the norm backward instead of the autograd engine."""
+    if res_noise is not None and not _fusable_noise(x, w, stride, pad, ups, res_noise[1]):
+        # (the shortcut's own node must see its gradient: no sink)
+        res, res_noise, res_sink = UpNoise.apply(res, res_noise[0], res_noise[1], 0), None, None
+    rn = (None, None) if res_noise is None else res_noise
+    if noise is None or (_fusable_noise(x, w, stride, pad, ups, noise[1]) and act == L.ACT_NONE):
+        nz = (None, None) if noise is None else noise
+        return Conv2d.apply(x, w, bias, res, stride, pad, ups, act, nz[0], nz[1], rn[0], rn[1], res_sink)
+    y = Conv2d.apply(x, w, bias, res, stride, pad, ups, act, None, None, rn[0], rn[1], res_sink)
+    return UpNoise.apply(y, noise[0], noise[1], 0)
 
 
 # ------------------------------------------------------------------------------------ spectral norm
@@ -821,7 +889,7 @@ def bn_stats(x, running_mean, running_var, training):
 FUSE_DM = os.environ.get("DSEE_FUSE_DM", "1") != "0"
 
 
-def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False):
+def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=None):
     """Backward of BN + modulate + LeakyReLU: (dx, dgb, col_sums [2][C], dM).  With SyncBN (`cfg`) the two per-channel
     sums of the BN backward are all-reduced over the ranks between the reduce and the apply pass.  `as_dm`: the
     gamma/beta gradient leaves the reduce pass as dM = A (g*xhat | g) A^T [36][T][rows] (dgb is None)."""
@@ -844,8 +912,8 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False):
         from . import parallel
         parallel.allreduce_sums(sums[0:2], cfg.world, cfg.group)
         count *= cfg.world
-    L.call("modulate_bwd_apply", dh.contiguous(), out, x, scale, mean, invstd, sums, None, dx, n, h * w, c, 1.0 / count,
-           LRELU_SLOPE)
+    L.call("modulate_bwd_apply", dh.contiguous(), out, x, scale, mean, invstd, sums, add, dx, n, h * w, c, 1.0 / count,
+           LRELU_SLOPE)          # dx += add: the gradient of the other consumer of x (the resblock shortcut)
     return dx, dgb, sums[2:4], dm
 
 
@@ -854,7 +922,8 @@ class SpadeNormAct(torch.autograd.Function):
     epilogue; BN = sync-free batch statistics in training, running statistics in eval."""
 
     @staticmethod
-    def forward(ctx, x, cat, w2, b2, running_mean, running_var, training, add_one, cat_ups):
+    def forward(ctx, x, cat, w2, b2, running_mean, running_var, training, add_one, cat_ups, grad_sink=None):
+        ctx.grad_sink = grad_sink
         n, h, w, c = x.shape
         rows, kin = w2.shape[0], w2.shape[1]
         assert cat.shape[3] == kin and kin % 4 == 0
@@ -877,7 +946,8 @@ class SpadeNormAct(torch.autograd.Function):
         geom = ctx.geom
         n, h, w, c = x.shape
         rows, kin = w2.shape[0], w2.shape[1]
-        dx, dgb, cs, _ = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync)
+        add = ctx.grad_sink.take() if ctx.grad_sink is not None else None
+        dx, dgb, cs, _ = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync, add=add)
         dcat = dw2 = db2 = None
         if ctx.needs_input_grad[1]:
             gd = L.geom_dgrad(geom)
@@ -892,7 +962,7 @@ class SpadeNormAct(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             idx, _ = packed_perm(c, x.device)
             db2 = torch.cat([cs.reshape(-1), torch.zeros(1, device=x.device)]).index_select(0, idx)
-        return dx, dcat, dw2, db2, None, None, None, None, None
+        return dx, dcat, dw2, db2, None, None, None, None, None, None
 
 
 class SeanNormTable(torch.autograd.Function):
@@ -905,7 +975,9 @@ class SeanNormTable(torch.autograd.Function):
     gradient rows.  `table` None -> SPADE (128 channels); `w2a` None -> PureSEAN (one-hot only)."""
 
     @staticmethod
-    def forward(ctx, x, w_sh, b_sh, w2a, table, b2, running_mean, running_var, labels, shift, training, add_one):
+    def forward(ctx, x, w_sh, b_sh, w2a, table, b2, running_mean, running_var, labels, shift, training, add_one,
+                grad_sink=None):
+        ctx.grad_sink = grad_sink
         n, h, w, c = x.shape
         nc = labels.nc
         has_a, has_t = w2a is not None, table is not None
@@ -974,7 +1046,8 @@ class SeanNormTable(torch.autograd.Function):
         # every consumer of the gamma/beta gradient reads dM: let the norm backward write it directly
         as_dm = (FUSE_DM and wino_w and nb == n and _wgrad_mode(ld, rows) != 1 and (fused_d or not ctx.has_a)
                  and 256 % (c // 4) == 0)
-        dx, dgb, cs, dm_all = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync, as_dm)
+        add = ctx.grad_sink.take() if ctx.grad_sink is not None else None
+        dx, dgb, cs, dm_all = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync, as_dm, add)
 
         def wino_wgrad():
             dw2a = dtable = None
@@ -1066,7 +1139,7 @@ class SeanNormTable(torch.autograd.Function):
         if ctx.needs_input_grad[5]:
             idx, _ = packed_perm(c, x.device)
             db2 = torch.cat([cs.reshape(-1), torch.zeros(1, device=x.device)]).index_select(0, idx)
-        return dx, dw_sh, db_sh, dw2a, dtable, db2, None, None, None, None, None, None
+        return dx, dw_sh, db_sh, dw2a, dtable, db2, None, None, None, None, None, None, None
 
 
 class _StyleGemm(torch.autograd.Function):

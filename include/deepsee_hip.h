@@ -83,8 +83,14 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
  *   y = dsee_wino43_output(M, bias, residual, act)
  * with U = dsee_wino43_weights(w, transpose_flip = 0) (forward) or 1 (data gradient of the same conv). */
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, float* amax, hipStream_t stream);
+/* noise_w != NULL: y += noise_w[c] * eps, eps = the Philox N(0,1) stream (noise_seed, noise_offset) of dsee_rng_fill in
+ * NHWC element order -- the NoiseInjection that follows the conv (architecture.py:111-112) fused into its epilogue.
+ * res_noise_w != NULL: the residual is residual + res_noise_w[c] * eps' (stream res_noise_seed / _offset) -- the resblock
+ * shortcut x_s = noise_skip(x) (architecture.py:133-134,127) regenerated from x instead of read from its own tensor. */
 int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
-                       int H, int W, int C, int act, float slope, hipStream_t stream);
+                       int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
+                       uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
+                       uint64_t res_noise_offset, hipStream_t stream);
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
                         const float* amax_w, hipStream_t stream);
 /* fp32-accurate GEMM on the bf16 matrix cores (operands split into three bf16 terms by their producers, six MFMA

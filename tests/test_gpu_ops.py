@@ -529,3 +529,76 @@ def test_benchmark_shape_norm_vs_float64(kind):
           "gradients worst %.1e (%s), dx %.1e" % (kind, fwd, flips, errs[worst], worst, errs["dx"]))
     assert fwd < 1e-4 and flips < 1e-4
     assert errs[worst] < 1e-3, errs
+
+
+def test_conv_noise_fused_in_output_transform():
+    """noise_middle (architecture.py:111-112) fused into the Winograd output transform of conv_0: same values as the
+    convolution followed by the stand-alone UpNoise pass on the same Philox stream, same gradients for the input, the
+    weights and the noise weight."""
+    from deepsee_amd import ops
+    g = gen(41)
+    n, c, h = 2, 128, 32
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    b, nw, gy = torch.randn(c, generator=g), torch.randn(c, generator=g), torch.randn(n, c, h, h, generator=g)
+    eps = ops.PhiloxNormal((n, h, h, c), 4242, 1000)
+    outs = []
+    for fused in (True, False):
+        xd = nhwc(x).requires_grad_()
+        wd, bd, nd = w.cuda().requires_grad_(), b.cuda().requires_grad_(), nw.cuda().requires_grad_()
+        if fused:
+            y = ops.conv2d(xd, wd, bd, noise=(nd, eps))
+            assert y.grad_fn.__class__.__name__.startswith("Conv2d")       # one node: no separate UpNoise pass
+        else:
+            y = ops.UpNoise.apply(ops.conv2d(xd, wd, bd), nd, eps, 0)
+        y.backward(nhwc(gy))
+        outs.append([t.detach().cpu() for t in (y, xd.grad, wd.grad, bd.grad, nd.grad)])
+    torch.cuda.synchronize()
+    for a, r in zip(*outs):
+        assert rel(a, r) < 1e-6
+    # and the noise really is N(0,1) * nw on top of the convolution
+    y0 = ops.conv2d(nhwc(x), w.cuda(), b.cuda())
+    z = (outs[0][0] - y0.cpu()) / nw.view(1, 1, 1, c)
+    assert abs(float(z.mean())) < 2e-2 and abs(float(z.std()) - 1.0) < 2e-2
+
+
+@pytest.mark.parametrize("kind,ups", [("sean", 0), ("spade", 1)])
+def test_resblock_fused_noise_shortcut_and_gradient_sink(kind, ups):
+    """A whole SPADEResnetBlock with the production noise source (Philox draws regenerated in registers: noise_middle in
+    conv_0's output transform, the shortcut x + w_skip * eps in conv_1's, the shortcut's gradient folded into norm_0's
+    backward through ops.GradSink) against the same block fed the SAME draws as explicit tensors (every fusion off:
+    separate UpNoise passes, autograd's own fan-in addition)."""
+    from types import SimpleNamespace
+    from deepsee_amd import ops, networks as Nw, lib as L
+    g = gen(17 + ups)
+    n, c, r, Lc = 2, 128, 64, 19
+    opt = SimpleNamespace(add_noise=True, semantic_nc=Lc, regional_style_size=128, max_fm_size=256)
+    blk = Nw.SPADEResnetBlock(c, opt, kind)
+    st = {k: O.recipe_tensor("rb_" + kind, k, v.shape, 1.0) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(st)
+    blk.cuda()
+    label = F.interpolate(torch.randint(0, Lc, (n, 1, 16, 16), generator=g).float(), size=(256, 256), mode="nearest")
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
+    x0 = torch.randn(n, c, r >> ups, r >> ups, generator=g)
+    style = torch.rand(n, Lc, 128, generator=g) * 2 - 1
+    gy = torch.randn(n, c, r, r, generator=g)
+
+    class Tensors(Nw.DeviceNoise):          # same Philox positions, handed out as materialised tensors
+        def normal_nhwc(self, shape, tag):
+            return super().normal_nhwc(shape, tag).materialize()
+
+    res = []
+    for src in (Nw.DeviceNoise(seed=5), Tensors(seed=5)):
+        blk.load_state_dict(st)           # (a forward advances the spectral-norm u / v and the BN running statistics)
+        blk.zero_grad()
+        xd = nhwc(x0).requires_grad_()
+        sd = style.cuda().requires_grad_()
+        y = blk(xd, labels, sd, src, "b", ups, True, L.ACT_LRELU)
+        y.backward(nhwc(gy))
+        res.append([y.detach().cpu(), xd.grad.cpu(), sd.grad.cpu() if sd.grad is not None else torch.zeros(1)] +
+                   [p.grad.detach().cpu().clone() for _, p in sorted(blk.named_parameters()) if p.grad is not None])
+    torch.cuda.synchronize()
+    assert len(res[0]) == len(res[1]) and len(res[0]) > 10
+    for a, b in zip(*res):
+        assert rel(a, b) < 2e-5, (a.shape, rel(a, b))
+    assert float(res[0][-1].abs().max()) > 0
