@@ -18,6 +18,13 @@
 
 #include "dsee_common.h"
 
+// Measurement builds only (tools/exp/build_abl.sh compiles this file with -DDSEE_GEMM_ABL=<mask> into separate
+// libraries): bit 1 no MFMAs, 2 no fragment reads, 4 no fp32 -> split conversion, 8 no LDS-DMA, 16 no C stores.
+// The shipped library is built without the macro: none of this exists in it.
+#ifndef DSEE_GEMM_ABL
+#define DSEE_GEMM_ABL 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -343,7 +350,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   constexpr int F32_STAGE = BM * 64;                     // bytes of one fp32 A stage
   constexpr int IMG = (SA * 16 + 255) / 256 * 256;       // bytes of one split A image
   constexpr int BST = NB * 1024;                         // bytes of one B stage
-  constexpr int OFF_IMG = 2 * F32_STAGE, OFF_B = OFF_IMG + 2 * IMG;
+  // The fp32 A rows come from HBM (B mostly from L2).  fp16x2: they are requested THREE slabs ahead into a ring of
+  // NFS = 3 fp32 stages, B two slabs ahead into a ring of three stages -- two A slabs are in flight while a third is being
+  // converted (with one in flight the kernel was bound by bytes-in-flight x latency at ~2.5 TB/s, not by HBM or the
+  // matrix cores).  bf16x3 (6-byte images: no LDS left for a third stage) keeps NFS = 2.
+  constexpr int NFS = TERMS == 2 ? 3 : 2;
+  constexpr int OFF_IMG = NFS * F32_STAGE, OFF_B = OFF_IMG + 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -380,38 +392,52 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   const int nk = a.K / 16;
   const long sb_ = a.b_slab_bytes;
 
-  long lt = blockIdx.x;
-  int lk = 0, bvalid = 0, avalid = 0;
+  // two independent slab streams (A runs one slab further ahead than B), each walking the block's tile list
+  long lta = blockIdx.x, ltb = blockIdx.x;
+  int lka = 0, lkb = 0, bvalid = 0, avalid = 0;
   const unsigned char *pa = a.A, *pb = a.B;
-  auto load_base = [&]() {
+  auto base_a = [&]() {
     long z, bm;
     int bn;
-    const bool live = lt < ntile;
-    decode(live ? lt : (long)blockIdx.x, z, bm, bn);
-    const long group = (bm * BM) / a.rows_per_group;
+    const bool live = lta < ntile;
+    decode(live ? lta : (long)blockIdx.x, z, bm, bn);
     pa = uniform_ptr(a.A + bm * BM * arow);
+    avalid = __builtin_amdgcn_readfirstlane(live ? (int)min((long)BM * arow, 0x7FFFFFFFL) : 0);  // past the end: zeros
+  };
+  auto base_b = [&]() {
+    long z, bm;
+    int bn;
+    const bool live = ltb < ntile;
+    decode(live ? ltb : (long)blockIdx.x, z, bm, bn);
+    const long group = (bm * BM) / a.rows_per_group;
     pb = uniform_ptr(a.B + group * a.b_group_bytes + (long)bn * BN * I::ROWB);
     bvalid = __builtin_amdgcn_readfirstlane(live ? min(BN, a.N - bn * BN) * I::ROWB : 0);
-    avalid = __builtin_amdgcn_readfirstlane(live ? (int)min((long)BM * arow, 0x7FFFFFFFL) : 0);
   };
-  auto issue = [&](int fstage, int bstage) {
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lk * 64), 0, avalid, 0x00020000);
-    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * sb_), 0, bvalid, 0x00020000);
+  auto issue_a = [&](int fstage) {
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lka * 64), 0, avalid, 0x00020000);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       auto* dst = (__attribute__((address_space(3))) void*)(smem + fstage * F32_STAGE + (wave + NW * jj) * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
     }
+    if (++lka == nk) {
+      lka = 0;
+      lta += G;
+      base_a();
+    }
+  };
+  auto issue_b = [&](int bstage) {
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lkb * sb_), 0, bvalid, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NIB; ++j)
       if (j + 1 < NIB || has_last) {
         auto* dst = (__attribute__((address_space(3))) void*)(smem + OFF_B + bstage * BST + (wave + NW * j) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, voffb[j], 0, 0, 0);
       }
-    if (++lk == nk) {
-      lk = 0;
-      lt += G;
-      load_base();
+    if (++lkb == nk) {
+      lkb = 0;
+      ltb += G;
+      base_b();
     }
   };
   // conversion of this wave's 32 rows of fp32 stage `fstage` into image `img`: lane = (instruction jj = lane>>5, row
@@ -429,11 +455,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 #pragma unroll
     for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
   };
-  auto wait_own = [&]() {  // everything but this wave's newest slab has landed
+  // Per interval every wave issues B(k+2) then A(k+NFS); vmcnt retires in issue order, so "everything up to B(k+1)" --
+  // which includes A(k+1) -- has landed once at most the younger [A(k+2),] B(k+2), A(k+NFS) remain outstanding:
+  // 2 (NFS - 1) + (this wave's B instructions per slab).
+  auto wait_own = [&]() {
     if (has_last)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NIB) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NFS - 1) + NIB) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + NIB) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NFS - 1) + NIB - 1) : "memory");
   };
 
   f32x16 acc[MT][NT];
@@ -449,74 +478,159 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   const unsigned fb = (unsigned)((I::CH * rb0 + I::pad(rb0) + (lane >> 5)) * 16);
   constexpr int TSTEP = I::TSTEP;
 
-  load_base();
-  issue(0, 0);
-  issue(1, 1);
-  wait_own();
+  base_a();
+  base_b();
+  issue_b(0);   // slab 0
+  issue_a(0);
+  issue_b(1);   // slab 1
+  issue_a(1);
+  if constexpr (NFS == 3) issue_a(2);   // slab 2 (A only: one further ahead)
+  wait_own();   // slab 0 landed (B(1), A(1)[, A(2)] may still be in flight)
   asm volatile("" ::: "memory");
   convert(0, 0);
-  int par = 0, bcur = 0, bnxt = 2, ck = 0;  // slab parity (fp32 stage / image), B stage being computed / to fill
+  // slab parity (image), fp32 stage of the NEXT slab to convert / of the slab to request, B stage computed / to fill
+  int par = 0, fcv = 1, fis = 0, bcur = 0, bnxt = 2, ck = 0;
   long ct = blockIdx.x;
-  for (;;) {
+  auto store_tile = [&]() {
+    long z, bm;
+    int bn;
+    decode(ct, z, bm, bn);
+    float* cz = a.C + z * a.c_z_elems;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const long mb = bm * BM + wm * MT * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
+        if (n < a.N && (!(DSEE_GEMM_ABL & 16) || acc[i][j][0] == 12345.678f))
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r];
+            if constexpr (TERMS == 2) v *= oscale;
+            cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = v;
+          }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+    }
+  };
+  if constexpr (NW == 8) {
+    // ---- ping-pong: the two waves of every SIMD (w and w + 4) run half a slab apart.  A slab is two barrier intervals:
+    // in its L interval a wave reads its fragments, issues the LDS-DMA of slab k+2 and converts its own fp32 rows of
+    // slab k+1; in its M interval it only issues its 3 * MT * NT MFMAs.  While group 0 is in M(k), group 1 is in L(k): the
+    // matrix pipe of a SIMD always has exactly one wave feeding it and the LDS / VALU / DMA work of the other wave hides
+    // under it (lock-stepped, both waves of a SIMD did the same thing at the same time and nothing overlapped).
+    // Hazards: image / B stage of slab k are complete before the barrier that opens I(2k) (conversions and vmcnt waits
+    // of slab k sit in L(k-1), i.e. in I(2k-2) / I(2k-1)); image (k+1)%2 and B stage (k+2)%3 are rewritten in L(k), after
+    // their last readers L(k-1) of both groups.
+    const bool late = wave >= 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const unsigned char* sa_ = smem + OFF_IMG + par * IMG;
-    const unsigned char* sb = smem + OFF_B + bcur * BST;
-    u32x4 af[MT][TERMS];
+    if (late) __builtin_amdgcn_s_barrier();
+    for (;;) {
+      // ---- L interval
+      const unsigned char* sa_ = smem + OFF_IMG + par * IMG;
+      const unsigned char* sb = smem + OFF_B + bcur * BST;
+      u32x4 af[MT][TERMS], bf[NT][TERMS];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < TERMS; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      u32x4 bf[TERMS];
-#pragma unroll
-      for (int p = 0; p < TERMS; ++p) bf[p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
-      if (j == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        issue(par, bnxt);  // fp32 stage `par` was converted one iteration ago (by this wave); B stage bnxt is free
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) mfma_terms<TERMS>(af[i], bf, acc[i][j]);
-    }
-    // next slab: its fp32 rows (this wave's own) and B chunks have been in flight for a whole iteration
-    __builtin_amdgcn_sched_barrier(0);
-    wait_own();
-    asm volatile("" ::: "memory");
-    convert(par ^ 1, par ^ 1);
-    par ^= 1;
-    bcur = bcur == 2 ? 0 : bcur + 1;
-    bnxt = bnxt == 2 ? 0 : bnxt + 1;
-    ++ck;
-    if (ck < nk) continue;
-    {
-      long z, bm;
-      int bn;
-      decode(ct, z, bm, bn);
-      float* cz = a.C + z * a.c_z_elems;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const long mb = bm * BM + wm * MT * 32 + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
-          if (n < a.N)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float v = acc[i][j][r];
-              if constexpr (TERMS == 2) v *= oscale;
-              cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = v;
-            }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int p = 0; p < TERMS; ++p) {
+          if constexpr (DSEE_GEMM_ABL & 2) af[i][p] = (u32x4){(unsigned)ck, 1u, 2u, (unsigned)lane};
+          else af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
         }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) {
+          if constexpr (DSEE_GEMM_ABL & 2) bf[j][p] = (u32x4){(unsigned)ck, 3u, 4u, (unsigned)lane};
+          else bf[j][p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(DSEE_GEMM_ABL & 8)) {
+        issue_b(bnxt);   // slab k+2
+        issue_a(fis);    // slab k+3, into the fp32 stage this wave converted in its previous L interval
       }
+      __builtin_amdgcn_sched_barrier(0);
+      wait_own();
+      asm volatile("" ::: "memory");
+      if constexpr (!(DSEE_GEMM_ABL & 4)) convert(fcv, par ^ 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ---- M interval
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if constexpr (DSEE_GEMM_ABL & 1) {
+#pragma unroll
+            for (int p = 0; p < TERMS; ++p) acc[i][j][p] += __builtin_bit_cast(float, af[i][p][0] ^ bf[j][p][1]);
+          } else {
+            mfma_terms<TERMS>(af[i], bf[j], acc[i][j]);
+          }
+        }
+      __builtin_amdgcn_s_setprio(0);
+      par ^= 1;
+      fcv = fcv == NFS - 1 ? 0 : fcv + 1;
+      fis = fis == NFS - 1 ? 0 : fis + 1;
+      bcur = bcur == 2 ? 0 : bcur + 1;
+      bnxt = bnxt == 2 ? 0 : bnxt + 1;
+      if (++ck == nk) {
+        store_tile();
+        ck = 0;
+        ct += G;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ct >= ntile) break;
     }
-    ck = 0;
-    ct += G;
-    if (ct >= ntile) break;
+    if (!late) __builtin_amdgcn_s_barrier();
+  } else {
+    for (;;) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned char* sa_ = smem + OFF_IMG + par * IMG;
+      const unsigned char* sb = smem + OFF_B + bcur * BST;
+      u32x4 af[MT][TERMS];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        u32x4 bf[TERMS];
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) bf[p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
+        if (j == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_b(bnxt);  // slab k+2: B stage bnxt is free
+          issue_a(fis);   // slab k+3: fp32 stage `fis` was converted one iteration ago (by this wave)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mfma_terms<TERMS>(af[i], bf, acc[i][j]);
+      }
+      // next slab: its fp32 rows (this wave's own) and B chunks have been in flight for at least a whole iteration
+      __builtin_amdgcn_sched_barrier(0);
+      wait_own();
+      asm volatile("" ::: "memory");
+      convert(fcv, par ^ 1);
+      par ^= 1;
+      fcv = fcv == NFS - 1 ? 0 : fcv + 1;
+      fis = fis == NFS - 1 ? 0 : fis + 1;
+      bcur = bcur == 2 ? 0 : bcur + 1;
+      bnxt = bnxt == 2 ? 0 : bnxt + 1;
+      ++ck;
+      if (ck < nk) continue;
+      store_tile();
+      ck = 0;
+      ct += G;
+      if (ct >= ntile) break;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -760,7 +874,7 @@ int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int NB = (I::slots(BN) + 63) / 64;
   constexpr int IMG = (I::slots(BM) * 16 + 255) / 256 * 256;
-  const size_t lds = (size_t)2 * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
+  const size_t lds = (size_t)(TERMS == 2 ? 3 : 2) * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS>),
