@@ -1,20 +1,26 @@
 #!/usr/bin/env python
 """Benchmark of the DeepSEE G+D training step on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" = TrainerManager.run_generator_one_step + run_discriminator_one_step (train.py:40-44) on one synthetic
-batch that is already resident in HBM: independent 8x 32->256, 19-class blocky masks, bs=8 per GPU, fp32
-(BASELINE.json configs[1]; weak scaling: the per-GPU batch is fixed as N grows).  Rank 0 prints ONE JSON line.
+batch that is already resident in HBM.  Default workload: independent 8x 32->256, 19-class blocky masks, bs=8 per
+GPU, fp32 (BASELINE.json configs[1]; weak scaling: the per-GPU batch is fixed as N grows).  `--config` selects the
+other BASELINE configurations (guided_8x_256 = configs[3], independent_32x_512 = configs[4]) for separate lines.
+`python bench.py --gpus N` without a launcher starts the N ranks itself.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline     — the dominant kernel (by summed time in a step), measured live with HIP events on the launch
-                 stream in one extra instrumented step after the timed region: algorithmic fp32 FLOPs (2*M*N*K of
-                 every launch of that kernel) / summed duration.  Peak: 157.3 TFLOP/s for the v_mfma_f32 kernels;
-                 for the bf16x3 kernels (fp32 multiply = 6 exact bf16 MFMA products, deepsee_amd/csrc/gemm_bf16x3.hip)
-                 the dense bf16 MFMA peak / 6 = 419.4 TFLOP/s of fp32 work.
+                 stream in one extra instrumented step after the timed region.  Both of its rooflines are computed:
+                 matrix cores (algorithmic fp32 FLOPs = 2*M*N*K of every launch / summed duration, against the peak of
+                 its arithmetic: 157.3 TFLOP/s for v_mfma_f32; dense bf16/fp16 MFMA peak / 6 for bf16x3, / 3 for fp16x2,
+                 deepsee_amd/csrc/gemm_bf16x3.hip) and HBM (algorithmic bytes / summed duration against 8 TB/s); `bound`
+                 / `frac` are the one it sits closer to.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
+                 (profiles/r02_pmc_traffic.json, provenance in `traffic_source`).
+  spade_fused  — the HBM-bound fused SPADE/SEAN kernel north_star's 70 % target names (output transform of the
+                 gamma/beta GEMM + BN-normalise + modulate + LeakyReLU): bytes it moves / its time against 8 TB/s.
   f32_mfma_only— the same step with every GEMM kept on v_mfma_f32_32x32x2_f32 (DSEE_F32_MFMA=1 path), rank 0 / N=1.
   cpu_baseline — the oracle (CPU restatement of the reference path, oracle/deepsee_oracle.py) timed on this box's
                  host cores: one G+D iteration at bs=1 of the same workload (rank 0, N=1 only).
@@ -32,34 +38,44 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
-BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense (same guide); a bf16x3 fp32 multiply-add costs 6 bf16 MFMA products
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md
+F16_MFMA_PEAK_TFLOPS = 2516.6   # dense bf16 / fp16 MFMA (same guide)
+HBM_PEAK_GBPS = 8000.0          # HBM3E spec (same guide; ~6.3 TB/s achievable by a float4 copy)
 
-
-# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --steps 2 --warmup 1` (372 launches of the kernel):
-# FETCH_SIZE 0.2816 GB reported -> x2 (gfx950 correction, MI355X_MICROARCH.md) = 0.563 GB, WRITE_SIZE 0.546 GB per launch
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {"winograd_gemm_bf16x3": 1.109e9}
+CONFIGS = {
+    # name: (preset, per-GPU batch, BASELINE.json reference)
+    "independent_8x_256": ("independent_8x_256", 8, "configs[1]"),
+    "guided_8x_256": ("guided_8x_256", 8, "configs[3]"),
+    "independent_32x_512": ("independent_32x_512", 1, "configs[4]"),
+}
 
 
 def kernel_peak(name):
-    """fp32-equivalent peak of a kernel: an fp32 multiply-add costs 6 bf16 MFMA products (bf16x3), 3 fp16 MFMA products
-    (fp16x2, same MFMA rate) or one v_mfma_f32 product."""
+    """fp32-equivalent matrix-core peak of a kernel: an fp32 multiply-add costs 6 bf16 MFMA products (bf16x3), 3 fp16
+    MFMA products (fp16x2, same MFMA rate) or one v_mfma_f32 product."""
     if "bf16x3" in name:
-        return BF16_MFMA_PEAK_TFLOPS / 6.0
+        return F16_MFMA_PEAK_TFLOPS / 6.0
     if "f16x2" in name:
-        return BF16_MFMA_PEAK_TFLOPS / 3.0
+        return F16_MFMA_PEAK_TFLOPS / 3.0
     return FP32_MFMA_PEAK_TFLOPS
-N_PER_GPU = 8
 
 
 def synthetic_batch(opt, n, seed, device):
     """blocky 19-class label map (16x16 cells, nearest-upsampled) + uniform [-1,1] image."""
     g = torch.Generator().manual_seed(seed)
     h = opt.crop_size
-    cells = torch.randint(0, opt.label_nc, (n, 1, 16, 16), generator=g).float()
-    label = torch.nn.functional.interpolate(cells, size=(h, h), mode="nearest")
-    image = torch.rand(n, 3, h, h, generator=g) * 2 - 1
-    return {"label": label.to(device), "image": image.to(device)}
+
+    def pair():
+        cells = torch.randint(0, opt.label_nc, (n, 1, 16, 16), generator=g).float()
+        label = torch.nn.functional.interpolate(cells, size=(h, h), mode="nearest")
+        image = torch.rand(n, 3, h, h, generator=g) * 2 - 1
+        return label.to(device), image.to(device)
+
+    label, image = pair()
+    out = {"label": label, "image": image}
+    if getattr(opt, "guiding_style_image", False):
+        out["guiding_label"], out["guiding_image"] = pair()
+    return out
 
 
 def effective_cores():
@@ -110,14 +126,25 @@ def spawn_ranks(n):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (counters cannot be read live)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(path):
+        rec = json.load(open(path)).get(kernel)
+        if rec:
+            return rec["bytes_per_launch"], "profiles/r02_pmc_traffic.json: %s" % rec["source"]
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="independent_8x_256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-run", action="store_true", help="skip the extra v_mfma_f32-only measurement")
-    ap.add_argument("--batch-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--batch-per-gpu", type=int, default=0)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -131,9 +158,14 @@ def main():
     if world != args.gpus:   # never report a number for a world size other than the one asked for
         raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local)
-    n = args.batch_per_gpu
-    opt = make_opt("independent_8x_256", batchSize=n, seed=0)
-    tm = TrainerManager(opt)                # encoder-branch coins: DeviceNoise's own RNG, identical on every rank
+    preset, n_default, ref = CONFIGS[args.config]
+    n = args.batch_per_gpu or n_default
+    headline = args.config == "independent_8x_256"
+    opt = make_opt(preset, batchSize=n, seed=0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)   # (the no-pretrained-VGG notice: synthetic benchmark)
+        tm = TrainerManager(opt)            # encoder-branch coins: DeviceNoise's own RNG, identical on every rank
     parallel.attach(tm, world)              # gradient all-reduce hooks, rank-0 broadcast, per-rank noise seed
     batch = synthetic_batch(opt, n, 1234 + rank, dev)
 
@@ -160,7 +192,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    # ---- one extra instrumented step: per-launch HIP events around every MFMA conv kernel
+    # ---- one extra instrumented step: per-launch HIP events around every MFMA kernel and the fused SPADE kernel
     ops.PROFILE = {}
     ops.PROFILE_BYTES.clear()
     step()
@@ -169,15 +201,19 @@ def main():
     kernels = {}
     for name, recs in prof.items():
         ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-        kernels[name] = {"launches": len(recs), "ms": ms, "tflop": sum(f for _, _, f in recs) / 1e12}
+        kernels[name] = {"launches": len(recs), "ms": ms, "tflop": sum(f for _, _, f in recs) / 1e12,
+                         "gb": ops.PROFILE_BYTES.get(name, 0.0) / 1e9}
+    fused = kernels.pop("spade_modulate_fused", None)
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     kd = kernels[dom]
-    achieved = kd["tflop"] / (kd["ms"] / 1e3)
+    tf = kd["tflop"] / (kd["ms"] / 1e3)
+    gbps = kd["gb"] / (kd["ms"] / 1e3) if kd["gb"] else 0.0
     peak = kernel_peak(dom)
+    f_mfma, f_hbm = tf / peak, gbps / HBM_PEAK_GBPS
     mfma_ms = sum(k["ms"] for k in kernels.values())
 
     f32_only = None
-    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run:
+    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run and headline:
         ops.GEMM_SPLIT = False
         step()
         fence()
@@ -188,49 +224,66 @@ def main():
         dt = (time.perf_counter() - t1) / 3
         ops.GEMM_SPLIT = True
         f32_only = {"value": n / dt, "unit": "img/s", "ms_per_step": dt * 1e3, "steps": 3,
-                    "note": "same step, Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 instead of bf16x3"}
+                    "note": "same step, Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 instead of split operands"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        kind = "f16x2" if (ops.GEMM_SPLIT and ops.GEMM_F16X2) else ("bf16x3" if ops.GEMM_SPLIT else "f32")
+        arithmetic = {
+            "f16x2": "fp32 storage and accumulation; the wide 3x3 layers run as Winograd F(4x4,3x3) GEMMs on the fp16 "
+                     "matrix cores: every fp32 operand is scaled by an exact power of two and split into two fp16 terms "
+                     "(residual <= 2^-22, rms 2^-24), 3 MFMA products per multiply-add, fp32 accumulate; error vs float64 "
+                     "equal to a CPU sgemm's (tests/test_gpu_conv.py::test_gemm_f16x2_is_fp32_accurate); DSEE_BF16X3=1 "
+                     "selects the exact 3-term bf16 split (6 products)",
+            "bf16x3": "fp32 storage and accumulation; Winograd-domain GEMMs from exact 3-term bf16 operand splits (6 bf16 "
+                      "MFMA products)",
+            "f32": "fp32 (v_mfma_f32_32x32x2_f32)"}[kind]
+        traffic, traffic_src = pmc_traffic(dom)
+        roof = {"bound": "mfma" if f_mfma >= f_hbm else "hbm", "kernel": dom,
+                "achieved": tf if f_mfma >= f_hbm else gbps, "peak": peak if f_mfma >= f_hbm else HBM_PEAK_GBPS,
+                "unit": "TFLOP/s" if f_mfma >= f_hbm else "GB/s", "frac": max(f_mfma, f_hbm),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "mfma": {"achieved_tflops_fp32_equiv": tf, "peak": peak, "frac": f_mfma,
+                         "peak_note": "%.1f dense fp16/bf16 MFMA TFLOP/s / %d products per fp32 multiply-add"
+                                      % (F16_MFMA_PEAK_TFLOPS, round(F16_MFMA_PEAK_TFLOPS / peak)) if peak > 200
+                         else "v_mfma_f32 dense peak"},
+                "hbm": {"achieved_gbps_algorithmic": gbps, "peak": HBM_PEAK_GBPS, "frac": f_hbm},
+                "launches_per_step": kd["launches"], "avg_launch_ms": kd["ms"] / kd["launches"],
+                "algorithmic_gb_per_launch": (kd["gb"] / kd["launches"]) or None,
+                "algorithmic_tflop_per_step": kd["tflop"],
+                "mfma_kernels_ms_per_step": mfma_ms,
+                "all_mfma_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                         "tflops": round(v["tflop"] / (v["ms"] / 1e3), 2),
+                                         "frac": round(v["tflop"] / (v["ms"] / 1e3) / kernel_peak(k), 3),
+                                         "gbps": round(v["gb"] / (v["ms"] / 1e3), 1) if v["gb"] else None}
+                                     for k, v in kernels.items()}}
         out = {
-            "metric": "train-step images/sec (G+D fwd+bwd), 8x 32->256 bs=8",
+            "metric": "train-step images/sec (G+D fwd+bwd), 8x 32->256 bs=8" if headline
+                      else "train-step images/sec (G+D fwd+bwd), %s bs=%d" % (args.config, n),
             "value": n * world / (elapsed / args.steps),
             "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
-            "arithmetic": ("fp32 storage and accumulation; the wide 3x3 layers run as Winograd F(4x4,3x3) GEMMs whose "
-                           "fp32 products are formed exactly from 3-term bf16 operand splits (6 bf16 MFMA products, "
-                           "error below one fp32 rounding; tests/test_gpu_conv.py::test_gemm_bf16x3_is_fp32_accurate)"
-                           if ops.GEMM_SPLIT else "fp32 (v_mfma_f32_32x32x2_f32)"),
-            "config": {"workload": "independent 8x 32->256, 19-class masks, bs=%d per GPU, fp32 G+D train step "
-                                   "(BASELINE.json configs[1])" % n,
+            "arithmetic": arithmetic,
+            "config": {"workload": "%s, 19-class masks, bs=%d per GPU, fp32 G+D train step (BASELINE.json %s)"
+                                   % (args.config.replace("_", " "), n, ref),
                        "global_batch": n * world, "parallelism": "dp%d" % world,
                        "losses": {k: float(v.detach()) for k, v in tm.get_latest_losses().items()}},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak,
-                         # HBM bytes per launch of this kernel from PMC passes over this same command (not live:
-                         # counters need rocprofv3), profiles/r01_pmc_gemm_bf16x3.md
-                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(dom),
-                         "peak_note": ("fp32 work on the bf16 matrix cores: 2516.6 dense bf16 TFLOP/s / 6 products per "
-                                       "fp32 multiply-add" if "bf16x3" in dom else "v_mfma_f32 dense peak"),
-                         "launches_per_step": kd["launches"], "avg_launch_ms": kd["ms"] / kd["launches"],
-                         "algorithmic_gb_per_launch": (ops.PROFILE_BYTES.get(dom, 0.0) / kd["launches"] / 1e9) or None,
-                         "traffic_note": ("PMC passes over this command (profiles/r01_pmc_gemm_bf16x3.md): FETCH_SIZE x2 "
-                                          "(gfx950 correction) + WRITE_SIZE, averaged over the step's launches of this "
-                                          "kernel; 7.04 GB vs 6.06 GB algorithmic at the dominant shape"
-                                          if "bf16x3" in dom else None),
-                         "algorithmic_tflop_per_step": kd["tflop"],
-                         "mfma_kernels_ms_per_step": mfma_ms,
-                         "all_mfma_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                                  "tflops": round(v["tflop"] / (v["ms"] / 1e3), 2),
-                                                  "frac": round(v["tflop"] / (v["ms"] / 1e3) / kernel_peak(k), 3)}
-                                              for k, v in kernels.items()}},
+            "roofline": roof,
         }
+        if fused:
+            g = fused["gb"] / (fused["ms"] / 1e3)
+            out["spade_fused"] = {"kernel": "wino43_output_modulate (output transform of the gamma/beta GEMM + BN-normalise "
+                                            "+ SPADE/SEAN modulate + LeakyReLU)", "bound": "hbm",
+                                  "launches": fused["launches"], "ms_per_step": fused["ms"],
+                                  "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
+                                  "bytes_note": "bytes the kernel itself moves: M (36/16 x 2C fp32 per pixel) + x read, h "
+                                                "[+ scale] written"}
         if f32_only:
             out["f32_mfma_only"] = f32_only
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -178,6 +178,8 @@ class SpadeNorm(nn.Module):
         sh = self.mlp_shared._modules["0"]
         st = self.param_free_norm
         capped = fm != h
+        if capped and (h * w) % 128 == 0 and c % 64 == 0:
+            return self._forward_capped(x, labels, training, fm, grad_sink)
         if capped or (self.kind != "spade" and (h * w) % 128 != 0):
             return self._forward_dense(x, labels, style, training, fm, grad_sink)
         shift = labels.shift_for(h)
@@ -204,6 +206,29 @@ class SpadeNorm(nn.Module):
         table = ops.style_table(style, ws2)
         return ops.SeanNormTable.apply(x, None, None, None, table, b2, st.running_mean, st.running_var, labels, shift,
                                        training, 0.0, grad_sink)
+
+    def _forward_capped(self, x, labels, training, fm, grad_sink=None):
+        """The reference's max_fm_size cap (normalization.py:171-190, 258-277) on the fused / Winograd path: above the
+        cap BOTH the SPADE embedding and the "style map" are the embedding computed at the capped resolution and
+        nearest-upsampled (the style matrix is ignored; it only type-checks because nhidden == style size), so the two
+        weight sets act on the same 128 channels and fold into one: gamma/beta = conv(up(actv), W_folded)."""
+        n, h, w, c = x.shape
+        sh, st = self.mlp_shared._modules["0"], self.param_free_norm
+        ups = int(round(math.log2(h // fm)))
+        if self.kind == "sean":
+            wg, wb = torch.sigmoid(self.alpha_gamma), torch.sigmoid(self.alpha_beta)
+            wgam = (1.0 - wg) * self.mlp_gamma.weight + wg * self.mlp_style_gamma.weight
+            wbet = (1.0 - wb) * self.mlp_beta.weight + wb * self.mlp_style_beta.weight
+            bg = (1.0 - wg) * self.mlp_gamma.bias + wg * self.mlp_style_gamma.bias
+            bb = (1.0 - wb) * self.mlp_beta.bias + wb * self.mlp_style_beta.bias
+            w2a, b2 = ops.pack_gamma_beta(wgam, wbet, bg, bb)
+            add_one = 1.0
+        else:  # puresean: out = xhat * gamma_s + beta_s
+            w2a, b2 = ops.pack_gamma_beta(self.mlp_style_gamma.weight, self.mlp_style_beta.weight,
+                                          self.mlp_style_gamma.bias, self.mlp_style_beta.bias)
+            add_one = 0.0
+        return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, None, b2, st.running_mean, st.running_var, labels,
+                                       labels.shift_for(fm), training, add_one, grad_sink, ups)
 
     def _forward_dense(self, x, labels, style, training, fm, grad_sink=None):
         """General path (style map materialised as 128 gathered channels): resolutions below 16x16, and the

@@ -976,7 +976,10 @@ class SeanNormTable(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_sh, b_sh, w2a, table, b2, running_mean, running_var, labels, shift, training, add_one,
-                grad_sink=None):
+                grad_sink=None, cat_ups=0):
+        """`cat_ups` > 0 (the reference's max_fm_size cap, normalization.py:188-190 / 275-277): the 128-channel
+        embedding is computed at the capped resolution (`shift` refers to IT) and nearest-upsampled by 2^cat_ups to x's
+        resolution before the gamma/beta convolution; there is no style table then."""
         ctx.grad_sink = grad_sink
         n, h, w, c = x.shape
         nc = labels.nc
@@ -985,10 +988,19 @@ class SeanNormTable(torch.autograd.Function):
         ca = NHIDDEN if has_a else 0
         ld = ca + (32 if has_t else 0)
         cat = new(n, h, w, ld)
+        actv_low = None
         if has_a:
             tab = new(9, nc, NHIDDEN)
             L.call("onehot_conv3x3_pack", w_sh.contiguous(), tab, NHIDDEN, nc)
-            L.call("onehot_conv3x3_fwd", labels.t, tab, b_sh, cat, n, labels.h, labels.w, shift, nc, NHIDDEN, ld, 0, 1)
+            if cat_ups:
+                assert not has_t and ld == NHIDDEN
+                actv_low = new(n, h >> cat_ups, w >> cat_ups, NHIDDEN)
+                L.call("onehot_conv3x3_fwd", labels.t, tab, b_sh, actv_low, n, labels.h, labels.w, shift, nc, NHIDDEN,
+                       NHIDDEN, 0, 1)
+                L.call("upsample_noise_fwd", actv_low, None, None, cat, n, h, w, NHIDDEN, cat_ups)
+            else:
+                L.call("onehot_conv3x3_fwd", labels.t, tab, b_sh, cat, n, labels.h, labels.w, shift, nc, NHIDDEN, ld, 0,
+                       1)
         if has_t:
             L.call("label_onehot", labels.t, cat, n, labels.h, labels.w, shift, ld, ca)
         mean, invstd, ctx.sync = bn_stats(x, running_mean, running_var, training)
@@ -1017,21 +1029,25 @@ class SeanNormTable(torch.autograd.Function):
                 else:
                     u, ua = _wino_u(w2a, rows, ca, False, rows, kp, split)
                 m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split, keep, ua)
-                L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
-                       scale[n0:n0 + nb] if need_scale else None, nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
+                px = nb * h * w
+                with _timed("spade_modulate_fused", 0.0,
+                            4.0 * (36 * (px // 16) * rows + px * c * (3 if need_scale else 2))):
+                    L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
+                           scale[n0:n0 + nb] if need_scale else None, nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
         else:
             wp = _pack_fwd(w2a, ca, 1) if has_a else None
             with _timed(_variant(geom, True), _flops(geom)):
                 L.call("conv2d_modulate_fwd", C.byref(geom), cat, wp, tb, ca, b2.contiguous(), x, mean, invstd, out,
                        scale, c, float(add_one), LRELU_SLOPE)
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
+        ctx.cat_ups = cat_ups
         vcat = keep[0] if (nb and keep) else (None, None)
-        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, *vcat)
+        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, *vcat, actv_low)
         return out
 
     @staticmethod
     def backward(ctx, dh):
-        x, cat, w2a, out, scale, mean, invstd, vc, vc_amax = ctx.saved_tensors
+        x, cat, w2a, out, scale, mean, invstd, vc, vc_amax, actv_low = ctx.saved_tensors
         vcat = (vc, vc_amax) if vc is not None else None
         geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
         n, h, w, c = x.shape
@@ -1116,8 +1132,14 @@ class SeanNormTable(torch.autograd.Function):
                          else conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga))
                 dw_sh, db_sh = new(NHIDDEN, lab.nc, 3, 3), new(NHIDDEN)
                 wso = scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, lab.h, lab.w, shift, lab.nc), "ohw")
-                L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, cat, ld, n, lab.h, lab.w, shift, lab.nc, dw_sh,
-                       db_sh, wso)
+                act_lo, ld_lo = cat, ld
+                if ctx.cat_ups:
+                    # gradient of the nearest upsample: 2^ups x 2^ups block sums; the ReLU mask is constant per block
+                    dlow = torch.empty_like(actv_low)
+                    L.call("sumpool", dactv, dlow, n, h, w, NHIDDEN, ctx.cat_ups)
+                    dactv, act_lo, ld_lo = dlow, actv_low, NHIDDEN
+                L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, act_lo, ld_lo, n, lab.h, lab.w, shift, lab.nc,
+                       dw_sh, db_sh, wso)
         if side is not None:
             side.join(dw2a, dtable)
         elif wino_w and not fused_d:
@@ -1139,7 +1161,7 @@ class SeanNormTable(torch.autograd.Function):
         if ctx.needs_input_grad[5]:
             idx, _ = packed_perm(c, x.device)
             db2 = torch.cat([cs.reshape(-1), torch.zeros(1, device=x.device)]).index_select(0, idx)
-        return dx, dw_sh, db_sh, dw2a, dtable, db2, None, None, None, None, None, None, None
+        return dx, dw_sh, db_sh, dw2a, dtable, db2, None, None, None, None, None, None, None, None
 
 
 class _StyleGemm(torch.autograd.Function):

@@ -105,9 +105,12 @@ def test_spade_sean_norm_fwd_bwd(kind, C, R, N):
             assert rel(p[k].grad.cpu(), v.grad) < 1e-4, k
 
 
-@pytest.mark.parametrize("kind,C,R,N", [("spade", 64, 16, 2), ("sean", 64, 16, 2), ("sean", 128, 32, 3), ("puresean", 64, 16, 2),
-                                        ("spade", 64, 64, 2), ("sean", 64, 64, 2), ("sean", 128, 64, 3), ("puresean", 64, 64, 2)])
-def test_sean_norm_table_path(kind, C, R, N):
+@pytest.mark.parametrize("kind,C,R,N,max_fm", [
+    ("spade", 64, 16, 2, 256), ("sean", 64, 16, 2, 256), ("sean", 128, 32, 3, 256), ("puresean", 64, 16, 2, 256),
+    ("spade", 64, 64, 2, 256), ("sean", 64, 64, 2, 256), ("sean", 128, 64, 3, 256), ("puresean", 64, 64, 2, 256),
+    # the reference's max_fm_size cap (normalization.py:188-190, 275-277): embedding at 32^2 / 16^2, upsampled, style ignored
+    ("puresean", 128, 64, 2, 32), ("sean", 128, 64, 2, 16), ("puresean", 64, 16, 2, 8)])
+def test_sean_norm_table_path(kind, C, R, N, max_fm):
     """The production path for R >= 16: style half as per-image one-hot tables (K = 1440 instead of 2304).  From R = 64
     the gamma/beta GEMM, its data gradient and its weight/table gradient run in the Winograd F(4x4,3x3) domain with
     (transform position, image) groups: ~10x the fp32 rounding error of the direct form, and the ReLU / LeakyReLU
@@ -120,9 +123,9 @@ def test_sean_norm_table_path(kind, C, R, N):
     seg = O.onehot_labels(label, Lc)
     style = (torch.rand(N, Lc, S, generator=g) * 2 - 1).requires_grad_()
     x = torch.randn(N, C, R, R, generator=g).requires_grad_()
-    mod = Nw.SpadeNorm(kind, C, Lc, S, 256)
+    mod = Nw.SpadeNorm(kind, C, Lc, S, max_fm)
     st = {"n." + k: O.recipe_tensor("tt_" + kind, k, v.shape, 1.0) for k, v in mod.state_dict().items()}
-    orc = O.Oracle(O.make_opt(), {"SR": st})
+    orc = O.Oracle(O.make_opt(max_fm_size=max_fm), {"SR": st})
     P = orc.S["SR"]
     y = F.leaky_relu(orc._norm(kind, P, "n", x, seg, style), 0.2)
     gy = torch.randn(y.shape, generator=g)
@@ -132,7 +135,8 @@ def test_sean_norm_table_path(kind, C, R, N):
     labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
     xs = nhwc(x.detach()).requires_grad_()
     sty = style.detach().cuda().requires_grad_()
-    wino = ops._wino_mod_chunk(N, R, R, C, 2 * C, kind != "spade") is not None
+    capped = kind != "spade" and max_fm < R
+    wino = ops._wino_mod_chunk(N, R, R, C, 2 * C, kind != "spade" and not capped) is not None
     assert wino == (R >= 64)
     h = mod(xs, labels, sty, True)
     h.backward(nhwc(gy))
@@ -141,8 +145,11 @@ def test_sean_norm_table_path(kind, C, R, N):
     assert rel(nchw(h.detach(), C), y.detach()) < ft
     assert rel(nchw(xs.grad, C), x.grad) < (gt if wino else 5 * TOL)
     assert rel(mod.param_free_norm.running_var.cpu(), P["n.param_free_norm.running_var"]) < TOL
-    if kind != "spade":
+    if kind != "spade" and not capped:
         assert rel(sty.grad.cpu(), style.grad) < (gt if wino else 1e-4)
+    if capped:                         # the capped path ignores the style matrix, like the reference
+        assert sty.grad is None or float(sty.grad.abs().max()) == 0.0
+        assert style.grad is None or float(style.grad.abs().max()) == 0.0
     for k, p in mod.named_parameters():
         ref = P["n." + k].grad
         if ref is None:

@@ -12,9 +12,6 @@ def run(name, preset, n, steps=3, **over):
     random.seed(1)
     tm = TrainerManager(opt)
     b = bench.synthetic_batch(opt, n, 7, "cuda")
-    if opt.guiding_style_image:
-        g = bench.synthetic_batch(opt, n, 8, "cuda")
-        b["guiding_label"], b["guiding_image"] = g["label"], g["image"]
     def step():
         tm.run_generator_one_step(b); tm.run_discriminator_one_step(b)
     step(); torch.cuda.synchronize()
