@@ -53,6 +53,8 @@ CONFIGS = {
 def kernel_peak(name):
     """fp32-equivalent matrix-core peak of a kernel: an fp32 multiply-add costs 6 bf16 MFMA products (bf16x3), 3 fp16
     MFMA products (fp16x2, same MFMA rate) or one v_mfma_f32 product."""
+    if "1term" in name:
+        return F16_MFMA_PEAK_TFLOPS
     if "bf16x3" in name:
         return F16_MFMA_PEAK_TFLOPS / 6.0
     if "f16x2" in name:
@@ -145,6 +147,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-run", action="store_true", help="skip the extra v_mfma_f32-only measurement")
     ap.add_argument("--batch-per-gpu", type=int, default=0)
+    ap.add_argument("--dtype", choices=["fp32", "fp16"], default="fp32",
+                    help="fp16: BASELINE configs[2]'s 16-bit arithmetic (one-term scaled-fp16 matrix-core GEMMs, fp32 master "
+                         "weights): a separate line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -161,7 +166,7 @@ def main():
     preset, n_default, ref = CONFIGS[args.config]
     n = args.batch_per_gpu or n_default
     headline = args.config == "independent_8x_256"
-    opt = make_opt(preset, batchSize=n, seed=0)
+    opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)   # (the no-pretrained-VGG notice: synthetic benchmark)
@@ -213,7 +218,7 @@ def main():
     mfma_ms = sum(k["ms"] for k in kernels.values())
 
     f32_only = None
-    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run and headline:
+    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run and headline and not ops.HALF:
         ops.GEMM_SPLIT = False
         step()
         fence()
@@ -229,7 +234,14 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         kind = "f16x2" if (ops.GEMM_SPLIT and ops.GEMM_F16X2) else ("bf16x3" if ops.GEMM_SPLIT else "f32")
+        if ops.HALF:
+            kind = "fp16"
         arithmetic = {
+            "fp16": "half-precision compute mode (BASELINE configs[2]'s 16-bit arithmetic): Winograd-domain GEMMs with operands "
+                    "scaled by powers of two and rounded to ONE fp16 term, one MFMA product, fp32 accumulate, products stored as "
+                    "scaled fp16 (fp16, not bf16: F(4x4,3x3) amplifies operand rounding ~10x); activations, statistics, master "
+                    "weights and Adam in fp32; generated image within 3e-2 of the fp32 path "
+                    "(tests/test_gpu_model.py::test_half_mode_tracks_fp32)",
             "f16x2": "fp32 storage and accumulation; the wide 3x3 layers run as Winograd F(4x4,3x3) GEMMs on the fp16 "
                      "matrix cores: every fp32 operand is scaled by an exact power of two and split into two fp16 terms "
                      "(residual <= 2^-22, rms 2^-24), 3 MFMA products per multiply-add, fp32 accumulate; error vs float64 "
@@ -265,7 +277,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "arithmetic": arithmetic,
             "config": {"workload": "%s, 19-class masks, bs=%d per GPU, fp32 G+D train step (BASELINE.json %s)"
                                    % (args.config.replace("_", " "), n, ref),
@@ -283,7 +295,7 @@ def main():
                                                 "[+ scale] written"}
         if f32_only:
             out["f32_mfma_only"] = f32_only
-        if world == 1 and not args.no_cpu_baseline and headline:
+        if world == 1 and not args.no_cpu_baseline and headline and not ops.HALF:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

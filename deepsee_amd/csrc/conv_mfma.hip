@@ -1256,7 +1256,7 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
                       int Cin_s, int Cout_s, int Cout, int Cin, int split, const float* amax_v, const float* amax_dm,
                       hipStream_t st) {
   DSEE_CHECK_ARG(V && dM && workspace && dw_oihw && T % 32 == 0 && Cin_s % 4 == 0 && Cout_s % 4 == 0);
-  DSEE_CHECK_ARG(split != 3 || (amax_v && amax_dm));
+  DSEE_CHECK_ARG(split < 3 || (amax_v && amax_dm));
   DSEE_CHECK_ARG(Cout <= Cout_s && Cin <= Cin_s && 36 * T < (1L << 31));
   DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_workspace(T, Cin_s, Cout_s));
   if (split) {
@@ -1265,7 +1265,8 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
     const int sper = wino_sper(T, Cin_s, Cout_s), Kpad = dsee_conv_kpad(1, 1, Cin_s);
     // split == 2: V / dM are the plain fp32 transforms, transposed + split inside the GEMM
     // split == 3: the same with two-term fp16 splits (3 MFMA products), operand scales from max |dM|, max |V|
-    int rc = split == 3   ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
+    int rc = split == 4   ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
+             : split == 3 ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
              : split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st)
                           : dsee_gemm_bf16x3_tn(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st);
     if (rc) return rc;
@@ -1304,14 +1305,15 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
                             float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,
                             const float* amax_dm, hipStream_t st) {
   DSEE_CHECK_ARG(V && dM && workspace && dtable && N > 0 && T % N == 0 && (T / N) % 32 == 0 && ca % 32 == 0);
-  DSEE_CHECK_ARG(split != 3 || (amax_v && amax_dm));
+  DSEE_CHECK_ARG(split < 3 || (amax_v && amax_dm));
   DSEE_CHECK_ARG(rows % 4 == 0 && L <= 32 && 36 * T < (1L << 31));
   DSEE_CHECK_ARG(workspace_bytes >= dsee_wino43_wgrad_table_workspace(T, N, ca, rows));
   const int ld = ca + 32;
   if (split) {
     DSEE_CHECK_ARG(rows % 128 == 0);
     const int sper = wino_sper(T / N, ld, rows, N), Kpad = dsee_conv_kpad(1, 1, ld);
-    int rc = split == 3   ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
+    int rc = split == 4   ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
+             : split == 3 ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
              : split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st)
                           : dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
     if (rc) return rc;

@@ -38,6 +38,7 @@ struct Gemm3Args {
   // are dsee_pow2_scale(amax); a pre-split B operand was scaled by its producer with the same function of *amax_b.
   const float* amax_a;
   const float* amax_b;
+  float* cscale;   // half-precision mode: receives the inverse of the power-of-two scale of the fp16 output
   long M;      // rows of A (per z)
   int N, K;    // valid columns (= rows of B), reduction length per z (multiple of 16)
   int ldc;     // row stride of C
@@ -87,16 +88,22 @@ template <int TERMS>
 struct Img {
   static constexpr int CH = 2 * TERMS;                              // chunks per row
   static constexpr int ROWB = 32 * TERMS;                           // bytes per row in the global (dense) image
-  static constexpr int PERIOD = TERMS == 3 ? 97 : 17;               // slots per dummy period (16 rows + 1 | 4 rows + 1)
-  static constexpr int TSTEP = (32 * CH + (TERMS == 3 ? 2 : 8)) * 16;  // bytes between 32-row MFMA tiles
-  __host__ __device__ static constexpr int pad(int r) { return TERMS == 3 ? r >> 4 : r >> 2; }
-  __host__ __device__ static constexpr int slots(int rows) { return rows * CH + (TERMS == 3 ? rows / 16 : rows / 4); }
+  // one dummy slot per 16 rows (3 terms: 96 + 1; 1 term: 32 + 1) or per 4 rows (2 terms: 16 + 1)
+  static constexpr int PERIOD = TERMS == 2 ? 17 : 16 * CH + 1;
+  static constexpr int TSTEP = (32 * CH + (TERMS == 2 ? 8 : 2)) * 16;  // bytes between 32-row MFMA tiles
+  __host__ __device__ static constexpr int pad(int r) { return TERMS == 2 ? r >> 2 : r >> 4; }
+  __host__ __device__ static constexpr int slots(int rows) { return rows * CH + (TERMS == 2 ? rows / 4 : rows / 16); }
 };
 
 // 8 fp32 values -> TERMS 16-byte chunks (8 k's of each term)
 template <int TERMS>
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, u32x4 (&w)[TERMS]) {
-  if constexpr (TERMS == 3) {
+  if constexpr (TERMS == 1) {   // half-precision compute mode: ONE scaled fp16 term (11 significand bits)
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (_Float16)(v[e] * scale);
+    w[0] = __builtin_bit_cast(u32x4, h);
+  } else if constexpr (TERMS == 3) {
     unsigned short h[8][3];
 #pragma unroll
     for (int e = 0; e < 8; ++e) split3_dev(v[e], h[e]);
@@ -120,7 +127,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, u32x4 (
 // all products of one (A tile, B tile) pair for one 16-k slab, smallest terms first
 template <int TERMS>
 __device__ __forceinline__ void mfma_terms(const u32x4 (&af)[TERMS], const u32x4 (&bf)[TERMS], f32x16& acc) {
-  if constexpr (TERMS == 3) {
+  if constexpr (TERMS == 1) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]), acc, 0,
+                                                 0, 0);
+  } else if constexpr (TERMS == 3) {
     const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[0]), a1 = __builtin_bit_cast(bf16x8, af[1]),
                  a2 = __builtin_bit_cast(bf16x8, af[2]);
     const bf16x8 b0 = __builtin_bit_cast(bf16x8, bf[0]), b1 = __builtin_bit_cast(bf16x8, bf[1]),
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
 // LDS-DMA as fp32 (64 B per row) into a 2-stage staging area; every wave converts the 32 rows it loaded itself (so only
 // its own vmcnt matters) into the bf16x3 LDS image one slab ahead of the MFMAs: lane = (row, k-half), 8 values ->
 // 3 x 8 bf16 -> the same 6r + c + (r>>4) slot layout the fragments are read from.  B (weights) stays pre-split.
-template <int WM, int WN, int MT, int NT, int TERMS>
+template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using I = Img<TERMS>;
@@ -373,9 +383,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   };
   // fp16x2: operand scales (exact powers of two), undone in the epilogue
   float sa = 1.f, oscale = 1.f;
-  if constexpr (TERMS == 2) {
+  if constexpr (TERMS != 3) {
     sa = pow2_scale(*a.amax_a);
     oscale = 1.f / (sa * pow2_scale(*a.amax_b));
+  }
+  if constexpr (C16) {
+    // the product leaves the kernel as fp16: |C| <= K max|A| max|B| is mapped below 2^15 (no overflow, ~2^8 of headroom
+    // over typical values); the consumer multiplies by *cscale (the inverse, a power of two)
+    const float sm = 2.f * pow2_scale((float)a.K * *a.amax_a * *a.amax_b);
+    oscale *= sm;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.cscale = 1.f / sm;
   }
   const long arow = (long)a.K * 4;  // bytes per A row
   // A instruction jj (0,1) of this wave: rows 16*(wave + NW*jj) .. +15, lane -> (row l>>2, 16-byte chunk l&3)
@@ -506,8 +523,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[i][j][r];
-            if constexpr (TERMS == 2) v *= oscale;
-            cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = v;
+            if constexpr (TERMS != 3) v *= oscale;
+            if constexpr (C16)   // half-precision compute mode: the Winograd-domain product leaves the GEMM as scaled fp16
+              reinterpret_cast<_Float16*>(cz)[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = (_Float16)v;
+            else
+              cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = v;
           }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -672,7 +692,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     bm = t / nbn;
   };
   float sp = 1.f, sq = 1.f, oscale = 1.f;   // fp16x2: operand scales (exact powers of two), undone in the epilogue
-  if constexpr (TERMS == 2) {
+  if constexpr (TERMS != 3) {
     sp = pow2_scale(*a.amax_a);
     sq = pow2_scale(*a.amax_b);
     oscale = 1.f / (sp * sq);
@@ -821,7 +841,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = d[r];
-            if constexpr (TERMS == 2) v *= oscale;
+            if constexpr (TERMS != 3) v *= oscale;
             cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = v;
           }
 #pragma unroll
@@ -868,7 +888,7 @@ int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int TERMS>
+template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false>
 int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -877,13 +897,13 @@ int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   const size_t lds = (size_t)(TERMS == 2 ? 3 : 2) * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS, C16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN);
   const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);
-  gemm3a_kernel<WM, WN, MT, NT, TERMS><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
+  gemm3a_kernel<WM, WN, MT, NT, TERMS, C16><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1014,6 +1034,49 @@ int dsee_gemm_bf16x3_tn_f32(const float* P, const float* Q, float* C, int groups
   a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
   if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 3>(a, groups * splits, st);
   return launch_gemm3t<4, 2, 2, 2, 16, 3>(a, groups * splits, st);
+}
+
+/* Half-precision compute mode (BASELINE configs[2]'s 16-bit arithmetic): A [M][K] fp32 scaled (power of two from *amax_a)
+ * and rounded to ONE fp16 term inside the kernel, B1 [groups][K/16][b_rows][16] fp16 pre-scaled with the scale of
+ * *amax_b, one MFMA product per multiply-add, fp32 accumulate.  c_f16 != 0: C is written as fp16 scaled by a power of two
+ * chosen from the bound K max|A| max|B| (no overflow); its inverse is stored to *cscale for the consumer.
+ * (fp16 rather than bf16 operands: the Winograd F(4x4,3x3) transforms amplify operand rounding ~10x -- measured per-layer
+ * error 2.6 % with bf16, 0.33 % with scaled fp16, vs 0.24 % for a direct bf16 convolution.) */
+int dsee_gemm_f16_af32(const float* A, const void* B1, void* C, long M, int N, int K, long rows_per_group, int b_rows,
+                       int tile, const float* amax_a, const float* amax_b, int c_f16, float* cscale, hipStream_t st) {
+  DSEE_CHECK_ARG(A && B1 && C && amax_a && amax_b && M > 0 && N > 0 && K > 0 && K % 16 == 0 && N % 128 == 0 && M % 128 == 0);
+  DSEE_CHECK_ARG(rows_per_group % 128 == 0 && M % rows_per_group == 0 && b_rows >= N && (long)K * 4 * 256 < 0x7FFFFFFFL);
+  DSEE_CHECK_ARG(!c_f16 || cscale);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)A; a.B = (const unsigned char*)B1; a.C = (float*)C;
+  a.amax_a = amax_a; a.amax_b = amax_b; a.cscale = cscale;
+  a.M = M; a.N = N; a.K = K; a.ldc = N; a.rows_per_group = rows_per_group;
+  a.b_group_bytes = (long)b_rows * K * 2; a.b_slab_bytes = (long)b_rows * 32; a.nz = 1;
+  const bool big_ok = rows_per_group % 256 == 0 && N % 256 == 0;
+  if (tile == 0) tile = (big_ok && (M / 256) * (N / 256) >= 512) ? 2 : 1;
+  if (tile == 2) {
+    DSEE_CHECK_ARG(big_ok);
+    return c_f16 ? launch_gemm3a<2, 4, 4, 2, 1, true>(a, st) : launch_gemm3a<2, 4, 4, 2, 1, false>(a, st);
+  }
+  return c_f16 ? launch_gemm3a<2, 2, 2, 2, 1, true>(a, st) : launch_gemm3a<2, 2, 2, 2, 1, false>(a, st);
+}
+
+/* half-precision mode of the split-K TN weight-gradient GEMM: fp32 operands transposed, scaled and rounded to one fp16
+ * term in the kernel; fp32 output */
+int dsee_gemm_f16_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                         int splits, const float* amax_p, const float* amax_q, hipStream_t st) {
+  DSEE_CHECK_ARG(P && Q && C && amax_p && amax_q && groups > 0 && T % 16 == 0 && rows_p % 256 == 0 && splits > 0);
+  DSEE_CHECK_ARG((T / 16) % splits == 0 && ldc >= rows_q && (rows_q == 160 || rows_q % 128 == 0));
+  DSEE_CHECK_ARG((long)rows_p * 64 < 0x7FFFFFFFL && (long)rows_q * 64 < 0x7FFFFFFFL);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)P; a.B = (const unsigned char*)Q; a.C = C;
+  a.amax_a = amax_p; a.amax_b = amax_q;
+  const long nk = T / 16 / splits;
+  a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p;
+  a.a_slab_bytes = (long)16 * rows_p * 4; a.b_slab_bytes = (long)16 * rows_q * 4;
+  a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
+  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 1>(a, groups * splits, st);
+  return launch_gemm3t<4, 2, 2, 2, 16, 1>(a, groups * splits, st);
 }
 
 /* fp16x2 form of dsee_gemm_bf16x3_tn_f32: both fp32 operands are transposed, scaled (powers of two from the device

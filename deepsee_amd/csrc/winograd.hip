@@ -71,6 +71,19 @@ __device__ __forceinline__ void store_split_pair(unsigned short* base, const f32
   }
 }
 
+// 4 consecutive channels of a Winograd-domain GEMM output: fp32, or scaled fp16 in the half-precision compute mode
+// (BASELINE configs[2]; the transforms are linear, so the power-of-two scale is undone once on their result)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <typename TM>
+__device__ __forceinline__ f32x4 ldm4(const TM* p) {
+  if constexpr (sizeof(TM) == 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+}
+
 // one column / row of B^T d : 6 -> 6
 __device__ __forceinline__ void bt6(const f32x4 (&d)[6], f32x4 (&o)[6]) {
   o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
@@ -320,14 +333,15 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
 
 // noise_w != NULL: y += noise_w[c] * eps with eps = element (pixel, quad) of the Philox N(0,1) stream (seed, offset) --
 // the NoiseInjection that follows the convolution (architecture.py:111-112 noise_middle) without its own pass over y
-template <bool NOISE>
-__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+template <bool NOISE, typename TM>
+__global__ __launch_bounds__(256) void wino43_output_kernel(const TM* __restrict__ M, const float* __restrict__ bias,
                                                             const float* __restrict__ res, int res_ld,
                                                             float* __restrict__ y, int N, int H, int W, int C, int act,
                                                             float slope, const float* __restrict__ noise_w,
                                                             uint64_t seed, uint64_t offset,
                                                             const float* __restrict__ res_nw, uint64_t res_seed,
-                                                            uint64_t res_offset) {
+                                                            uint64_t res_offset, const float* __restrict__ mscale) {
+  const float ms = mscale ? *mscale : 1.f;
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
     for (int j = 0; j < 6; ++j) {
       f32x4 col[6], o[4];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) col[k] = *reinterpret_cast<const f32x4*>(M + ((size_t)(k * 6 + j) * T + t) * C + q * 4);
+      for (int k = 0; k < 6; ++k) col[k] = ldm4(M + ((size_t)(k * 6 + j) * T + t) * C + q * 4);
       at4(col, o);
 #pragma unroll
       for (int k = 0; k < 4; ++k) tmp[k][j] = o[k];
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const size_t px = ((size_t)n * H + ty * 4 + k) * W + tx * 4 + j, off = px * C + q * 4;
-        f32x4 v = o[j] + b;
+        f32x4 v = o[j] * ms + b;
         if (act == DSEE_ACT_MASK) {  // backward of a ReLU whose output is `res`
           const f32x4 m = *reinterpret_cast<const f32x4*>(res + px * res_ld + q * 4);
 #pragma unroll
@@ -383,14 +397,14 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
 }
 
 // 4x4 output tile of one channel quad: y[k][j] = (A^T m A)[k][j], m[xi] read at column `col` of M [36][T][ld]
-__device__ __forceinline__ void out_tile(const float* __restrict__ M, long T, long t, int ld, int col,
-                                         f32x4 (&y)[4][4]) {
+template <typename TM>
+__device__ __forceinline__ void out_tile(const TM* __restrict__ M, long T, long t, int ld, int col, f32x4 (&y)[4][4]) {
   f32x4 tmp[4][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     f32x4 c6[6], o[4];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c6[k] = *reinterpret_cast<const f32x4*>(M + ((size_t)(k * 6 + j) * T + t) * ld + col);
+    for (int k = 0; k < 6; ++k) c6[k] = ldm4(M + ((size_t)(k * 6 + j) * T + t) * ld + col);
     at4(c6, o);
 #pragma unroll
     for (int k = 0; k < 4; ++k) tmp[k][j] = o[k];
@@ -401,10 +415,13 @@ __device__ __forceinline__ void out_tile(const float* __restrict__ M, long T, lo
 
 // Output transform of the gamma/beta GEMM fused with the SPADE/SEAN modulate + LeakyReLU (same arithmetic as the
 // EPI_MODULATE epilogue of conv_mfma.hip; packed column of channel c: (c/64)*128 + ((c%64)/32)*64 + c%32, beta +32)
+template <typename TM>
 __global__ __launch_bounds__(256) void wino43_output_modulate_kernel(
-    const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ x,
+    const TM* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ out,
-    float* __restrict__ scale, int N, int H, int W, int C, int rows, float add_one, float slope) {
+    float* __restrict__ scale, int N, int H, int W, int C, int rows, float add_one, float slope,
+    const float* __restrict__ mscale) {
+  const float ms = mscale ? *mscale : 1.f;
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -427,8 +444,8 @@ __global__ __launch_bounds__(256) void wino43_output_modulate_kernel(
       for (int j = 0; j < 4; ++j) {
         const size_t off = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + c;
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + off) - mu) * is;
-        const f32x4 sc = yg[k][j] + bg + add_one;
-        f32x4 v = xh * sc + (yb[k][j] + bb);
+        const f32x4 sc = yg[k][j] * ms + bg + add_one;
+        f32x4 v = xh * sc + (yb[k][j] * ms + bb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
         if (scale) *reinterpret_cast<f32x4*>(scale + off) = sc;  // saved for the backward pass only
@@ -455,9 +472,12 @@ __device__ __forceinline__ void b6(const f32x4 (&v)[6], f32x4 (&o)[6]) {
 // dV row / column 5 is needed) + the first patch row / column of the tiles below / right (B's row 0 = 4 e0) + 4 corner
 // scalars.  64 instead of 36 loads per thread, the 28 extra ones from rows of the same planes its neighbours just read.
 // mask != NULL: dx = mask > 0 ? dx : 0 (ReLU backward of the SPADE embedding, DSEE_ACT_MASK of the conv epilogues).
-__global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const float* __restrict__ dV,
+template <typename TM>
+__global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const TM* __restrict__ dV,
                                                                    const float* __restrict__ mask, int mask_ld,
-                                                                   float* __restrict__ dx, int N, int H, int W, int C) {
+                                                                   float* __restrict__ dx, int N, int H, int W, int C,
+                                                                   const float* __restrict__ mscale) {
+  const float ms = mscale ? *mscale : 1.f;
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const float* 
     const int tx = (int)(t % tw);
     const long r = t / tw;
     const int ty = (int)(r % th), n = (int)(r / th);
-    auto at = [&](int xi, long tt) { return *reinterpret_cast<const f32x4*>(dV + ((size_t)xi * T + tt) * C + q * 4); };
+    auto at = [&](int xi, long tt) { return ldm4(dV + ((size_t)xi * T + tt) * C + q * 4); };
     // own patch: tmp[a][s] = (B dV)[a][s], then P[a][b] = sum_s tmp[a][s] B[b][s]
     f32x4 tmp[6][6];
 #pragma unroll
@@ -528,7 +548,7 @@ __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const float* 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const size_t px = ((size_t)n * H + ty * 4 + k) * W + tx * 4 + j;
-        f32x4 v = y[k][j];
+        f32x4 v = y[k][j] * ms;
         if (mask) {
           const f32x4 m = *reinterpret_cast<const f32x4*>(mask + px * mask_ld + q * 4);
 #pragma unroll
@@ -579,7 +599,7 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
                                            float* __restrict__ U, int N, int rows, int ca, int Kpad, int split,
                                            const float* __restrict__ amax) {
   const long per = (long)rows * Kpad, total = (long)N * per;
-  const float sc = split == 2 ? dsee_pow2_scale(*amax) : 1.f;
+  const float sc = split >= 2 ? dsee_pow2_scale(*amax) : 1.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % Kpad);
     const long rr = i / Kpad;
@@ -597,7 +617,10 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
     ggt(g, u);
 #pragma unroll
     for (int xi = 0; xi < 36; ++xi) {
-      if (split == 2) {
+      if (split == 3) {   // half-precision compute mode: [K/16][rows][16], one scaled fp16 term
+        reinterpret_cast<_Float16*>(U)[((size_t)xi * N + n) * per + ((size_t)(k >> 4) * rows + row) * 16 + (k & 15)] =
+            (_Float16)(u[xi] * sc);
+      } else if (split == 2) {
         _Float16 h[2];
         split2(u[xi] * sc, h);
 #pragma unroll
@@ -624,7 +647,7 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
 __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows,
                                      int Kpad, int transpose_flip, int split, const float* __restrict__ amax) {
   const long total = (long)rows * Kpad;
-  const float sc = split == 2 ? dsee_pow2_scale(*amax) : 1.f;
+  const float sc = split >= 2 ? dsee_pow2_scale(*amax) : 1.f;
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / Kpad), k = (int)(i % Kpad);
@@ -666,7 +689,10 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
       u[5] = t2;
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        if (split == 2) {
+        if (split == 3) {
+          reinterpret_cast<_Float16*>(U)[(size_t)(a * 6 + b) * total + ((size_t)(k >> 4) * rows + row) * 16 + (k & 15)] =
+              (_Float16)(u[b] * sc);
+        } else if (split == 2) {
           _Float16 h[2];
           split2(u[b] * sc, h);
 #pragma unroll
@@ -755,11 +781,15 @@ int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, i
 
 /* dx [N][H][W][C] from dV [36][T][C] (see wino43_input_adjoint_kernel); mask [pixels][mask_ld] optional */
 int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
-                              hipStream_t st) {
+                              const float* dvscale, hipStream_t st) {
   DSEE_CHECK_ARG(dV && dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(!mask || (mask_ld >= C && mask_ld % 4 == 0));
-  wino43_input_adjoint_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dV, mask, mask_ld, dx, N, H,
-                                                                                            W, C);
+  const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
+  if (dvscale)
+    wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const _Float16*>(dV), mask, mask_ld, dx, N, H, W, C,
+                                                      dvscale);
+  else
+    wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, mask, mask_ld, dx, N, H, W, C, nullptr);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -767,19 +797,24 @@ int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, f
 int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
                        int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
                        uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
-                       uint64_t res_noise_offset, hipStream_t st) {
+                       uint64_t res_noise_offset, const float* mscale, hipStream_t st) {
   DSEE_CHECK_ARG(M && y && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(act != DSEE_ACT_MASK || residual);
   DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
   DSEE_CHECK_ARG(!res_noise_w || (residual && residual_ld == C && act != DSEE_ACT_MASK));
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
-  if (noise_w || res_noise_w)
-    wino43_output_kernel<true><<<grid, 256, 0, st>>>(M, bias, residual, residual_ld, y, N, H, W, C, act, slope, noise_w,
-                                                     noise_seed, noise_offset, res_noise_w, res_noise_seed,
-                                                     res_noise_offset);
-  else
-    wino43_output_kernel<false><<<grid, 256, 0, st>>>(M, bias, residual, residual_ld, y, N, H, W, C, act, slope, nullptr,
-                                                      0, 0, nullptr, 0, 0);
+  const _Float16* Mb = reinterpret_cast<const _Float16*>(M);
+  const bool nz = noise_w || res_noise_w;
+#define DSEE_OUT(NOISE, PTR)                                                                                       \
+  wino43_output_kernel<NOISE><<<grid, 256, 0, st>>>(PTR, bias, residual, residual_ld, y, N, H, W, C, act, slope, \
+                                                    noise_w, noise_seed, noise_offset, res_noise_w, res_noise_seed, \
+                                                    res_noise_offset, mscale)
+  if (mscale) {
+    if (nz) DSEE_OUT(true, Mb); else DSEE_OUT(false, Mb);
+  } else {
+    if (nz) DSEE_OUT(true, M); else DSEE_OUT(false, M);
+  }
+#undef DSEE_OUT
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -787,7 +822,7 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
 /* U: [36][dsee_conv_wrows(R)][dsee_conv_kpad(1,1,K)] with (R,K) = (Cout,Cin) forward, (Cin,Cout) data gradient */
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
                         const float* amax_w, hipStream_t st) {
-  DSEE_CHECK_ARG(w_oihw && U && (split != 2 || amax_w));
+  DSEE_CHECK_ARG(w_oihw && U && (split < 2 || amax_w));
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
   wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip,
@@ -798,11 +833,16 @@ int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int tr
 
 int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const float* x, const float* mean,
                                 const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
-                                int rows, float add_one, float slope, hipStream_t st) {
+                                int rows, float add_one, float slope, const float* mscale, hipStream_t st) {
   DSEE_CHECK_ARG(M && x && mean && invstd && out_h && C % 64 == 0 && rows == 2 * C);  // out_scale may be NULL
   DSEE_CHECK_ARG(H % 4 == 0 && W % 4 == 0);
-  wino43_output_modulate_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
-      M, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W, C, rows, add_one, slope);
+  const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
+  if (mscale)
+    wino43_output_modulate_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const _Float16*>(M), bias_packed, x, mean, invstd,
+                                                        out_h, out_scale, N, H, W, C, rows, add_one, slope, mscale);
+  else
+    wino43_output_modulate_kernel<<<grid, 256, 0, st>>>(M, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W, C, rows,
+                                                        add_one, slope, nullptr);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -810,7 +850,7 @@ int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const 
 /* U: [36][N][rows][Kpad(ca + 32)], rows % 128 == 0; w2a [rows][ca][3][3] (NULL if ca == 0), table [N][9][rows][32] */
 int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, int split,
                               const float* amax_w, hipStream_t st) {
-  DSEE_CHECK_ARG(table && U && (ca == 0 || w2a) && ca % 32 == 0 && rows % 128 == 0 && (split != 2 || amax_w));
+  DSEE_CHECK_ARG(table && U && (ca == 0 || w2a) && ca % 32 == 0 && rows % 128 == 0 && (split < 2 || amax_w));
   const int Kpad = dsee_conv_kpad(1, 1, ca + 32);
   wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad, split,
                                                                            amax_w);

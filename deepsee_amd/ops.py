@@ -286,11 +286,23 @@ def _split_ok(k_s, r_s):
     return GEMM_SPLIT and k_s % 32 == 0 and r_s % 128 == 0
 
 
+# Half-precision compute mode (BASELINE configs[2]'s 16-bit arithmetic; opt.precision = "fp16"): the Winograd-domain GEMMs
+# take operands scaled by powers of two and rounded to ONE fp16 term (one MFMA product, fp32 accumulate) and write their
+# products M / dV as scaled fp16; everything else -- activations, statistics, master weights, optimizer -- stays fp32.
+# fp16 and not bf16 because the F(4x4,3x3) transforms amplify operand rounding ~10x (per-layer error 2.6 % with bf16
+# operands, 0.33 % with scaled fp16; a direct bf16 convolution: 0.24 %).  Checked against the fp32 path (<= 3e-2 on
+# fake), not against the CPU reference.
+HALF = False
+
+
 def _split_kind(k_s, r_s):
-    """0: fp32 GEMM operands; 1: bf16x3; 2: fp16x2 (fp32 A operand split inside the GEMM kernel)."""
+    """0: fp32 GEMM operands; 1: bf16x3; 2: fp16x2 (fp32 A operand split inside the GEMM kernel); 3: one fp16 term."""
     if not _split_ok(k_s, r_s):
         return 0
-    return 2 if (GEMM_F16X2 and GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF) else 1
+    af32 = GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF
+    if HALF and af32:
+        return 3
+    return 2 if (GEMM_F16X2 and af32) else 1
 
 
 def _i16(n):
@@ -326,29 +338,40 @@ def weight_amax(*tensors):
 def _wino_u(w, co, ci, transpose_flip, rows, kp, split):
     """Winograd-domain weights U [36][rows][kp]: fp32 (split 0), bf16x3-split rows (1) or scaled fp16x2-split rows (2).
     Returns (U, amax) with amax = the device scalar the fp16x2 scale was derived from (None otherwise)."""
-    amax = weight_amax(w) if split == 2 else None
-    u = _i16(36 * rows * kp * (3 if split == 1 else 2)) if split else new(36, rows, kp)
+    amax = weight_amax(w) if split >= 2 else None
+    u = _i16(36 * rows * kp * {1: 3, 2: 2, 3: 1}[split]) if split else new(36, rows, kp)
     L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split), amax)
     return u, amax
 
 
 def _gemm_bytes(t, k_s, r_s, groups, rows, split):
     """algorithmic HBM bytes of a Winograd-domain GEMM: A (fp32, or 6 B/element pre-split) + B + C (fp32)"""
+    if split == 3:
+        return 4.0 * 36 * t * k_s + 2.0 * groups * rows * k_s + 2.0 * 36 * t * r_s
     return 4.0 * 36 * t * k_s + (4.0 if split == 2 else 6.0) * groups * rows * k_s + 4.0 * 36 * t * r_s
 
 
 def _gemm_name(split):
-    return "winograd_gemm_f16x2" if split == 2 else "winograd_gemm_bf16x3"
+    return {1: "winograd_gemm_bf16x3", 2: "winograd_gemm_f16x2", 3: "winograd_gemm_f16_1term"}[split]
 
 
 def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=None, u_amax=None):
-    """M [36][t][r_s] = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs.
+    """(M [36][t][r_s], mscale) = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs.
+    mscale: None (M is fp32) or the device scalar that rescales the fp16 M of the half-precision mode.
     `keep` (a list) receives (V, amax_V) when V exists in fp32 (it is the weight gradient's Q operand)."""
     tpi = (h // 4) * (wd // 4)
     t = nb * tpi
     groups, t_g = (36 * nb, tpi) if per_image else (36, t)
-    m = new(36, t, r_s)
-    if split == 2:
+    m = torch.empty(36, t, r_s, dtype=torch.float16, device="cuda") if split == 3 else new(36, t, r_s)
+    ms = None
+    if split == 3:
+        v, va, ms = new(36, t, k_s), amax_slot(), amax_slot()
+        L.call("wino43_input", xc, v, nb, h, wd, k_s, va)
+        with _timed(_gemm_name(3), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 3)):
+            L.call("gemm_f16_af32", v, u, m, 36 * t, r_s, k_s, t_g, rows, 0, va, u_amax, 1, ms)
+        if keep is not None:
+            keep.append((v, va))
+    elif split == 2:
         v, va = new(36, t, k_s), amax_slot()
         L.call("wino43_input", xc, v, nb, h, wd, k_s, va)
         with _timed(_gemm_name(2), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 2)):
@@ -375,7 +398,7 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
         g = L.ConvGeom(groups, t_g, 1, k_s, t_g, 1, r_s, 1, 1, 1, 0, 1, 0, 0, 1)
         with _timed("winograd_gemm_128x128(igemm,36 groups)", 2.0 * 36 * t * k_s * r_s):
             L.call("conv2d_fwd_grouped", C.byref(g), v, u, rows * kp, m)
-    return m
+    return m, ms
 
 
 def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0, keep=None,
@@ -392,12 +415,12 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     y = new(n, h, wd, r_s)
     nb = _wino_chunk(n, h, wd, max(r_s, k_s))
     for n0 in range(0, n, nb):
-        m = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None, ua)
+        m, ms = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None, ua)
         nz = (None, 0, 0) if noise is None else (noise[0], noise[1].seed, noise[1].offset + n0 * h * wd * r_s // 4)
         rz = ((None, 0, 0) if res_noise is None else
               (res_noise[0], res_noise[1].seed, res_noise[1].offset + n0 * h * wd * r_s // 4))
         L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
-               r_s, act, LRELU_SLOPE, *nz, *rz)
+               r_s, act, LRELU_SLOPE, *nz, *rz, ms)
     return y
 
 
@@ -412,8 +435,17 @@ def _wgrad_mode(cin_s, cout_s):
 
 
 def _wgrad_split(mode):
-    """`split` argument of dsee_wino43_wgrad[_table] for a weight-gradient mode: 3 = fp16x2 on fp32 operands."""
+    """`split` argument of dsee_wino43_wgrad[_table] for a weight-gradient mode: 3 = fp16x2, 4 = plain bf16, both on
+    fp32 operands transposed in the kernel."""
+    if mode == 2 and HALF:
+        return 4
     return 3 if (mode == 2 and GEMM_F16X2) else mode
+
+
+def _wgrad_name(mode):
+    if not mode:
+        return "winograd_wgrad_128x128(36 groups)"
+    return "winograd_wgrad_" + {4: "f16_1term", 3: "f16x2"}.get(_wgrad_split(mode), "bf16x3")
 
 
 def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None):
@@ -426,7 +458,7 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
         L.call("wino43_input_split_t", xc, v, nb, h, wd, cin_s)
         L.call("wino43_dout_split_t", gc, dm, nb, h, wd, cout_s)
         return (v, None), (dm, None)
-    need = GEMM_F16X2 and GEMM_SPLIT       # maxima for the fp16x2 scales (weight gradient and adjoint data gradient)
+    need = GEMM_SPLIT and (GEMM_F16X2 or HALF)   # maxima for the fp16 operand scales
     if v is None or (need and v[1] is None):
         v = (new(36, t, cin_s), amax_slot() if need else None)
         L.call("wino43_input", xc, v[0], nb, h, wd, cin_s, v[1])
@@ -450,15 +482,18 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
     """dx [nb,h,wd,r_s] of a 3x3 convolution from dm = (dM [36][t][k_s] = A dY A^T, amax): one grouped GEMM with the
     transposed forward weights u_t = (U^T [36][rows][k_s] split, amax) and the overlap-add of the patches B dV B^T."""
     t = nb * (h // 4) * (wd // 4)
-    dv = new(36, t, r_s)
-    split = 2 if u_t[1] is not None else 1
+    split = _split_kind(k_s, r_s)          # (the kind u_t was built with)
+    dv = torch.empty(36, t, r_s, dtype=torch.float16, device="cuda") if split == 3 else new(36, t, r_s)
+    dvs = amax_slot() if split == 3 else None
     with _timed(_gemm_name(split), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, 36, rows, split)):
-        if split == 2:
+        if split == 3:
+            L.call("gemm_f16_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0, dm[1], u_t[1], 1, dvs)
+        elif split == 2:
             L.call("gemm_f16x2_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0, dm[1], u_t[1])
         else:
             L.call("gemm_bf16x3_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0)
     dx = new(nb, h, wd, r_s)
-    L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s)
+    L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s, dvs)
     return dx
 
 
@@ -482,8 +517,7 @@ def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None
         v, dm = _wino_wgrad_operands(x[n0:n0 + nb], g[n0:n0 + nb], nb, h, wd, cin_s, cout_s, mode,
                                      v_fwd if (mode == 2 and nb == n) else None)
         dw = new(co, ci, 3, 3)
-        with _timed("winograd_wgrad_%s" % ("f16x2" if _wgrad_split(mode) == 3 else "bf16x3") if mode
-                    else "winograd_wgrad_128x128(36 groups)", 2.0 * 36 * t * cin_s * cout_s):
+        with _timed(_wgrad_name(mode), 2.0 * 36 * t * cin_s * cout_s):
             L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci, _wgrad_split(mode), v[1], dm[1])
         total = dw if total is None else total.add_(dw)
         if with_dx:
@@ -898,7 +932,7 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     sums = new(4, c)
     dgb = dm = None
     if as_dm:
-        dm = (new(36, n * (h // 4) * (w // 4), rows), amax_slot() if (GEMM_F16X2 and GEMM_SPLIT) else None)
+        dm = (new(36, n * (h // 4) * (w // 4), rows), amax_slot() if (GEMM_SPLIT and (GEMM_F16X2 or HALF)) else None)
         ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
         L.call("modulate_bwd_reduce_wino", dh.contiguous(), out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c,
                LRELU_SLOPE, ws, dm[1])
@@ -1022,18 +1056,19 @@ class SeanNormTable(torch.autograd.Function):
             keep = [] if (KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2) else None
             for n0 in range(0, n, nb):
                 if has_t:
-                    ua = weight_amax(w2a if has_a else None, tb[n0:n0 + nb]) if split == 2 else None
-                    u = _i16(36 * nb * rows * kp * (3 if split == 1 else 2)) if split else new(36, nb, rows, kp)
+                    ua = weight_amax(w2a if has_a else None, tb[n0:n0 + nb]) if split >= 2 else None
+                    u = _i16(36 * nb * rows * kp * {1: 3, 2: 2, 3: 1}[split]) if split else new(36, nb, rows, kp)
                     L.call("wino43_weights_table", w2a if has_a else None, tb[n0:n0 + nb], u, nb, rows, ca, int(split),
                            ua)
                 else:
                     u, ua = _wino_u(w2a, rows, ca, False, rows, kp, split)
-                m = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split, keep, ua)
+                m, ms = _wino_vgemm(cat[n0:n0 + nb], nb, h, w, ld, u, rows, rows, kp, has_t, split, keep, ua)
                 px = nb * h * w
                 with _timed("spade_modulate_fused", 0.0,
-                            4.0 * (36 * (px // 16) * rows + px * c * (3 if need_scale else 2))):
+                            (2.0 if split == 3 else 4.0) * 36 * (px // 16) * rows
+                            + 4.0 * px * c * (3 if need_scale else 2)):
                     L.call("wino43_output_modulate", m, b2c, x[n0:n0 + nb], mean, invstd, out[n0:n0 + nb],
-                           scale[n0:n0 + nb] if need_scale else None, nb, h, w, c, rows, float(add_one), LRELU_SLOPE)
+                           scale[n0:n0 + nb] if need_scale else None, nb, h, w, c, rows, float(add_one), LRELU_SLOPE, ms)
         else:
             wp = _pack_fwd(w2a, ca, 1) if has_a else None
             with _timed(_variant(geom, True), _flops(geom)):
@@ -1084,8 +1119,7 @@ class SeanNormTable(torch.autograd.Function):
                 v, dm = _wino_wgrad_operands(cat[n0:n0 + nb], None if as_dm else dgb[n0:n0 + nb], nb, h, w, ld, rows,
                                              mode, vcat if (mode == 2 and nb == n) else None, dm_all)
                 dwc = new(rows, NHIDDEN, 3, 3) if ctx.has_a else None
-                with _timed("winograd_wgrad_%s" % ("f16x2" if _wgrad_split(mode) == 3 else "bf16x3") if mode
-                            else "winograd_wgrad_128x128(36 groups)", 2.0 * 36 * nb * tpi * ld * rows):
+                with _timed(_wgrad_name(mode), 2.0 * 36 * nb * tpi * ld * rows):
                     if ctx.has_t:
                         L.call("wino43_wgrad_table", v[0], dm[0], wsw, nbytes, dwc, dtable[n0:n0 + nb], nb * tpi, nb, ca,
                                rows, lab.nc, _wgrad_split(mode), v[1], dm[1])

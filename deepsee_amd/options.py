@@ -25,6 +25,7 @@ DEFAULTS = dict(
     sync_bn=False,           # data-parallel: BatchNorm statistics over the global batch; default sync-free
     sync_bn_clamp=True,      # ... with the reference DP branch's clamp(var, eps) (batchnorm.py:145) instead of var + eps
     preprocess_mode="resize_and_crop", no_flip=False,
+    precision="fp32",        # "fp16": one-term scaled-fp16 matrix-core GEMMs + fp16 Winograd-domain products (BASELINE configs[2])
 )
 
 PRESETS = {

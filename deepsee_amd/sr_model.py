@@ -74,6 +74,10 @@ class SRModel(nn.Module):
             raise RuntimeError("deepsee_amd.SRModel needs an MI355X (HIP) device: there is no CPU fallback")
         L.lib()  # fail loudly if libdeepsee_hip.so is missing
         self.opt = opt
+        prec = getattr(opt, "precision", "fp32")
+        if prec not in ("fp32", "fp16"):
+            raise ValueError("opt.precision must be 'fp32' or 'fp16', got %r" % (prec,))
+        ops.HALF = prec == "fp16"   # process-wide (one model per process): 16-bit matrix-core GEMMs, fp32 everything else
         self.use_E = opt.netE is not None and len(opt.netE) > 0
         self.model_variant = "guided" if (self.use_E and "full" in opt.netE) else "independent"   # sr_model.py:26-30
         gen = torch.Generator().manual_seed(int(getattr(opt, "seed", 0)))

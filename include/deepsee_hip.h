@@ -90,7 +90,7 @@ int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, floa
 int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
                        int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
                        uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
-                       uint64_t res_noise_offset, hipStream_t stream);
+                       uint64_t res_noise_offset, const float* mscale, hipStream_t stream);
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
                         const float* amax_w, hipStream_t stream);
 /* fp32-accurate GEMM on the bf16 matrix cores (operands split into three bf16 terms by their producers, six MFMA
@@ -110,6 +110,17 @@ int dsee_gemm_bf16x3(const void* A3, const void* B3, float* C, long M, int N, in
  * max |dM| into `amax` (atomic max, the caller zeroes it); weights use dsee_absmax(w) (|G g G^T| <= max |g|), and
  * dsee_wino43_weights(..., split = 2, amax_w) writes B2 [K/16][rows][2][16] fp16 scaled by the same function. */
 int dsee_absmax(const float* x, long n, float* amax, hipStream_t stream);
+/* Half-precision compute mode (BASELINE configs[2]'s 16-bit data-parallel training; opt.precision = "fp16"): the same
+ * GEMMs with ONE 16-bit MFMA product per multiply-add -- operands scaled by powers of two and rounded to fp16 (fp32
+ * accumulate, fp32 master weights) -- and the Winograd-domain products M / dV stored as scaled fp16: the GEMM writes
+ * the inverse scale to *cscale and the output transforms take it as `mscale` / `dvscale` (non-NULL = the tensor is fp16).
+ * dsee_wino43_weights split = 3 writes B1 [K/16][rows][16] fp16.  fp16 and not bf16 operands because F(4x4,3x3) amplifies
+ * operand rounding ~10x (2.6 % per layer with bf16, 0.33 % with scaled fp16; a direct bf16 conv: 0.24 %).  Checked against
+ * the fp32 path, not against the CPU reference (<= 3e-2 on fake). */
+int dsee_gemm_f16_af32(const float* A, const void* B1, void* C, long M, int N, int K, long rows_per_group, int b_rows,
+                       int tile, const float* amax_a, const float* amax_b, int c_f16, float* cscale, hipStream_t stream);
+int dsee_gemm_f16_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                         int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
 int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                          int tile, const float* amax_a, const float* amax_b, hipStream_t stream);
 int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
@@ -127,7 +138,7 @@ int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const floa
  * backward: dsee_wino43_wgrad_table (dw2a, dtable) and the plain Winograd data gradient with a ReLU-mask epilogue. */
 int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const float* x, const float* mean,
                                 const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
-                                int rows, float add_one, float slope, hipStream_t stream);
+                                int rows, float add_one, float slope, const float* mscale, hipStream_t stream);
 int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, int split,
                               const float* amax_w, hipStream_t stream);
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
@@ -139,7 +150,7 @@ int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, flo
  * U^T = dsee_wino43_weights(w, transpose_flip = 2) [36][rows(Cin)][Cout], then dx = sum over tiles of the overlapping
  * 6x6 patches B dV B^T (gather form).  mask != NULL: dx = mask > 0 ? dx : 0 (ReLU backward, like DSEE_ACT_MASK). */
 int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
-                              hipStream_t stream);
+                              const float* dvscale, hipStream_t stream);
 size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
                       long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, const float* amax_v,
