@@ -61,18 +61,36 @@ __device__ __forceinline__ float dsee_pow2_scale(float amax) {
   return __builtin_bit_cast(float, (unsigned)e2 << 23);
 }
 
-// *amax = max(*amax, max over the wave of v) for v >= 0 (order independent -> deterministic).  Atomics on one address
-// serialise in the L2 (~12 ns each): the wave first looks at the current maximum (an L2-served load; a stale value only
-// costs a redundant atomic, never a missed update) and issues the atomic only if it would raise it -- after the first few
-// waves almost none do.
-__device__ __forceinline__ void dsee_wave_atomic_absmax(float* amax, float v) {
+// Operand maxima for the fp16 scales.  Accesses of many CUs to ONE address serialise in the L2 (~10 ns each: 65 536
+// per-wave atomics cost 0.65 ms per launch), so a maximum lives in DSEE_AMAX_LINES separate cache lines
+// (amax[i * DSEE_AMAX_STRIDE], i < 64; the true maximum is the max over them): a block reduces through LDS, then ONE
+// thread looks at its line (an L2-served load; a stale value only costs a redundant atomic, never a missed update) and
+// issues the atomic max only if it would raise it.  Max is order independent: deterministic.
+constexpr int DSEE_AMAX_LINES = 64, DSEE_AMAX_STRIDE = 32;   // 64 lines of 128 bytes = 2048 floats per operand
+
+// every thread of the (<= 1024-thread) block must call this, outside divergent control flow
+__device__ __forceinline__ void dsee_block_atomic_absmax(float* amax, float v) {
+  __shared__ float dsee_amax_red[16];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0) dsee_amax_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 1; i < nw; ++i) v = fmaxf(v, dsee_amax_red[i]);
+    unsigned* line = reinterpret_cast<unsigned*>(amax + (blockIdx.x & (DSEE_AMAX_LINES - 1)) * DSEE_AMAX_STRIDE);
     const unsigned bits = __builtin_bit_cast(unsigned, v);
-    const unsigned cur = __hip_atomic_load(reinterpret_cast<unsigned*>(amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (bits > cur) atomicMax(reinterpret_cast<unsigned*>(amax), bits);
+    const unsigned cur = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bits > cur) atomicMax(line, bits);
   }
+}
+
+// the maximum (all 64 lanes of the calling wave must be active; every lane gets the value)
+__device__ __forceinline__ float dsee_amax_read(const float* amax) {
+  float v = amax[(threadIdx.x & 63) * DSEE_AMAX_STRIDE];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
 }
 __device__ __forceinline__ float dsee_absmax4(const f32x4& v) {
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));

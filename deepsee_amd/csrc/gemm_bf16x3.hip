@@ -384,13 +384,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   // fp16x2: operand scales (exact powers of two), undone in the epilogue
   float sa = 1.f, oscale = 1.f;
   if constexpr (TERMS != 3) {
-    sa = pow2_scale(*a.amax_a);
-    oscale = 1.f / (sa * pow2_scale(*a.amax_b));
+    const float ama = dsee_amax_read(a.amax_a), amb = dsee_amax_read(a.amax_b);
+    sa = pow2_scale(ama);
+    oscale = 1.f / (sa * pow2_scale(amb));
   }
   if constexpr (C16) {
     // the product leaves the kernel as fp16: |C| <= K max|A| max|B| is mapped below 2^15 (no overflow, ~2^8 of headroom
     // over typical values); the consumer multiplies by *cscale (the inverse, a power of two)
-    const float sm = 2.f * pow2_scale((float)a.K * *a.amax_a * *a.amax_b);
+    const float sm = 2.f * pow2_scale((float)a.K * dsee_amax_read(a.amax_a) * dsee_amax_read(a.amax_b));
     oscale *= sm;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.cscale = 1.f / sm;
   }
@@ -693,8 +694,8 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   };
   float sp = 1.f, sq = 1.f, oscale = 1.f;   // fp16x2: operand scales (exact powers of two), undone in the epilogue
   if constexpr (TERMS != 3) {
-    sp = pow2_scale(*a.amax_a);
-    sq = pow2_scale(*a.amax_b);
+    sp = pow2_scale(dsee_amax_read(a.amax_a));
+    sq = pow2_scale(dsee_amax_read(a.amax_b));
     oscale = 1.f / (sp * sq);
   }
   const long lda = (long)a.M * 4, ldb = (long)a.N * 4;  // bytes per tile row of P / Q

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_kernel(
     vmax = fmaxf(vmax, store_ata(gx, dM, T, t, rows, pcol));
     vmax = fmaxf(vmax, store_ata(gg, dM, T, t, rows, pcol + 32));
   }
-  if (amax) dsee_wave_atomic_absmax(amax, vmax);
+  if (amax) dsee_block_atomic_absmax(amax, vmax);   // (amax is block-uniform)
   // fold the block's threads that share a channel quad (slots s = tid / C4), fixed order
   const int s = threadIdx.x / C4, ns = 256 / C4;
 #pragma unroll

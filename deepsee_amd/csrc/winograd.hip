@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
     }
   }
   if constexpr (OUT == OUT_F32) {
-    if (amax) dsee_wave_atomic_absmax(amax, vmax);
+    if (amax) dsee_block_atomic_absmax(amax, vmax);   // (amax is block-uniform)
   }
 }
 
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
     }
   }
   if constexpr (OUT == OUT_F32) {
-    if (amax) dsee_wave_atomic_absmax(amax, vmax);
+    if (amax) dsee_block_atomic_absmax(amax, vmax);   // (amax is block-uniform)
   }
 }
 
@@ -599,7 +599,7 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
                                            float* __restrict__ U, int N, int rows, int ca, int Kpad, int split,
                                            const float* __restrict__ amax) {
   const long per = (long)rows * Kpad, total = (long)N * per;
-  const float sc = split >= 2 ? dsee_pow2_scale(*amax) : 1.f;
+  const float sc = split >= 2 ? dsee_pow2_scale(dsee_amax_read(amax)) : 1.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % Kpad);
     const long rr = i / Kpad;
@@ -647,7 +647,7 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
 __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows,
                                      int Kpad, int transpose_flip, int split, const float* __restrict__ amax) {
   const long total = (long)rows * Kpad;
-  const float sc = split >= 2 ? dsee_pow2_scale(*amax) : 1.f;
+  const float sc = split >= 2 ? dsee_pow2_scale(dsee_amax_read(amax)) : 1.f;
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / Kpad), k = (int)(i % Kpad);
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     v = fmaxf(v, dsee_absmax4(*reinterpret_cast<const f32x4*>(x + i * 4)));
   if (blockIdx.x == 0)
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) v = fmaxf(v, fabsf(x[i]));
-  dsee_wave_atomic_absmax(amax, v);
+  dsee_block_atomic_absmax(amax, v);
 }
 
 inline int wgrid(long n) { return (int)min(16384L, (n + 255) / 256); }
@@ -733,7 +733,7 @@ extern "C" {
 int dsee_absmax(const float* x, long n, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(x && amax && n > 0);
   DSEE_CHECK_ARG(((uintptr_t)x & 15) == 0);
-  absmax_kernel<<<(int)min(1024L, (n / 4 + 255) / 256 + 1), 256, 0, st>>>(x, n, amax);
+  absmax_kernel<<<(int)min(128L, (n / 4 + 255) / 256 + 1), 256, 0, st>>>(x, n, amax);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -310,18 +310,20 @@ def _i16(n):
 
 
 _amax_pools = {}
+AMAX_FLOATS = 64 * 32   # DSEE_AMAX_LINES x DSEE_AMAX_STRIDE (dsee_common.h): a maximum lives in 64 separate cache lines
 
 
 def amax_slot():
-    """A zeroed 1-element device tensor for an atomic max |x| (operand scale of the fp16x2 GEMMs).  Slots come from a
-    4096-float pool that is zero-filled once per 4096 uses; every slot is used for one tensor only."""
+    """A zeroed device buffer for the atomic max |x| of one tensor (operand scale of the fp16 GEMMs; also used for the
+    one-float output scale of the 16-bit mode).  Slots come from a 4 MB pool that is zero-filled once per 512 uses;
+    every slot is used for one tensor only."""
     key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     st = _amax_pools.get(key)
-    if st is None or st[1] >= st[0].numel():
-        st = [torch.zeros(4096, dtype=torch.float32, device="cuda"), 0]
+    if st is None or st[1] + AMAX_FLOATS > st[0].numel():
+        st = [torch.zeros(512 * AMAX_FLOATS, dtype=torch.float32, device="cuda"), 0]
         _amax_pools[key] = st
-    t = st[0][st[1]:st[1] + 1]
-    st[1] += 1
+    t = st[0][st[1]:st[1] + AMAX_FLOATS]
+    st[1] += AMAX_FLOATS
     return t
 
 

@@ -27,6 +27,11 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # bring-up on a box with fewer GPUs than ranks: DSEE_DIST_BACKEND=gloo DSEE_ONE_DEVICE=1 runs every rank on cuda:0
+    # with gloo collectives (RCCL refuses two ranks on one device) -- exercises launcher, hooks and bench plumbing only
+    backend = backend or os.environ.get("DSEE_DIST_BACKEND")
+    if os.environ.get("DSEE_ONE_DEVICE") == "1":
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -14,9 +14,13 @@ def load(path, counter):
 
 f, fc = load(sys.argv[1], "FETCH_SIZE")
 w, wc = load(sys.argv[2], "WRITE_SIZE")
-groups = {"winograd_gemm_f16x2": lambda k: "gemm3a_kernel" in k and k.rstrip(")").split("<")[1].split(">")[0].endswith(", 2"),
-          "winograd_gemm_bf16x3": lambda k: "gemm3a_kernel" in k and k.split("<")[1].split(">")[0].endswith(", 3"),
-          "winograd_wgrad_f16x2": lambda k: "gemm3t_kernel" in k and k.split("<")[1].split(">")[0].endswith(", 2"),
+def targ(k, i):
+    return k.split("<")[1].split(">")[0].split(",")[i].strip()
+
+groups = {"winograd_gemm_f16x2": lambda k: "gemm3a_kernel" in k and targ(k, 4) == "2",
+          "winograd_gemm_bf16x3": lambda k: "gemm3a_kernel" in k and targ(k, 4) == "3",
+          "winograd_gemm_f16_1term": lambda k: "gemm3a_kernel" in k and targ(k, 4) == "1",
+          "winograd_wgrad_f16x2": lambda k: "gemm3t_kernel" in k and targ(k, 5) == "2",
           "spade_modulate_fused": lambda k: "wino43_output_modulate" in k}
 out = {}
 for name, pred in groups.items():
