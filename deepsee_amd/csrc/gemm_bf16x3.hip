@@ -150,6 +150,26 @@ __device__ __forceinline__ void mfma_terms(const u32x4 (&af)[TERMS], const u32x4
   }
 }
 
+// product `q` (smallest first) of an (A tile, B tile) pair: lets a caller run product-major over all accumulator tiles,
+// so that consecutive MFMAs never target the same accumulator (no dependent-issue gaps)
+template <int TERMS>
+__device__ __forceinline__ void mfma_product(int q, const u32x4 (&af)[TERMS], const u32x4 (&bf)[TERMS], f32x16& acc) {
+  if constexpr (TERMS == 1) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]), acc, 0,
+                                                 0, 0);
+  } else if constexpr (TERMS == 2) {
+    const int ia = q == 0 ? 1 : 0, ib = q == 1 ? 1 : 0;   // a1*b0, a0*b1, a0*b0
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[ia]), __builtin_bit_cast(f16x8, bf[ib]), acc,
+                                                 0, 0, 0);
+  } else {
+    constexpr int IA[6] = {2, 1, 0, 1, 0, 0}, IB[6] = {0, 1, 2, 0, 1, 0};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[IA[q]]), __builtin_bit_cast(bf16x8, bf[IB[q]]),
+                                                  acc, 0, 0, 0);
+  }
+}
+template <int TERMS>
+constexpr int products() { return TERMS == 3 ? 6 : (TERMS == 2 ? 3 : 1); }
+
 // ---------------------------------------------------------------- pre-split operands, direct to LDS
 // FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `acc`, which is then folded into `tot`
 // (long reductions of the weight gradients: keeps the fp32 accumulation error at the blocked-sum level).
@@ -463,6 +483,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   const int crow = 16 * (wave + NW * (lane >> 5)) + ((lane & 31) >> 1), ckh = lane & 1;
   const unsigned csrc = (unsigned)(crow * 64 + ckh * 32);
   const unsigned cdst = (unsigned)((I::CH * crow + I::pad(crow) + ckh) * 16);
+  auto cv_load = [&](int fstage, f32x4& v0, f32x4& v1) {
+    const unsigned char* f = smem + fstage * F32_STAGE + csrc;
+    v0 = *reinterpret_cast<const f32x4*>(f);
+    v1 = *reinterpret_cast<const f32x4*>(f + 16);
+  };
+  auto cv_store = [&](const f32x4& v0, const f32x4& v1, int img) {
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    u32x4 w[TERMS];
+    split8<TERMS>(v, sa, w);
+    unsigned char* d = smem + OFF_IMG + img * IMG + cdst;
+#pragma unroll
+    for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
+  };
   auto convert = [&](int fstage, int img) {
     const unsigned char* f = smem + fstage * F32_STAGE + csrc;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(f), v1 = *reinterpret_cast<const f32x4*>(f + 16);
@@ -548,11 +581,27 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();
+#if DSEE_GEMM_ABL & 32
+    unsigned long long tL = 0, tB1 = 0, tM = 0, tB2 = 0, tFr = 0, tIs = 0, tCv = 0, t0 = __builtin_readcyclecounter(), t1;
+#define STAMP(acc) t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1;
+#else
+#define STAMP(acc)
+#endif
     for (;;) {
-      // ---- L interval
+      // ---- L interval: the conversion's fp32 rows (landed a slab ago) are read first, the fragment reads follow behind
+      //      them, then the DMA requests, and the conversion arithmetic runs while all those LDS reads return
       const unsigned char* sa_ = smem + OFF_IMG + par * IMG;
       const unsigned char* sb = smem + OFF_B + bcur * BST;
       u32x4 af[MT][TERMS], bf[NT][TERMS];
+      f32x4 cv0, cv1;
+      constexpr bool EARLY = NFS == 3;   // A(k+1) was requested two slabs ago: only B(k+1), A(k+2) are younger
+      if constexpr (EARLY) {
+        if (has_last)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NIB) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NIB - 1) : "memory");
+        if constexpr (!(DSEE_GEMM_ABL & 4)) cv_load(fcv, cv0, cv1);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -568,30 +617,42 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
           else bf[j][p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
         }
       __builtin_amdgcn_sched_barrier(0);
+#if DSEE_GEMM_ABL & 32
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP(tFr)
+#endif
       if constexpr (!(DSEE_GEMM_ABL & 8)) {
         issue_b(bnxt);   // slab k+2
         issue_a(fis);    // slab k+3, into the fp32 stage this wave converted in its previous L interval
       }
       __builtin_amdgcn_sched_barrier(0);
-      wait_own();
+      STAMP(tIs)
+      wait_own();   // B(k+1) (and, two-stage form, A(k+1)) landed before the barrier that publishes them
       asm volatile("" ::: "memory");
-      if constexpr (!(DSEE_GEMM_ABL & 4)) convert(fcv, par ^ 1);
+      if constexpr (!EARLY && !(DSEE_GEMM_ABL & 4)) cv_load(fcv, cv0, cv1);
+      if constexpr (!(DSEE_GEMM_ABL & 4)) cv_store(cv0, cv1, par ^ 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP(tCv)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      STAMP(tB1)
       // ---- M interval
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (DSEE_GEMM_ABL & 1) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          if constexpr (DSEE_GEMM_ABL & 1) {
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int p = 0; p < TERMS; ++p) acc[i][j][p] += __builtin_bit_cast(float, af[i][p][0] ^ bf[j][p][1]);
-          } else {
-            mfma_terms<TERMS>(af[i], bf[j], acc[i][j]);
-          }
-        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < products<TERMS>(); ++q)   // product-major: 8 independent accumulators between reuses
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) mfma_product<TERMS>(q, af[i], bf[j], acc[i][j]);
+      }
       __builtin_amdgcn_s_setprio(0);
       par ^= 1;
       fcv = fcv == NFS - 1 ? 0 : fcv + 1;
@@ -604,11 +665,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
         ct += G;
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(tM)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      STAMP(tB2)
       if (ct >= ntile) break;
     }
     if (!late) __builtin_amdgcn_s_barrier();
+#if DSEE_GEMM_ABL & 32
+    if (lane == 0 && blockIdx.x < 8) {   // per-wave cycle totals: fragment reads | DMA issue | wait+convert | barrier 1 | MFMA(+stores) | barrier 2
+      float* o = a.C + (blockIdx.x * 8 + wave) * 8;
+      o[0] = (float)tFr; o[1] = (float)tIs; o[2] = (float)tCv; o[3] = (float)tB1; o[4] = (float)tM; o[5] = (float)tB2;
+      o[6] = (float)(tL + 0); o[7] = 0.f;
+    }
+#endif
   } else {
     for (;;) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
