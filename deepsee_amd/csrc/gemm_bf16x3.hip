@@ -536,7 +536,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   issue_b(1);   // slab 1
   issue_a(1);
   if constexpr (NFS == 3) issue_a(2);   // slab 2 (A only: one further ahead)
-  wait_own();   // slab 0 landed (B(1), A(1)[, A(2)] may still be in flight)
+  if constexpr (NW == 8 && NFS == 3)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // slabs 0 and 1 landed: the ping-pong loop reads slab 1's fp32 rows
+                                                        // at the head of its first interval (only A(2) may be in flight)
+  else
+    wait_own();   // slab 0 landed (B(1), A(1) may still be in flight)
   asm volatile("" ::: "memory");
   convert(0, 0);
   // slab parity (image), fp32 stage of the NEXT slab to convert / of the slab to request, B stage computed / to fill
@@ -1002,7 +1006,30 @@ int launch_gemm3t(Gemm3Args a, int nz, hipStream_t st) {
 
 }  // namespace
 
+// test hook: every LDS byte of every CU <- quiet-NaN pattern (a kernel's LDS keeps what the previous workgroup on that CU
+// left there, so a pipelined kernel that reads a stage before its data has landed normally sees plausible stale values)
+__global__ __launch_bounds__(256, 1) void lds_poison_kernel(float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* w = reinterpret_cast<unsigned*>(smem);
+  for (int i = threadIdx.x; i < 163840 / 4; i += 256) w[i] = 0x7FC00000u;
+  __syncthreads();
+  if (w[(threadIdx.x * 97) % (163840 / 4)] == 1u) sink[0] = 1.f;   // keeps the stores
+}
+
 extern "C" {
+
+int dsee_selftest_lds_poison(float* sink, hipStream_t st) {
+  DSEE_CHECK_ARG(sink);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              163840);
+    attr_done = true;
+  }
+  lds_poison_kernel<<<4 * gemm3_num_cus(), 256, 163840, st>>>(sink);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
 
 /* C[m][n] = sum_k A[m][k] * B[m / rows_per_group][n][k]  in fp32 accuracy from bf16x3-split operands.
  * A3 [K/16][M][3][16] bf16, B3 [groups][K/16][b_rows][3][16] bf16 (b_rows >= N rows per group), C [M][N] fp32.

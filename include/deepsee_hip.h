@@ -125,6 +125,9 @@ int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N
                          int tile, const float* amax_a, const float* amax_b, hipStream_t stream);
 int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                            int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
+/* Test hook (no reference counterpart): fills the LDS of every CU with NaN bit patterns, so that a pipelined kernel
+ * launched next shows a read of a not-yet-landed LDS stage as NaN instead of as stale but plausible data.  sink: one float. */
+int dsee_selftest_lds_poison(float* sink, hipStream_t stream);
 int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
                             float* out, hipStream_t stream);
 /* Weight gradient of the same convs in the Winograd domain (backward of architecture.py:98,122):

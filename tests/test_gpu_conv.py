@@ -370,3 +370,52 @@ def test_f16x2_special_values():
     c = run(a2, b)
     assert not torch.isfinite(c[7]).any() or torch.isnan(c[7]).any() or torch.isinf(c[7]).any()
     assert torch.isfinite(c[8]).all()
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "f16"])
+def test_pipelined_gemms_with_poisoned_lds(mode):
+    """Hazard check of the hand-pipelined GEMM loops (LDS-DMA rings, vmcnt / barrier protocol): before every launch the
+    LDS of all CUs is filled with NaN patterns (dsee_selftest_lds_poison), so a fragment or conversion read of a stage
+    whose data has not landed yields NaN instead of stale data from the previous launch.  NT form (128 and 256 tiles,
+    short and long K, one and several tiles per block) and the split-K TN form; every launch must be finite and
+    bit-identical to the first."""
+    from deepsee_amd import lib as L
+    g = torch.Generator().manual_seed(5)
+    sink = torch.zeros(1, device="cuda")
+
+    def nt(groups, tg, n, k, tile):
+        a = torch.randn(groups * tg, k, generator=g).cuda()
+        b = torch.randn(groups, n, k, generator=g)
+        am_a, am_b = _amax(float(a.abs().max())), _amax(float(b.abs().max()))
+        c = torch.empty(groups * tg, n, device="cuda")
+        if mode == "f16x2":
+            b2 = torch.stack([_split2_rows(b[i], _pow2_scale(float(b.abs().max()))) for i in range(groups)]).cuda()
+            return lambda: (L.call("gemm_f16x2_af32", a, b2, c, groups * tg, n, k, tg, n, tile, am_a, am_b), c)[1]
+        if mode == "f16":
+            xs = b * _pow2_scale(float(b.abs().max()))
+            b1 = xs.half().view(groups, n, k // 16, 16).permute(0, 2, 1, 3).contiguous().view(torch.int16).cuda()
+            cs = torch.zeros(1, device="cuda")
+            return lambda: (L.call("gemm_f16_af32", a, b1, c, groups * tg, n, k, tg, n, tile, am_a, am_b, 0, cs), c)[1]
+        b3 = torch.stack([_split_rows(b[i]) for i in range(groups)]).cuda()
+        return lambda: (L.call("gemm_bf16x3_af32", a, b3, c, groups * tg, n, k, tg, n, tile), c)[1]
+
+    def tn(groups, t, rp, rq, splits):
+        p = torch.randn(groups * t, rp, generator=g).cuda()
+        q = torch.randn(groups * t, rq, generator=g).cuda()
+        am_p, am_q = _amax(float(p.abs().max())), _amax(float(q.abs().max()))
+        c = torch.empty(groups * splits, rp, rq, device="cuda")
+        name = {"f16x2": "gemm_f16x2_tn_f32", "f16": "gemm_f16_tn_f32", "bf16x3": "gemm_bf16x3_tn_f32"}[mode]
+        extra = () if mode == "bf16x3" else (am_p, am_q)
+        return lambda: (L.call(name, p, q, c, groups, t, rp, rq, rq, splits, *extra), c)[1]
+
+    runs = [nt(2, 256, 128, 32, 1), nt(1, 256, 256, 16, 2), nt(36, 4096, 256, 160, 2), nt(40, 2048, 512, 512, 2),
+            nt(600, 128, 128, 64, 1), tn(2, 256, 256, 128, 1), tn(72, 512, 256, 160, 2), tn(36, 1024, 512, 256, 4)]
+    for run in runs:
+        first = None
+        for it in range(6):
+            L.call("selftest_lds_poison", sink)
+            out = run().clone()
+            assert torch.isfinite(out).all(), "NaN from a poisoned LDS stage (launch %d)" % it
+            if first is None:
+                first = out
+            assert torch.equal(out, first)

@@ -19,3 +19,4 @@ python $R/tools/rocpd_summary.py /tmp/prof/ev_results.db > $O/kernel_stats.md
 for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-run > /dev/null 2>&1; done
 python $R/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE/*counter_collection.csv /tmp/pmc_WRITE_SIZE/*counter_collection.csv > $O/pmc_traffic.json
 ls -la $O
+cd $R && DSEE_LIB=tools/exp/libabl_32.so python tools/exp/gemm_phases.py > $O/gemm_phases.txt 2>&1

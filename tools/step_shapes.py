@@ -23,10 +23,10 @@ def wr(x, dout, geom, cout, cin, kh, kw, cin_first=0):
 ops.wgrad_raw = wr
 _t = ops._timed
 class T(_t):
-    def __init__(self, name, flops):
+    def __init__(self, name, flops, *rest):
         if name.startswith("conv_wgrad"): name = getattr(ops, "_wg", name)
         if name.startswith("winograd"): name = "%s %.3f TFLOP" % (name, flops / 1e12)
-        super().__init__(name, flops)
+        super().__init__(name, flops, *rest)
 ops._timed = T
 ops.PROFILE = {}
 step(); torch.cuda.synchronize()
