@@ -1174,6 +1174,7 @@ int dsee_gemm_f16_tn_f32(const float* P, const float* Q, float* C, int groups, l
   a.a_slab_bytes = (long)16 * rows_p * 4; a.b_slab_bytes = (long)16 * rows_q * 4;
   a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
   if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 1>(a, groups * splits, st);
+  if (rows_q % 256 == 0 && !(DSEE_GEMM_ABL & 128)) return launch_gemm3t<2, 4, 4, 2, 0, 1>(a, groups * splits, st);
   return launch_gemm3t<4, 2, 2, 2, 16, 1>(a, groups * splits, st);
 }
 
@@ -1192,6 +1193,10 @@ int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups,
   a.a_slab_bytes = (long)16 * rows_p * 4; a.b_slab_bytes = (long)16 * rows_q * 4;
   a.a_z_bytes = nk * a.a_slab_bytes; a.b_z_bytes = nk * a.b_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
   if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 2>(a, groups * splits, st);
+  // 256x256 tile where Q is wide enough: 24 instead of 12 MFMAs per wave and slab for 16 instead of 12 transposed +
+  // split values per lane (512x512 @256^2: 4.7 -> 2.8 ms).  Its 128 accumulator registers leave no room for the second
+  // accumulator level: one fp32 chain per split (7e-7 of the result at 4096 tiles per split, a library sgemm: 1.2e-6).
+  if (rows_q % 256 == 0 && !(DSEE_GEMM_ABL & 128)) return launch_gemm3t<2, 4, 4, 2, 0, 2>(a, groups * splits, st);
   return launch_gemm3t<4, 2, 2, 2, 16, 2>(a, groups * splits, st);
 }
 

@@ -28,7 +28,10 @@ for name, g, tg, n, k in nt:
             t = timeit(lambda: L.call("gemm_f16x2_af32", a, b, c, m, n, k, tg, n, tile, one, one))
         fl, by = 2.0 * m * n * k, m * k * 4.0 + m * n * 4.0 + g * n * k * 2.0 * terms
         print("%-36s tile %s: %.3f ms  %4.0f TF/s fp32-eq  %.2f GB -> %.2f TB/s" % (name, "128" if tile == 1 else "256", t, fl / t / 1e9, by / 1e9, by / t / 1e9))
-tn = [("wgrad conv 512x512 @256^2", 36, 32768, 512, 512, 1), ("wgrad table 1024x160 @256^2", 288, 4096, 1024, 160, 1),
+tn = [("wgrad conv 512x512 @256^2", 36, 32768, 512, 512, 1), ("wgrad conv 512x512 @256^2 split 8", 36, 32768, 512, 512, 8),
+      ("wgrad conv 512x512 @256^2 split 16", 36, 32768, 512, 512, 16), ("wgrad conv 512x512 @256^2 split 32", 36, 32768, 512, 512, 32),
+      ("wgrad conv 512x512 @128^2 split 8", 36, 8192, 512, 512, 8), ("wgrad conv 512x512 @64^2 split 4", 36, 2048, 512, 512, 4),
+      ("wgrad conv 512x512 @64^2 split 2", 36, 2048, 512, 512, 2), ("wgrad table 1024x160 @256^2", 288, 4096, 1024, 160, 1),
       ("wgrad conv 512x512 @128^2", 36, 8192, 512, 512, 2), ("wgrad table 1024x160 @128^2", 288, 1024, 1024, 160, 1)]
 for name, g, t_, rp, rq, sp in tn:
     p = torch.randn(g * t_, rp, device="cuda"); q = torch.randn(g * t_, rq, device="cuda")
