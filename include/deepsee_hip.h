@@ -125,6 +125,15 @@ int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N
                          int tile, const float* amax_a, const float* amax_b, hipStream_t stream);
 int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                            int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
+/* Evaluation metrics on the device: per image PSNR, SSIM and RMSE of `fake` against `real`, both fp32 NHWC
+ * [N][H][W][Cs] in [-1, 1] (channels 0..2 used).  Replaces MetricsEvaluator.collect_samples' per-sample CPU loop
+ * (evaluator/evaluation.py:88-137: util/util.py:72-103 tensor2im quantisation, evaluator/calculate_PSNR_SSIM.py:71-79
+ * calculate_psnr, :81-122 calculate_ssim -- 11x11 Gaussian window, sigma 1.5, valid region, float64 -- and the RMSE of
+ * evaluation.py:107-110).  out [N][3] doubles = {psnr (inf for identical images), ssim, rmse}; workspace from
+ * dsee_psnr_ssim_workspace; deterministic (no atomics).  H, W > 10. */
+size_t dsee_psnr_ssim_workspace(int N, int H, int W);
+int dsee_psnr_ssim(const float* fake, const float* real, int N, int H, int W, int Cs, double* workspace,
+                   size_t workspace_bytes, double* out, hipStream_t stream);
 /* Test hook (no reference counterpart): fills the LDS of every CU with NaN bit patterns, so that a pipelined kernel
  * launched next shows a read of a not-yet-landed LDS stage as NaN instead of as stale but plausible data.  sink: one float. */
 int dsee_selftest_lds_poison(float* sink, hipStream_t stream);

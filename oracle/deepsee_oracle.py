@@ -390,6 +390,59 @@ def device_pipeline_reference(image_u8, label_u8, flip, label_nc):
     return img.permute(0, 3, 1, 2).contiguous(), lab[:, None].contiguous()
 
 
+def metric_case_inputs(seed, n, h, w, kind):
+    """Seeded (fake, real) image pairs [n,3,h,w] of tests/golden/metrics.json (shared by the generator and the tests)."""
+    g = torch.Generator().manual_seed(seed)
+    real = torch.rand(n, 3, h, w, generator=g) * 2 - 1
+    if kind == "smooth":
+        real = F.interpolate(torch.rand(n, 3, 8, 8, generator=g), (h, w), mode="bilinear") * 2 - 1
+    if kind == "noise":
+        fake = torch.rand(n, 3, h, w, generator=g) * 2 - 1
+    elif kind == "saturated":
+        fake = real * 1.7 + 0.2 * torch.randn(n, 3, h, w, generator=g)     # values beyond [-1, 1]: clipped by tensor2im
+    elif kind == "identical":
+        fake = real.clone()
+    else:
+        fake = real + 0.05 * torch.randn(n, 3, h, w, generator=g)
+    return fake, real
+
+
+def psnr_ssim_rmse(fake, real):
+    """MetricsEvaluator.collect_samples' PSNR / SSIM / RMSE for a batch (evaluator/evaluation.py:88-137): images
+    [N,3,H,W] in [-1,1] -> float64 [N,3].  tensor2im (util/util.py:93-103): uint8(clip((x+1)/2*255, 0, 255)) in float32;
+    calculate_psnr (evaluator/calculate_PSNR_SSIM.py:71-79) in float64 over the whole image; calculate_ssim (:81-122):
+    Gaussian 11x11 window (cv2.getGaussianKernel(11, 1.5) = normalised exp(-(i-5)^2/(2*1.5^2)), outer product), windowed
+    moments on the valid region, C1 = (0.01*255)^2, C2 = (0.03*255)^2, mean of the map over positions and channels (the
+    channel loop at :113-116 passes the full 3-channel image each time); RMSE on the [-1,1] values (evaluation.py:107-110).
+    Pinned by tests/golden/metrics.json, which oracle/gen_golden.py writes by running the reference's own functions (cv2 is
+    absent from this image: its two calls, getGaussianKernel and filter2D, are provided there from their documented
+    definitions through scipy)."""
+    import numpy as np
+    from scipy.signal import correlate2d
+    k = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    k /= k.sum()
+    window = np.outer(k, k)
+    out = []
+    for f, r in zip(fake, real):
+        f32, r32 = f.detach().cpu().float().numpy(), r.detach().cpu().float().numpy()
+        q = [np.clip((np.transpose(a, (1, 2, 0)) + 1) / 2.0 * 255.0, 0, 255).astype(np.uint8) for a in (f32, r32)]
+        a, b = q[0].astype(np.float64), q[1].astype(np.float64)
+        mse = np.mean((a - b) ** 2)
+        psnr = float("inf") if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
+        c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        vals = []
+        for c in range(3):
+            filt = lambda z: correlate2d(z, window, mode="valid")
+            mu1, mu2 = filt(a[..., c]), filt(b[..., c])
+            s11 = filt(a[..., c] ** 2) - mu1 ** 2
+            s22 = filt(b[..., c] ** 2) - mu2 ** 2
+            s12 = filt(a[..., c] * b[..., c]) - mu1 * mu2
+            vals.append(((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s11 + s22 + c2)))
+        rmse = float(np.sqrt(np.mean((f32.astype(np.float64) - r32.astype(np.float64)) ** 2)))
+        out.append([psnr, float(np.mean(vals)), rmse])
+    return torch.tensor(out, dtype=torch.float64)
+
+
 def nearest_resize(x, size):
     """F.interpolate(mode='nearest'): src = floor(dst * in / out) (SURVEY B-3)."""
     return F.interpolate(x, size=size, mode="nearest")

@@ -17,6 +17,8 @@ import random
 import sys
 import types
 
+import numpy as np
+
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -387,6 +389,60 @@ def host_logic():
     print("host_logic                       written")
 
 
+def install_cv2_stub():
+    """cv2 is absent from this image.  evaluator/calculate_PSNR_SSIM.py needs two of its functions; they are provided
+    from OpenCV's documented definitions so that the REFERENCE's PSNR / SSIM code (quantisation, window, cropping,
+    constants, the channel loop) runs unmodified:
+      getGaussianKernel(ksize, sigma): G_i = alpha * exp(-(i - (ksize-1)/2)^2 / (2 sigma^2)), sum G_i = 1, [ksize,1] float64
+      filter2D(src, -1, kernel): correlation, anchor at the kernel centre, BORDER_REFLECT_101, every channel separately
+    (the border mode is irrelevant to the reference: it keeps [5:-5, 5:-5] only)."""
+    import types
+    import numpy as np
+    from scipy import ndimage
+    cv2 = types.ModuleType("cv2")
+
+    def getGaussianKernel(ksize, sigma):
+        x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        g = np.exp(-(x ** 2) / (2.0 * sigma ** 2))
+        return (g / g.sum()).reshape(ksize, 1)
+
+    def filter2D(src, ddepth, kernel):
+        assert ddepth == -1
+        if src.ndim == 2:
+            return ndimage.correlate(src, kernel, mode="mirror")
+        return np.stack([ndimage.correlate(src[..., c], kernel, mode="mirror") for c in range(src.shape[2])], axis=2)
+
+    cv2.getGaussianKernel, cv2.filter2D = getGaussianKernel, filter2D
+    sys.modules["cv2"] = cv2
+
+
+def metrics():
+    """(f4) PSNR / SSIM / RMSE of MetricsEvaluator.collect_samples (evaluator/evaluation.py:88-137), from the
+    reference's own tensor2im / calculate_psnr / calculate_ssim on seeded image pairs -> tests/golden/metrics.json
+    (inputs are regenerated from the recorded seeds by the tests)."""
+    install_cv2_stub()
+    from evaluator.calculate_PSNR_SSIM import calculate_psnr, calculate_ssim
+    from util.util import tensor2im
+    cases = []
+    for seed, (n, h, w), kind in ((1, (2, 32, 32), "noise"), (2, (3, 48, 40), "close"), (3, (1, 64, 64), "smooth"),
+                                 (4, (2, 21, 37), "saturated"), (5, (1, 32, 32), "identical")):
+        fake, real = O.metric_case_inputs(seed, n, h, w, kind)
+        fake_np, real_np = tensor2im(fake), tensor2im(real)
+        psnr = [calculate_psnr(fake_np[i], real_np[i]) for i in range(n)]
+        ssim = [float(calculate_ssim(fake_np[i], real_np[i])) for i in range(n)]
+        rmse = [float(v) for v in torch.nn.MSELoss(reduction="none")(fake, real).mean(dim=[1, 2, 3]).sqrt()]
+        mine = O.psnr_ssim_rmse(fake, real)
+        for i in range(n):
+            assert (psnr[i] == mine[i, 0]) or abs(psnr[i] - float(mine[i, 0])) < 1e-9 * abs(psnr[i]), (psnr[i], mine[i])
+            assert abs(ssim[i] - float(mine[i, 1])) < 1e-10, (ssim[i], mine[i])
+            assert abs(rmse[i] - float(mine[i, 2])) < 1e-6 * rmse[i] + 1e-12
+        cases.append({"seed": seed, "shape": [n, h, w], "kind": kind, "psnr": [repr(p) for p in psnr], "ssim": ssim,
+                      "rmse": rmse, "u8_checksum": [int(fake_np.astype(np.int64).sum()), int(real_np.astype(np.int64).sum())]})
+    with open(os.path.join(ROOT, "tests", "golden", "metrics.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "cases": cases}, f, indent=1)
+    print("metrics                          written")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*")
@@ -404,6 +460,8 @@ def main():
         layer_kats()
     if not a.cases or "host_logic" in a.cases:
         host_logic()
+    if not a.cases or "metrics" in a.cases:
+        metrics()
 
 
 if __name__ == "__main__":

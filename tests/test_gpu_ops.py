@@ -1,5 +1,7 @@
 """Layer-level parity of the HIP ops (through the C ABI) against torch-CPU fp32 restatements / the oracle,
 forward and backward, on the same seeded inputs."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -609,3 +611,38 @@ def test_resblock_fused_noise_shortcut_and_gradient_sink(kind, ups):
     for a, b in zip(*res):
         assert rel(a, b) < 2e-5, (a.shape, rel(a, b))
     assert float(res[0][-1].abs().max()) > 0
+
+
+def test_psnr_ssim_rmse_kernel_matches_reference_numbers():
+    """dsee_psnr_ssim against tests/golden/metrics.json -- the reference's own tensor2im / calculate_psnr /
+    calculate_ssim outputs -- and against the oracle on a 256x256 pair: PSNR from exact integer sums (1e-12), SSIM in
+    float64 (1e-9; the reference's filter2D and the kernel's separable window differ in summation order), RMSE 1e-6;
+    identical images give PSNR = inf; values beyond [-1, 1] are clipped by the quantisation as in tensor2im.  Also the
+    MetricsEvaluator mirror: buffers, get_result keys, per-sample CSV rows."""
+    import json, math, tempfile
+    from deepsee_amd import metrics as M, ops
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics.json")))["cases"]
+    for rec in cases:
+        n, h, w = rec["shape"]
+        fake, real = O.metric_case_inputs(rec["seed"], n, h, w, rec["kind"])
+        got = M.psnr_ssim_rmse(fake.cuda(), real.cuda())
+        for i in range(n):
+            ref = float(rec["psnr"][i])
+            assert (math.isinf(ref) and math.isinf(float(got[i, 0]))) or abs(float(got[i, 0]) - ref) <= 1e-12 * abs(ref), rec["kind"]
+            assert abs(float(got[i, 1]) - rec["ssim"][i]) <= 1e-9, (rec["kind"], float(got[i, 1]), rec["ssim"][i])
+            assert abs(float(got[i, 2]) - rec["rmse"][i]) <= 1e-6 * rec["rmse"][i] + 1e-12
+    g = torch.Generator().manual_seed(9)
+    real = torch.nn.functional.interpolate(torch.rand(2, 3, 32, 32, generator=g), (256, 256), mode="bicubic").clamp(0, 1) * 2 - 1
+    fake = (real + 0.1 * torch.randn(2, 3, 256, 256, generator=g)).clamp(-1, 1)
+    want = O.psnr_ssim_rmse(fake, real)
+    got = M.psnr_ssim_rmse(ops.to_nhwc(fake.cuda()), ops.to_nhwc(real.cuda()))        # native layout in, no conversion
+    assert float((got[:, 0] - want[:, 0]).abs().max()) <= 1e-11 and float((got[:, 1] - want[:, 1]).abs().max()) <= 1e-9
+    assert float((got[:, 2] - want[:, 2]).abs().max()) <= 1e-9
+    with tempfile.TemporaryDirectory() as d:
+        ev = M.MetricsEvaluator(write_details=True, folder_out=d, extra_columns=("split",), extra_columns_content=("val",))
+        ev.collect_samples(fake.cuda(), real.cuda(), name=["a/7394.jpg", "a/12.png"])
+        res = ev.get_result()
+        assert list(res) == ["psnr/mean", "ssim/mean", "rmse/mean", "psnr/std", "ssim/std", "rmse/std", "n_samples"]
+        assert res["n_samples"] == 2 and abs(res["ssim/mean"] - float(want[:, 1].mean())) <= 1e-9
+        rows = open(os.path.join(d, "metrics.csv")).read().strip().splitlines()
+        assert rows[0] == "split,ID,PSNR,SSIM,RMSE" and rows[1].startswith("val,7394,") and rows[2].startswith("val,12,")

@@ -14,7 +14,7 @@ from oracle import deepsee_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "*.json"))
-               if not p.endswith(("layer_kats.json", "host_logic.json")))
+               if not p.endswith(("layer_kats.json", "host_logic.json", "metrics.json")))
 
 # Bounds: losses / outputs are tight; gradients are bounded by the reference's OWN noise floor
 # (oracle/noise_floor.py: a 1e-7 relative input perturbation moves G-step grads by 2.6e-3 and
@@ -212,3 +212,21 @@ def check_init_stats(tensors, stats):
             assert abs(float(v.mean())) <= 6.0 * ref["std"] / n ** 0.5 + 1e-9, k
         else:
             assert float(v.abs().max()) <= 8 * max(ref["std"], abs(ref["max"]), abs(ref["min"])) + 1e-9, k
+
+
+# ------------------------------------------------------------------ evaluation metrics pinned by gen_golden.metrics()
+METRICS = json.load(open(os.path.join(GOLD, "metrics.json")))["cases"]
+
+
+@pytest.mark.parametrize("rec", METRICS, ids=lambda r: r["kind"])
+def test_oracle_psnr_ssim_rmse_match_reference(rec):
+    """MetricsEvaluator.collect_samples' PSNR / SSIM / RMSE (evaluation.py:88-137): the oracle's restatement against the
+    numbers the reference's own tensor2im / calculate_psnr / calculate_ssim produced for the same seeded images."""
+    n, h, w = rec["shape"]
+    fake, real = O.metric_case_inputs(rec["seed"], n, h, w, rec["kind"])
+    got = O.psnr_ssim_rmse(fake, real)
+    for i in range(n):
+        ref_psnr = float(rec["psnr"][i])
+        assert float(got[i, 0]) == ref_psnr or abs(float(got[i, 0]) - ref_psnr) <= 1e-12 * abs(ref_psnr)
+        assert abs(float(got[i, 1]) - rec["ssim"][i]) <= 1e-10
+        assert abs(float(got[i, 2]) - rec["rmse"][i]) <= 1e-6 * rec["rmse"][i] + 1e-12
