@@ -120,6 +120,9 @@ class DeviceNoise:
     def uniform(self, shape, tag):
         return self._fill(shape, False)
 
+    def normal(self, shape, tag):
+        return self._fill(shape, True)
+
 
 class ReplayNoise:
     """Test-time source: replays a tape recorded from the oracle (oracle.RecordingCtl) so both sides see the
@@ -145,6 +148,11 @@ class ReplayNoise:
 
     def uniform(self, shape, tag):
         v = self._next("uniform", tag)
+        assert tuple(v.shape) == tuple(shape)
+        return v.cuda()
+
+    def normal(self, shape, tag):
+        v = self._next("normal", tag)
         assert tuple(v.shape) == tuple(shape)
         return v.cuda()
 
@@ -409,8 +417,10 @@ class StyleEncoder(nn.Module):
             nw = torch.sigmoid(self.noise_weights)[None, :, None]
             if self.dist == "uniform":
                 z = noise.uniform(tuple(sm.shape), "style_noise")
+            elif self.dist == "normal":
+                z = noise.normal(tuple(sm.shape), "style_noise")
             else:
-                raise NotImplementedError("noisy_style_dist=%s" % self.dist)
+                raise ValueError("Does not exist: {}".format(self.dist))      # encoder.py:66
             sm = (sm + ((z * 2 - 1) * self.scale) * nw).clamp(-1, 1)
         return sm
 

@@ -40,6 +40,10 @@ CASES = {
     "guided_4to32_bs2_ngf8": dict(opt=dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8,
                                             netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True),
                                   n=2, seed=13, iters=1),
+    # the other corruption distribution of encoder.py:59-66 ('normal': (randn * 2 - 1) * scale)
+    "guided_normal_4to32_bs2_ngf8": dict(opt=dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8,
+                                                   netE="fullstyle", noisy_style_scale=0.05, noisy_style_dist="normal",
+                                                   guiding_style_image=True), n=2, seed=17, iters=1),
     # two full iterations: double BN/SN update per iteration + Adam
     "indep_4to32_two_iters_ngf8": dict(opt=dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8),
                                        n=2, seed=14, iters=2),

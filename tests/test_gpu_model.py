@@ -20,6 +20,8 @@ CASES = {
     "indep_8to64_ngf8": dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8),
     "guided_4to32_ngf8": dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8, netE="fullstyle",
                               noisy_style_scale=0.05, guiding_style_image=True),
+    "guided_normal_4to32_ngf8": dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8, netE="fullstyle",
+                                     noisy_style_scale=0.05, noisy_style_dist="normal", guiding_style_image=True),
     "config1_4to32_full": dict(start_size=4, crop_size=32, load_size=32, batchSize=2),
     "puresean_4to128_ngf4": dict(start_size=4, crop_size=128, load_size=512, batchSize=2, ngf=4, add_noise=False,
                                  max_fm_size=64),
