@@ -27,6 +27,7 @@ Extra objects on the line:
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -269,6 +270,9 @@ def main():
                                          "frac": round(v["tflop"] / (v["ms"] / 1e3) / kernel_peak(k), 3),
                                          "gbps": round(v["gb"] / (v["ms"] / 1e3), 1) if v["gb"] else None}
                                      for k, v in kernels.items()}}
+        losses = {k: float(v.detach()) for k, v in tm.get_latest_losses().items()}
+        if not all(math.isfinite(v) for v in losses.values()):
+            raise RuntimeError("bench.py: non-finite losses after the timed steps %r -- the measurement is void" % losses)
         out = {
             "metric": "train-step images/sec (G+D fwd+bwd), 8x 32->256 bs=8" if headline
                       else "train-step images/sec (G+D fwd+bwd), %s bs=%d" % (args.config, n),
@@ -282,9 +286,16 @@ def main():
             "config": {"workload": "%s, 19-class masks, bs=%d per GPU, fp32 G+D train step (BASELINE.json %s)"
                                    % (args.config.replace("_", " "), n, ref),
                        "global_batch": n * world, "parallelism": "dp%d" % world,
-                       "losses": {k: float(v.detach()) for k, v in tm.get_latest_losses().items()}},
+                       "losses": losses},
             "roofline": roof,
         }
+        # whole-model rate in the reference's dense-convolution FLOP count (conv MACs x 2 of the reference's
+        # graph per image and iteration); the Winograd layers execute 2.25x fewer multiplies than that
+        dense = {"independent_8x_256": 7.15, "guided_8x_256": 7.15, "independent_32x_512": 22.6}[args.config]
+        out["model_flops"] = {"reference_dense_tflop_per_image": dense, "achieved_tflops": out["value"] * dense,
+                              "fp32_matrix_peak_tflops": 157.3 * world,
+                              "note": "N * F_iter / t_iter with SURVEY 8(d)'s F_iter; exceeds the fp32 MFMA peak because "
+                                      "the wide layers run on the fp16 matrix cores in the Winograd domain"}
         if fused:
             g = fused["gb"] / (fused["ms"] / 1e3)
             out["spade_fused"] = {"kernel": "wino43_output_modulate (output transform of the gamma/beta GEMM + BN-normalise "
