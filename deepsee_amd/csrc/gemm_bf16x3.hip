@@ -483,18 +483,32 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   const int crow = 16 * (wave + NW * (lane >> 5)) + ((lane & 31) >> 1), ckh = lane & 1;
   const unsigned csrc = (unsigned)(crow * 64 + ckh * 32);
   const unsigned cdst = (unsigned)((I::CH * crow + I::pad(crow) + ckh) * 16);
+  // rows 8..15 of a 16-row instruction read their two 16-byte chunks in the other order: with 64-byte rows the 16 lanes of
+  // a ds_read_b128 group otherwise hit every second 16-byte bank group twice
+  const bool cswap = ((lane & 31) >> 4) != 0;
+  const unsigned csrc0 = csrc + (cswap ? 16u : 0u), csrc1 = csrc + (cswap ? 0u : 16u);
   auto cv_load = [&](int fstage, f32x4& v0, f32x4& v1) {
-    const unsigned char* f = smem + fstage * F32_STAGE + csrc;
-    v0 = *reinterpret_cast<const f32x4*>(f);
-    v1 = *reinterpret_cast<const f32x4*>(f + 16);
+    const unsigned char* f = smem + fstage * F32_STAGE;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(f + csrc0), a1 = *reinterpret_cast<const f32x4*>(f + csrc1);
+    v0 = cswap ? a1 : a0;
+    v1 = cswap ? a0 : a1;
   };
   auto cv_store = [&](const f32x4& v0, const f32x4& v1, int img) {
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     u32x4 w[TERMS];
     split8<TERMS>(v, sa, w);
     unsigned char* d = smem + OFF_IMG + img * IMG + cdst;
+    if constexpr (TERMS == 2) {
+      // rows 2, 3 (mod 4) store their second term first: the 8 lanes of a ds_write_b128 group (4 rows x 2 k-halves) then
+      // cover 8 different 16-byte bank groups (term-major order put rows r and r + 2 on the same ones)
+      const bool sw = ((crow >> 1) & 1) != 0;
+      const u32x4 first = sw ? w[1] : w[0], second = sw ? w[0] : w[1];
+      *reinterpret_cast<u32x4*>(d + (sw ? 32 : 0)) = first;
+      *reinterpret_cast<u32x4*>(d + (sw ? 0 : 32)) = second;
+    } else {
 #pragma unroll
-    for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
+      for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
+    }
   };
   auto convert = [&](int fstage, int img) {
     const unsigned char* f = smem + fstage * F32_STAGE + csrc;
@@ -826,15 +840,30 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     u32x4 w[TERMS];
     split8<TERMS>(v, sc, w);
     unsigned char* d = img + (I::CH * row + I::pad(row) + th) * 16;
+    if constexpr (TERMS == 2) {   // same store order rule as gemm3a's cv_store (8 consecutive rows per ds_write_b128 group)
+      const bool sw = ((row >> 1) & 1) != 0;
+      const u32x4 first = sw ? w[1] : w[0], second = sw ? w[0] : w[1];
+      *reinterpret_cast<u32x4*>(d + (sw ? 32 : 0)) = first;
+      *reinterpret_cast<u32x4*>(d + (sw ? 0 : 32)) = second;
+    } else {
 #pragma unroll
-    for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
+      for (int p = 0; p < TERMS; ++p) *reinterpret_cast<u32x4*>(d + p * 32) = w[p];
+    }
   };
+  // lane -> (channel, tile half).  With 32 channels per wave (128-byte tile rows) channel = lane & 31: the 32 lanes of a
+  // ds_read_b32 group read 32 different banks (channel = lane >> 1 put the two halves of a channel on one bank: 36 % of
+  // this kernel's LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).
   auto convert = [&](int fs, int im) {
-    conv_item(smem + fs * FA + wave * 2048, 128, lane >> 1, lane & 1, smem + OFF_IA + im * IMGA, 32 * wave + (lane >> 1),
+    conv_item(smem + fs * FA + wave * 2048, 128, lane & 31, lane >> 5, smem + OFF_IA + im * IMGA, 32 * wave + (lane & 31),
               sp);
-    if (lane < 2 * RB)
-      conv_item(smem + OFF_FB + fs * FB + wave * QI * 1024, RB * 4, lane >> 1, lane & 1, smem + OFF_IB + im * IMGB,
-                RB * wave + (lane >> 1), sq);
+    if constexpr (RB == 32) {
+      conv_item(smem + OFF_FB + fs * FB + wave * QI * 1024, RB * 4, lane & 31, lane >> 5, smem + OFF_IB + im * IMGB,
+                RB * wave + (lane & 31), sq);
+    } else {
+      if (lane < 2 * RB)
+        conv_item(smem + OFF_FB + fs * FB + wave * QI * 1024, RB * 4, lane >> 1, lane & 1, smem + OFF_IB + im * IMGB,
+                  RB * wave + (lane >> 1), sq);
+    }
   };
 
   f32x16 acc[MT][NT], tot[FL > 0 ? MT : 1][FL > 0 ? NT : 1];
