@@ -84,6 +84,41 @@ __device__ __forceinline__ f32x4 ldm4(const TM* p) {
   }
 }
 
+// The same element through a buffer load: the 36 transform planes of M / dV are `plane` elements apart, so a thread needs
+// ONE 32-bit offset (tile, column) for all of them and the plane base is scalar (buffer resource built per plane by the
+// scalar unit) -- instead of a 64-bit address pair per load, which cost the output transforms ~70 VGPRs and two VALU
+// operations per load.  plane * sizeof(TM) < 4 GB (checked by the launchers).
+// cache policy of the M / dV plane reads: 2 = nt (streamed once, no reuse: the fused SPADE transform gains 7 %)
+#ifndef DSEE_M_AUX
+#define DSEE_M_AUX 2
+#endif
+// activation-sized results leave with non-temporal stores (each is consumed by another kernel after > L2 of other
+// traffic; the fused SPADE transform gains 3.5 %)
+#ifndef DSEE_NT_STORE
+#define DSEE_NT_STORE 1
+#endif
+#ifndef DSEE_NT_STORE2
+#define DSEE_NT_STORE2 1   // output 0.62 -> 0.58 ms, input 0.68 -> 0.64 ms at N = 8, 256^2, C = 512
+#endif
+__device__ __forceinline__ void st4(float* p, const f32x4& v) {
+  if constexpr (DSEE_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+__device__ __forceinline__ void st4b(float* p, const f32x4& v) {
+  if constexpr (DSEE_NT_STORE2) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <typename TM>
+__device__ __forceinline__ f32x4 ldm4b(const TM* M, int xi, size_t plane, unsigned voff) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M + (size_t)xi * plane), 0, 0xFFFFFFFE, 0x00020000);
+  if constexpr (sizeof(TM) == 4) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, DSEE_M_AUX));
+  } else {
+    const f16x4 h = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, DSEE_M_AUX));
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+}
+
 // one column / row of B^T d : 6 -> 6
 __device__ __forceinline__ void bt6(const f32x4 (&d)[6], f32x4 (&o)[6]) {
   o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
         if constexpr (OUT == OUT_SPLIT_T)
           emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(V), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
         else {
-          *reinterpret_cast<f32x4*>(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+          st4b(V + ((size_t)(k * 6 + j) * T + t) * C + q * 4, o[j]);
           vmax = fmaxf(vmax, dsee_absmax4(o[j]));
         }
       }
@@ -320,7 +355,7 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
         if constexpr (OUT == OUT_SPLIT_T)
           emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
         else {
-          *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4) = o[j];
+          st4b(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4, o[j]);
           vmax = fmaxf(vmax, dsee_absmax4(o[j]));
         }
       }
@@ -355,7 +390,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const TM* __restrict
     for (int j = 0; j < 6; ++j) {
       f32x4 col[6], o[4];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) col[k] = ldm4(M + ((size_t)(k * 6 + j) * T + t) * C + q * 4);
+      for (int k = 0; k < 6; ++k) col[k] = ldm4b(M, k * 6 + j, (size_t)T * C, (unsigned)((t * C + q * 4) * sizeof(TM)));
       at4(col, o);
 #pragma unroll
       for (int k = 0; k < 4; ++k) tmp[k][j] = o[k];
@@ -390,7 +425,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const TM* __restrict
         if constexpr (NOISE) {
           if (noise_w) v += nw * philox_normal4(seed, offset + (uint64_t)(px * C4 + q));
         }
-        *reinterpret_cast<f32x4*>(y + off) = v;
+        st4b(y + off, v);
       }
     }
   }
@@ -404,7 +439,7 @@ __device__ __forceinline__ void out_tile(const TM* __restrict__ M, long T, long 
   for (int j = 0; j < 6; ++j) {
     f32x4 c6[6], o[4];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c6[k] = ldm4(M + ((size_t)(k * 6 + j) * T + t) * ld + col);
+    for (int k = 0; k < 6; ++k) c6[k] = ldm4b(M, k * 6 + j, (size_t)T * ld, (unsigned)((t * ld + col) * sizeof(TM)));
     at4(c6, o);
 #pragma unroll
     for (int k = 0; k < 4; ++k) tmp[k][j] = o[k];
@@ -416,7 +451,7 @@ __device__ __forceinline__ void out_tile(const TM* __restrict__ M, long T, long 
 // Output transform of the gamma/beta GEMM fused with the SPADE/SEAN modulate + LeakyReLU (same arithmetic as the
 // EPI_MODULATE epilogue of conv_mfma.hip; packed column of channel c: (c/64)*128 + ((c%64)/32)*64 + c%32, beta +32)
 template <typename TM>
-__global__ __launch_bounds__(256) void wino43_output_modulate_kernel(
+__global__ __launch_bounds__(256, 2) void wino43_output_modulate_kernel(
     const TM* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ out,
     float* __restrict__ scale, int N, int H, int W, int C, int rows, float add_one, float slope,
@@ -435,21 +470,33 @@ __global__ __launch_bounds__(256) void wino43_output_modulate_kernel(
     const f32x4 bg = bias ? *reinterpret_cast<const f32x4*>(bias + pg) : z4;
     const f32x4 bb = bias ? *reinterpret_cast<const f32x4*>(bias + pg + 32) : z4;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
-    f32x4 yg[4][4], yb[4][4];
-    out_tile(M, T, t, rows, pg, yg);
-    out_tile(M, T, t, rows, pg + 32, yb);
+    // gamma first: scale = gamma + bias + add_one is stored and folded with x-hat into y = x-hat * scale, then beta.  One
+    // 4x4 tile of 16 float4 is live across the second transform instead of two (422 -> < 256 VGPRs: two waves per SIMD,
+    // so the load phase of one wave overlaps the store phase of the other).
+    f32x4 y[4][4];
+    out_tile(M, T, t, rows, pg, y);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const size_t off = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + c;
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + off) - mu) * is;
-        const f32x4 sc = yg[k][j] * ms + bg + add_one;
-        f32x4 v = xh * sc + (yb[k][j] * ms + bb);
+        const f32x4 sc = y[k][j] * ms + bg + add_one;
+        if (scale) st4(scale + off, sc);  // saved for the backward pass only
+        y[k][j] = xh * sc + bb;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 yb[4][4];
+    out_tile(M, T, t, rows, pg + 32, yb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t off = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + c;
+        f32x4 v = y[k][j] + yb[k][j] * ms;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-        if (scale) *reinterpret_cast<f32x4*>(scale + off) = sc;  // saved for the backward pass only
-        *reinterpret_cast<f32x4*>(out + off) = v;
+        st4(out + off, v);
       }
   }
 }
@@ -554,7 +601,7 @@ __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const TM* __r
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(dx + px * C + q * 4) = v;
+        st4b(dx + px * C + q * 4, v);
       }
     }
 }
