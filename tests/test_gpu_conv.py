@@ -314,6 +314,29 @@ def test_gemm_f16x2_is_fp32_accurate(groups, tg, n, k, tile, spread):
     assert float(slot.max()) == am_a
 
 
+def test_gemm_f16x2_tn_long_chain_accuracy():
+    """The 256x256 TN tile keeps ONE fp32 accumulator chain per split (no second level: 128 accumulator registers are
+    all a wave has): at the step's longest chain, 4096 tiles per split (512x512 layer at 256^2, bs = 8, split-K 8), on
+    zero-mean and on positive-mean operands (sums that grow), the result must stay below 1e-6 of float64 and below the
+    error of the library fp32 GEMM (torch / rocBLAS) on the same data."""
+    from deepsee_amd import lib as L
+    g = torch.Generator().manual_seed(3)
+    groups, t, rp, rq, splits = 2, 8192, 256, 256, 2
+    for off in (0.0, 0.5):
+        p = (torch.randn(groups * t, rp, generator=g) + off).cuda()
+        q = (torch.randn(groups * t, rq, generator=g) + off).cuda()
+        c = torch.empty(groups * splits, rp, rq, device="cuda")
+        L.call("gemm_f16x2_tn_f32", p, q, c, groups, t, rp, rq, rq, splits, _amax(float(p.abs().max())), _amax(float(q.abs().max())))
+        ts = t // splits
+        pz, qz = p.view(groups * splits, ts, rp), q.view(groups * splits, ts, rq)
+        ref = torch.einsum("ztp,ztq->zpq", pz.double(), qz.double())
+        f32 = torch.einsum("ztp,ztq->zpq", pz, qz)
+        e = ((c.double() - ref).norm() / ref.norm()).item()
+        e32 = ((f32.double() - ref).norm() / ref.norm()).item()
+        print("mean %.1f: fp16x2 TN 256x256 %.2e | library sgemm %.2e" % (off, e, e32))
+        assert e < 1e-6 and e <= e32, (e, e32)
+
+
 @pytest.mark.parametrize("groups,t,rp,rq,splits", [(2, 1024, 256, 128, 2), (3, 512, 256, 160, 1), (36, 256, 512, 512, 1)])
 def test_gemm_f16x2_tn_matches_float64(groups, t, rp, rq, splits):
     """Split-K "TN" weight-gradient form with both fp32 operands transposed, scaled and split inside the kernel
