@@ -1200,38 +1200,12 @@ class SeanNormTable(torch.autograd.Function):
         return dx, dw_sh, db_sh, dw2a, dtable, db2, None, None, None, None, None, None, None, None
 
 
-class _StyleGemm(torch.autograd.Function):
-    """t[nr][j] = sum_s style[nr][s] * wt[j][s]  (nr = N*19 style rows, j = 9*rows table columns) on the MFMA 1x1
-    conv kernel.  The gradient w.r.t. `style` contracts over j (K = 9216 with only N*19 = 152 output rows): run as
-    a 1x1 conv it is 2 tiles x 288 K-slabs on 2 CUs (0.7 ms), so it is computed with the split-K weight-gradient
-    kernel instead (j plays the pixel role): d_style^T[s][nr] = sum_j wt[j][s] * dt^T[j][nr]."""
-
-    @staticmethod
-    def forward(ctx, x, wt):
-        nr, sdim = x.shape
-        j = wt.shape[0]
-        geom = L.geom_fwd(1, nr, 1, sdim, L.pad4(j), 1, 1, 0)
-        t = conv_raw(x.reshape(1, nr, 1, sdim), _pack_fwd(wt.reshape(j, sdim, 1, 1), sdim, geom.korder), geom)
-        ctx.geom = geom
-        ctx.save_for_backward(x, wt)
-        return t.reshape(nr, -1)[:, :j]
-
-    @staticmethod
-    def backward(ctx, dt):
-        x, wt = ctx.saved_tensors
-        nr, sdim = x.shape
-        j = wt.shape[0]
-        dt = dt.contiguous()
-        dx = dw = None
-        if ctx.needs_input_grad[1]:
-            dw = wgrad_raw(x.reshape(1, nr, 1, sdim), dt.reshape(1, nr, 1, j), ctx.geom, j, sdim, 1, 1).reshape(j, sdim)
-        if ctx.needs_input_grad[0]:
-            nrp = L.pad4(nr)
-            dtt = torch.nn.functional.pad(dt.t(), (0, nrp - nr)).contiguous()            # [j][nr] (5 MB transpose)
-            g2 = L.geom_fwd(1, j, 1, nrp, sdim, 1, 1, 0)
-            dx = wgrad_raw(dtt.reshape(1, j, 1, nrp), wt.reshape(1, j, 1, sdim), g2, sdim, nr, 1, 1)
-            dx = dx.reshape(sdim, nr).t().contiguous()
-        return dx, dw
+def _style_gemm(x, wt):
+    """t[nr][j] = sum_s style[nr][s] * wt[j][s]  (nr = N*19 style rows, S = 128, j = 9*rows table columns): a plain
+    152 x 128 x 9216 GEMM on parameter-sized operands (<= 6 MB) -- rocBLAS through torch.matmul, forward and both
+    gradients (round 1 ran it on the 1x1-conv / split-K weight-gradient kernels: 1.9 ms per step at 3-11 TF/s, the
+    shapes fill 2 CUs)."""
+    return x @ wt.t()
 
 
 def style_table(style, ws2):
@@ -1242,7 +1216,7 @@ def style_table(style, ws2):
     rows = ws2.shape[0]
     assert s % 4 == 0 and (9 * rows) % 4 == 0
     wt = ws2.permute(2, 3, 0, 1).reshape(9 * rows, s)                   # [(tap,row)][s]
-    t = _StyleGemm.apply(style.reshape(n * nc, s).contiguous(), wt.contiguous())   # [N*19, 9*rows]
+    t = _style_gemm(style.reshape(n * nc, s), wt)                       # [N*19, 9*rows]
     t = t.reshape(n, nc, 9, rows).permute(0, 2, 3, 1)                   # [N,9,rows,19]
     return torch.nn.functional.pad(t, (0, 32 - nc)).contiguous()
 
