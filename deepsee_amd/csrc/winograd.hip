@@ -849,6 +849,7 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
   DSEE_CHECK_ARG(act != DSEE_ACT_MASK || residual);
   DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
   DSEE_CHECK_ARG(!res_noise_w || (residual && residual_ld == C && act != DSEE_ACT_MASK));
+  DSEE_CHECK_ARG((long)N * (H / 4) * (W / 4) * C * 4 < 0xFFFFFFF0L);   // one transform plane is addressed with 32-bit offsets
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
   const _Float16* Mb = reinterpret_cast<const _Float16*>(M);
   const bool nz = noise_w || res_noise_w;
@@ -883,6 +884,7 @@ int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const 
                                 int rows, float add_one, float slope, const float* mscale, hipStream_t st) {
   DSEE_CHECK_ARG(M && x && mean && invstd && out_h && C % 64 == 0 && rows == 2 * C);  // out_scale may be NULL
   DSEE_CHECK_ARG(H % 4 == 0 && W % 4 == 0);
+  DSEE_CHECK_ARG((long)N * (H / 4) * (W / 4) * rows * 4 < 0xFFFFFFF0L);   // 32-bit offsets within one transform plane
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
   if (mscale)
     wino43_output_modulate_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const _Float16*>(M), bias_packed, x, mean, invstd,

@@ -85,6 +85,7 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, float* amax, hipStream_t stream);
 /* noise_w != NULL: y += noise_w[c] * eps, eps = the Philox N(0,1) stream (noise_seed, noise_offset) of dsee_rng_fill in
  * NHWC element order -- the NoiseInjection that follows the conv (architecture.py:111-112) fused into its epilogue.
+ * One transform plane of M (N * H/4 * W/4 * C elements) must stay below 4 GB (32-bit plane offsets; DSEE_EINVAL otherwise).
  * res_noise_w != NULL: the residual is residual + res_noise_w[c] * eps' (stream res_noise_seed / _offset) -- the resblock
  * shortcut x_s = noise_skip(x) (architecture.py:133-134,127) regenerated from x instead of read from its own tensor. */
 int dsee_wino43_output(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
