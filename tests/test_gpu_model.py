@@ -166,7 +166,7 @@ def test_full_size_step_matches_oracle():
           % (dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
 
 
-def smooth_loss_errors(over, seed=555):
+def smooth_loss_errors(over, seed=555, plain_f32=True):
     """Backward parity with the sign-function losses taken out: L_G = <fake, R>, L_D = sum_k <D_k(cat[fake;real]), R_k>,
     L_V = sum_i <VGG_i(fake), R_i> with fixed random R.  Every HIP backward kernel of the path (SPADE/SEAN modulate,
     BN, convs dgrad/wgrad, SN, noise, upsample, IN, pools, style pool/gather, one-hot conv) is exercised.  Returns, per
@@ -210,8 +210,13 @@ def smooth_loss_errors(over, seed=555):
                  if p.grad is not None}
         return orc, ctl, fake.detach(), float(loss.detach()), grads, Rs
 
-    orc32, ctl, fake32, loss32, g32, Rs = oracle_run(torch.float32)
-    _, _, fake64, loss64, g64, _ = oracle_run(torch.float64, ctl.tape)
+    if plain_f32:
+        orc32, ctl, fake32, loss32, g32, Rs = oracle_run(torch.float32)
+        _, _, fake64, loss64, g64, _ = oracle_run(torch.float64, ctl.tape)
+    else:   # full-size cases: the unperturbed fp32 oracle is informational only -- one CPU pass less (the tape is the same)
+        _, ctl, fake64, loss64, g64, Rs = oracle_run(torch.float64)
+        Rs = {k: v.float() for k, v in Rs.items()}
+        g32 = None
     tm = TrainerManager(make_opt(**over))
     m = tm.sr_model
     m.load_states(states)
@@ -248,7 +253,8 @@ def smooth_loss_errors(over, seed=555):
         # alpha_gamma / alpha_beta (SEAN blend scalars) are differences of two ~1e6-term inner products in both
         # implementations (cancellation): judge them against 1 % of the largest gradient instead of their own size
         den = max(float(v.norm()), (1e-2 if v.numel() == 1 else 1e-3) * gmax)
-        rows.append((kk, float((hg[kk].double() - v).norm()) / den, float((g32[kk].double() - v).norm()) / den,
+        rows.append((kk, float((hg[kk].double() - v).norm()) / den,
+                     float((g32[kk].double() - v).norm()) / den if g32 is not None else float("nan"),
                      float((g32p[kk].double() - v).norm()) / den))
     return rows, dev, pert
 
@@ -294,7 +300,7 @@ def test_full_size_smooth_loss_backward(name, over):
         (floor 3e-3), and HIP's median over all tensors <= 1.5x the perturbed oracle's median.
     The kink-free check of the same kernels at the same shapes to 1e-3 is tests/test_gpu_ops.py::
     test_benchmark_shape_conv_vs_float64 / test_benchmark_shape_norm_vs_float64."""
-    rows, dev, pert = smooth_loss_errors(over, seed=777)
+    rows, dev, pert = smooth_loss_errors(over, seed=777, plain_f32=False)
     med, q90, ehs, ecs, eps_ = _summ(rows)
     well = [r for r in rows if r[3] <= 3e-4]
     ill = [r for r in rows if r[3] > 3e-4]
