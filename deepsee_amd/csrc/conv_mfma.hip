@@ -895,46 +895,58 @@ __global__ void wino43_wgrad_finalize_kernel(const float* __restrict__ slab, flo
 __global__ void wino43_wgrad_table_finalize_kernel(const float* __restrict__ slab, float* __restrict__ dw2a,
                                                    float* __restrict__ dtable, int N, int sper, int rows, int Kpad,
                                                    int ca, int L) {
-  const long total = (long)rows * (ca + 32);
+  // work items: first rows * ca shared elements (sum over the N images), then N * rows * 32 per-image table elements --
+  // separate index ranges, so that a wave runs one of the two paths (a thread per (row, column) doing both made every
+  // wave walk the table path N times with 4/5 of its lanes idle: 141 us per call at any size)
+  const long n_shared = dw2a ? (long)rows * ca : 0, total = n_shared + (long)N * rows * 32;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(i / (ca + 32)), k = (int)(i % (ca + 32));
-    const bool shared = k < ca;
+    const bool shared = i < n_shared;
+    int row, k, n0, n1;
+    if (shared) {
+      row = (int)(i / ca);
+      k = (int)(i % ca);
+      n0 = 0;
+      n1 = N;
+    } else {
+      const long e = i - n_shared;
+      k = ca + (int)(e % 32);
+      row = (int)((e / 32) % rows);
+      n0 = (int)(e / (32L * rows));
+      n1 = n0 + 1;
+    }
     float acc[36];
 #pragma unroll
     for (int xi = 0; xi < 36; ++xi) acc[xi] = 0.f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = n0; n < n1; ++n)
 #pragma unroll
       for (int xi = 0; xi < 36; ++xi) {
         float v = 0.f;
         for (int j = 0; j < sper; ++j) v += slab[((size_t)((xi * N + n) * sper + j) * rows + row) * Kpad + k];
-        acc[xi] = shared ? acc[xi] + v : v;
+        acc[xi] += v;
       }
-      if (shared && n + 1 < N) continue;
-      float t[3][6], dg[9];
+    float t[3][6], dg[9];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        const float u0 = acc[b], u1 = acc[6 + b], u2 = acc[12 + b], u3 = acc[18 + b], u4 = acc[24 + b], u5 = acc[30 + b];
-        const float s12 = u1 + u2, d12 = u1 - u2, s34 = u3 + u4, d34 = u3 - u4;
-        t[0][b] = 0.25f * u0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-        t[1][b] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-        t[2][b] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + u5;
-      }
+    for (int b = 0; b < 6; ++b) {
+      const float u0 = acc[b], u1 = acc[6 + b], u2 = acc[12 + b], u3 = acc[18 + b], u4 = acc[24 + b], u5 = acc[30 + b];
+      const float s12 = u1 + u2, d12 = u1 - u2, s34 = u3 + u4, d34 = u3 - u4;
+      t[0][b] = 0.25f * u0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+      t[1][b] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+      t[2][b] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + u5;
+    }
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float s12 = t[a][1] + t[a][2], d12 = t[a][1] - t[a][2], s34 = t[a][3] + t[a][4], d34 = t[a][3] - t[a][4];
-        dg[a * 3 + 0] = 0.25f * t[a][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-        dg[a * 3 + 1] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-        dg[a * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[a][5];
-      }
-      if (shared) {
-        if (dw2a)
+    for (int a = 0; a < 3; ++a) {
+      const float s12 = t[a][1] + t[a][2], d12 = t[a][1] - t[a][2], s34 = t[a][3] + t[a][4], d34 = t[a][3] - t[a][4];
+      dg[a * 3 + 0] = 0.25f * t[a][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+      dg[a * 3 + 1] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+      dg[a * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[a][5];
+    }
+    if (shared) {
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap) dw2a[((size_t)row * ca + k) * 9 + tap] = dg[tap];
-      } else {
-        const int r = k - ca;
+      for (int tap = 0; tap < 9; ++tap) dw2a[((size_t)row * ca + k) * 9 + tap] = dg[tap];
+    } else {
+      const int r = k - ca;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) dtable[(((size_t)n * 9 + tap) * rows + row) * 32 + r] = r < L ? dg[tap] : 0.f;
-      }
+      for (int tap = 0; tap < 9; ++tap) dtable[(((size_t)n0 * 9 + tap) * rows + row) * 32 + r] = r < L ? dg[tap] : 0.f;
     }
   }
 }
@@ -1317,7 +1329,7 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
              : split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st)
                           : dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);
     if (rc) return rc;
-    const long total = (long)rows * ld;
+    const long total = (long)rows * ca + (long)N * rows * 32;
     wino43_wgrad_table_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
         workspace, ca > 0 ? dw2a : nullptr, dtable, N, sper, rows, Kpad, ca, L);
     DSEE_LAUNCH_CHECK();
@@ -1334,7 +1346,7 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
   a.msplit = (int)(T / N / sper);
   int rc = wgrad_launch(a, 36 * N * sper, st);
   if (rc) return rc;
-  const long total = (long)rows * ld;
+  const long total = (long)rows * ca + (long)N * rows * 32;
   wino43_wgrad_table_finalize_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(
       workspace, ca > 0 ? dw2a : nullptr, dtable, N, sper, rows, a.Kpad, ca, L);
   DSEE_LAUNCH_CHECK();
