@@ -48,6 +48,10 @@ struct ConvArgs {
   int act;
   float slope;
   int M;
+  // fp16x2 operand mode (conv_igemm_kernel<..., F16 = true>): device maxima of the input tensor and of the packed
+  // weights in the 64-line layout of dsee_common.h; NULL = exact fp32 MFMA
+  const float* amax_a;
+  const float* amax_w;
 };
 
 constexpr int BK = 32;
@@ -114,7 +118,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 //          odd channel counts) with a division per slab.  Both are branch-free inside the K loop so that the address
 //          arithmetic and the global loads of slab kt+1 interleave with the MFMAs of slab kt (the matrix pipe takes a
 //          new MFMA only every 64 cycles per wave; everything else issues in its shadow).
-template <int MT, int NT, int WM, int WN, int EPI, int GEO>
+// F16: the two operands are scaled by powers of two from their device-side maxima and split into two fp16 terms when a
+//      slab is stored to LDS (row = [32 k of term 0][32 k of term 1][16 B pad], the same 144 bytes as an fp32 row);
+//      6 v_mfma_f32_32x32x16_f16 (48 passes) replace the 16 v_mfma_f32_32x32x2_f32 (256 passes) of a 32-k slab per
+//      accumulator tile -- the same arithmetic as the Winograd-domain GEMMs (gemm_bf16x3.hip), as accurate as an sgemm.
+template <int MT, int NT, int WM, int WN, int EPI, int GEO, bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
   constexpr int NTHR = WM * WN * 64, RPP = NTHR / 8;  // threads, LDS rows filled per pass
@@ -264,6 +272,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(ConvArgs a)
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
   };
+  float sc_a = 1.f, sc_w = 1.f;
+  if constexpr (F16) {
+    sc_a = dsee_pow2_scale(dsee_amax_read(a.amax_a));
+    sc_w = dsee_pow2_scale(dsee_amax_read(a.amax_w));
+  }
+  // 4 consecutive k of one row -> 4 halfs of each term, at byte 8 * chunk of the row's term-0 / term-1 half
+  auto store_split = [&](float* row, const f32x4& v, float sc) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h0, h1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e] * sc;
+      h0[e] = (_Float16)x;
+      h1[e] = (_Float16)(x - (float)h0[e]);
+    }
+    unsigned char* p = reinterpret_cast<unsigned char*>(row) + chunk * 8;
+    *reinterpret_cast<h4*>(p) = h0;
+    *reinterpret_cast<h4*>(p + 64) = h1;
+  };
   auto store_tile = [&](int buf) {
     float* Ab = As + buf * BM * LDK;
     float* Bb = Bs + buf * BN * LDK;
@@ -272,10 +299,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(ConvArgs a)
       // GEO 1: the buffer range check already returned zeros.  GEO 0: select (not multiply: a masked row may have
       // read Inf/NaN from an unrelated element)
       const f32x4 v = (GEO == 1 || ra_keep[j] != 0.f) ? ra[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(Ab + (lrow + RPP * j) * LDK + chunk * 4) = v;
+      if constexpr (F16) store_split(Ab + (lrow + RPP * j) * LDK, v, sc_a);
+      else *reinterpret_cast<f32x4*>(Ab + (lrow + RPP * j) * LDK + chunk * 4) = v;
     }
 #pragma unroll
-    for (int j = 0; j < B_CH; ++j) *reinterpret_cast<f32x4*>(Bb + (lrow + RPP * j) * LDK + chunk * 4) = rb[j];
+    for (int j = 0; j < B_CH; ++j) {
+      if constexpr (F16) store_split(Bb + (lrow + RPP * j) * LDK, rb[j], sc_w);
+      else *reinterpret_cast<f32x4*>(Bb + (lrow + RPP * j) * LDK + chunk * 4) = rb[j];
+    }
   };
 
   // Two-level accumulation: the MFMA chain runs over at most FLUSH*32 k's into `part`, which is then folded
@@ -289,6 +320,70 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(ConvArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
 
+  if constexpr (F16) {
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    load_tile(min(1, nk - 1));   // staging registers hold slab 1
+    // fragment of k-step s (16 k), term p of the 32-row tile at `row0`: 16 bytes at p * 64 + s * 32 + (lane >> 5) * 16
+    const int fo = (lane & 31) * LDK * 4 + (lane >> 5) * 16;
+    auto frag = [&](const float* base, int row0, int s16, int p) {
+      return *reinterpret_cast<const u32x4v*>(reinterpret_cast<const unsigned char*>(base + row0 * LDK) + fo + p * 64 +
+                                              s16 * 32);
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+      const float* Ac = As + cur * BM * LDK;
+      const float* Bc = Bs + cur * BN * LDK;
+#pragma unroll
+      for (int s16 = 0; s16 < 2; ++s16) {
+        u32x4v af[MT][2], bf[NT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) af[i][p] = frag(Ac, wm * MT * 32 + i * 32, s16, p);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) bf[j][p] = frag(Bc, wn * NT * 32 + j * 32, s16, p);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)   // a1*b0, a0*b1, a0*b0 (smallest first)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                  __builtin_bit_cast(f16x8v, af[i][q == 0 ? 1 : 0]), __builtin_bit_cast(f16x8v, bf[j][q == 1 ? 1 : 0]),
+                  part[i][j], 0, 0, 0);
+        if (s16 == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          store_tile(cur ^ 1);   // slab kt+1 (loaded a whole slab ago) into the buffer every wave left before the last barrier
+        }
+      }
+      __syncthreads();
+      load_tile(min(kt + 2, nk - 1));
+      if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] += part[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+          }
+      }
+      cur ^= 1;
+    }
+    const float oscale = 1.f / (sc_a * sc_w);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= oscale;
+  } else {
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -345,6 +440,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(ConvArgs a)
         }
     }
     cur ^= 1;
+  }
+
   }
 
   // ---- epilogue.  C/D map of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -551,15 +648,24 @@ struct WgradArgs {
   int korder, Kuse;  // slab column order; number of slab columns actually computed (<= Ktot)
   int Kstart;        // first slab column computed (multiple of 128)
   int margin;  // WGEO 1: bytes the `in` buffer base is moved down (most negative tap shift)
+  // fp16x2 operand mode (F16 = true): device maxima of dout and in (64-line layout of dsee_common.h), NULL = fp32 MFMA
+  const float* amax_dout;
+  const float* amax_in;
 };
 
-constexpr int WLD = 132;  // padded LDS row for the 32 x 128 wgrad tiles
+constexpr int WLD = 132;
+constexpr int WROWB = 576;  // F16: bytes of one pixel row of a 32 x 128 tile: 128 halfs of term 0 | 128 of term 1 | 64 B pad  // padded LDS row for the 32 x 128 wgrad tiles
 
 // WGEO = 1: stride-1 "same" convolution (mul 1, dshift 0, ups 0, Hi == Ho, Wi == Wo): the source pixel of output
 //           pixel m under tap (kh,kw) is m + const, so both operands are read with buffer loads whose per-thread
 //           VGPR offset is fixed for the whole kernel and whose per-slab offset is ONE scalar; out-of-image taps
 //           get the out-of-range offset and come back as zeros.  WGEO = 0: general geometry (two divisions per row).
-template <int WGEO>
+// F16: both operands are scaled (powers of two from their device maxima) and split into two fp16 terms when a slab is
+//      stored to LDS, in the natural [pixel][column] order; the MFMA fragments -- 8 consecutive PIXELS of one column per
+//      lane -- come out of ds_read_b64_tr_b16 (LDS transpose read: within a 16-lane group, lanes 4e..4e+3 address row e,
+//      lane i receives column i of the 4 x 16 block), two reads per 8 pixels.  6 v_mfma_f32_32x32x16_f16 per 32-pixel
+//      slab and accumulator tile instead of 16 v_mfma_f32_32x32x2_f32.
+template <int WGEO, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   // D[i = cout][j = k'] = sum over pixels.  A'[px][co] = dout tile, B'[px][k'] = shifted input tile.
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -676,14 +782,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   };
+  float sc_a = 1.f, sc_b = 1.f;
+  if constexpr (F16) {
+    sc_a = dsee_pow2_scale(dsee_amax_read(a.amax_dout));
+    sc_b = dsee_pow2_scale(dsee_amax_read(a.amax_in));
+  }
+  unsigned char* A16 = reinterpret_cast<unsigned char*>(smem);   // F16: [2][32][WROWB] per operand
+  unsigned char* B16 = A16 + 2 * 32 * WROWB;
+  auto store_split = [&](unsigned char* row, const f32x4& v, float sc) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h0, h1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e] * sc;
+      h0[e] = (_Float16)x;
+      h1[e] = (_Float16)(x - (float)h0[e]);
+    }
+    *reinterpret_cast<h4*>(row + chunk * 8) = h0;
+    *reinterpret_cast<h4*>(row + 256 + chunk * 8) = h1;
+  };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(As + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) =
-          (WGEO == 1 || keep_a[j] != 0.f) ? ra[j] : z4;
-      *reinterpret_cast<f32x4*>(Bs + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) =
-          (WGEO == 1 || keep_b[j] != 0.f) ? rb[j] : z4;
+      const f32x4 va_ = (WGEO == 1 || keep_a[j] != 0.f) ? ra[j] : z4, vb_ = (WGEO == 1 || keep_b[j] != 0.f) ? rb[j] : z4;
+      if constexpr (F16) {
+        store_split(A16 + (buf * 32 + lrow + 8 * j) * WROWB, va_, sc_a);
+        store_split(B16 + (buf * 32 + lrow + 8 * j) * WROWB, vb_, sc_b);
+      } else {
+        *reinterpret_cast<f32x4*>(As + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) = va_;
+        *reinterpret_cast<f32x4*>(Bs + (buf * 32 + lrow + 8 * j) * WLD + chunk * 4) = vb_;
+      }
     }
   };
 
@@ -696,6 +825,73 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
 
   const int nk = (m1 - m0 + 31) / 32;
+  if constexpr (F16) {
+    typedef short v4i16 __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    // this lane's part of a transpose read: row (pixel) (lane & 15) >> 2 of the 4-row block, columns 16 * ((lane >> 4) & 1)
+    // + 4 * (lane & 3) .. + 3 of the 32-column tile; pixel block 8 * (lane >> 5) (+ 4 for the second read) of a 16-pixel step
+    const int t_row = 8 * (lane >> 5) + ((lane & 15) >> 2), t_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto frag = [&](const unsigned char* base, int buf, int s16, int col0, int term) {
+      const unsigned char* p = base + (buf * 32 + 16 * s16 + t_row) * WROWB + term * 256 + (col0 + t_col) * 2;
+      const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(p));
+      const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(p + 4 * WROWB));
+      typedef short v8i16 __attribute__((ext_vector_type(8)));
+      const v8i16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(f16x8v, v);
+    };
+    if (nk > 0) {
+      load_tile(0, true);
+      store_tile(0);
+    }
+    __syncthreads();
+    if (nk > 0) load_tile(min(1, nk - 1), nk > 1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+      for (int s16 = 0; s16 < 2; ++s16) {
+        f16x8v fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            fa[i][p] = frag(A16, cur, s16, wm * 64 + i * 32, p);
+            fb[i][p] = frag(B16, cur, s16, wn * 64 + i * 32, p);
+          }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][q == 0 ? 1 : 0], fb[j][q == 1 ? 1 : 0], part[i][j],
+                                                                  0, 0, 0);
+        if (s16 == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          store_tile(cur ^ 1);
+        }
+      }
+      __syncthreads();
+      load_tile(min(kt + 2, nk - 1), kt + 2 < nk);
+      if ((kt & (FLUSH - 1)) == FLUSH - 1 || kt + 1 == nk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] += part[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+          }
+      }
+      cur ^= 1;
+    }
+    const float oscale = 1.f / (sc_a * sc_b);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= oscale;
+  } else {
   const int fcol = lane & 31, fk = lane >> 5;
   // fragments double-buffered in registers: 4 k-steps (16 MFMAs) per group, the next group's 16 ds_read_b32 are in
   // flight while the current group's MFMAs issue, and the last group of a slab runs across the barrier (as in the
@@ -756,6 +952,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
     cur ^= 1;
+  }
   }
   float* slab = a.slab + (size_t)z * a.rows * a.Kpad;
 #pragma unroll
@@ -951,20 +1148,28 @@ __global__ void wino43_wgrad_table_finalize_kernel(const float* __restrict__ sla
   }
 }
 
-template <int MT, int NT, int WM, int WN, int EPI, int GEO>
-int launch_conv_geo(const ConvArgs& a, hipStream_t st) {
+template <int MT, int NT, int WM, int WN, int EPI, int GEO, bool F16>
+int launch_conv_geo_t(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = MT * WM * 32, BN = NT * WN * 32;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MT, NT, WM, WN, EPI, GEO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MT, NT, WM, WN, EPI, GEO, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid(dsee_cdiv(a.M, BM), EPI == EPI_MODULATE ? dsee_cdiv(a.C, BN / 2) : dsee_cdiv(a.Cout, BN));
-  conv_igemm_kernel<MT, NT, WM, WN, EPI, GEO><<<grid, WM * WN * 64, lds, st>>>(a);
+  conv_igemm_kernel<MT, NT, WM, WN, EPI, GEO, F16><<<grid, WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
+}
+
+template <int MT, int NT, int WM, int WN, int EPI, int GEO>
+int launch_conv_geo(const ConvArgs& a, hipStream_t st) {
+  if constexpr (EPI == EPI_PLAIN) {
+    if (a.amax_a && a.amax_w) return launch_conv_geo_t<MT, NT, WM, WN, EPI, GEO, true>(a, st);
+  }
+  return launch_conv_geo_t<MT, NT, WM, WN, EPI, GEO, false>(a, st);
 }
 
 template <int EPI, int WM>
@@ -990,7 +1195,7 @@ static bool halo_ok(const ConvArgs& a) {
 
 template <int MT, int NT, int WM, int WN, int EPI>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-  if (MT == 2 && NT == 2 && WM == 2 && WN == 2 && halo_ok(a)) return launch_conv_halo<EPI, 2>(a, st);
+  if (MT == 2 && NT == 2 && WM == 2 && WN == 2 && halo_ok(a) && !a.amax_a) return launch_conv_halo<EPI, 2>(a, st);
   ConvArgs b = a;
   bool fast = a.korder == 1;
   if (fast) {
@@ -1072,6 +1277,25 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
   return launch_conv<1, 1, 4, 1, EPI_PLAIN>(a, st);
 }
 
+/* dsee_conv2d_fwd with both operands split into two scaled fp16 terms inside the kernel (3 fp16 MFMA products per
+ * multiply-add instead of the fp32 MFMA; as accurate as an sgemm).  amax_in / amax_w: device maxima |in|, |w_packed| in
+ * the 64-line layout dsee_absmax writes. */
+int dsee_conv2d_fwd_f16x2(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
+                          const float* residual, int residual_ld, float* out, int act, float slope,
+                          const float* amax_in, const float* amax_w, hipStream_t st) {
+  ConvArgs a = {};
+  int rc = fill_geom(a, g);
+  if (rc) return rc;
+  DSEE_CHECK_ARG(in && w_packed && out && amax_in && amax_w);
+  DSEE_CHECK_ARG(act != DSEE_ACT_MASK || residual != nullptr);
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out; a.act = act; a.slope = slope;
+  a.res_ld = residual_ld > 0 ? residual_ld : a.Cout;
+  a.amax_a = amax_in; a.amax_w = amax_w;
+  if (a.Cout > 64) return launch_conv<2, 2, 2, 2, EPI_PLAIN>(a, st);
+  if (a.Cout > 32) return launch_conv<2, 2, 4, 1, EPI_PLAIN>(a, st);
+  return launch_conv<1, 1, 4, 1, EPI_PLAIN>(a, st);
+}
+
 /* Grouped GEMM on the implicit-GEMM kernel: a 1x1 "convolution" whose image n multiplies the weight matrix
  * w_packed + n * group_stride (floats).  Used for the 36 Winograd-domain GEMMs (image = transform position). */
 int dsee_conv2d_fwd_grouped(const dsee_conv_geom* g, const float* in, const float* w_packed, long group_stride,
@@ -1134,13 +1358,18 @@ size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g) {
 
 static int wgrad_launch(WgradArgs& a, int S, hipStream_t st) {
   const int tx = dsee_cdiv(a.Kuse - a.Kstart, 128), ty = dsee_cdiv(a.rows, 128);
-  const size_t lds = (size_t)4 * 32 * WLD * sizeof(float);
+  const bool f16 = a.amax_dout && a.amax_in;
+  const size_t lds = f16 ? (size_t)4 * 32 * WROWB : (size_t)4 * 32 * WLD * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32 * WLD * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * 32 * WLD * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * WROWB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * WROWB);
     attr_done = true;
   }
   // fast path: stride-1 "same" conv, rows at least 32 wide, everything addressable with 32-bit byte offsets
@@ -1154,10 +1383,16 @@ static int wgrad_launch(WgradArgs& a, int S, hipStream_t st) {
   a.margin = (int)(-mn);
   const bool fast = a.mul == 1 && a.dshift == 0 && a.ups == 0 && a.Hi == a.Ho && a.Wi == a.Wo && a.Wo >= 32 &&
                     in_bytes + a.margin + 65536 < 0xFFFFFFFEL && out_bytes + 65536 < 0xFFFFFFFEL && -mn < (1L << 30);
-  if (fast)
+  if (f16) {
+    if (fast)
+      conv_wgrad_kernel<1, true><<<dim3(tx, ty, S), 256, lds, st>>>(a);
+    else
+      conv_wgrad_kernel<0, true><<<dim3(tx, ty, S), 256, lds, st>>>(a);
+  } else if (fast) {
     conv_wgrad_kernel<1><<<dim3(tx, ty, S), 256, lds, st>>>(a);
-  else
+  } else {
     conv_wgrad_kernel<0><<<dim3(tx, ty, S), 256, lds, st>>>(a);
+  }
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1170,9 +1405,9 @@ static void wgrad_fill(WgradArgs& a, const ConvArgs& c, const float* in, const f
   a.M = c.M; a.rows = c.Cout;
 }
 
-int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
-                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
-                      hipStream_t st) {
+static int conv2d_wgrad_impl(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
+                             size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
+                             const float* amax_in, const float* amax_dout, hipStream_t st) {
   ConvArgs c = {};
   int rc = fill_geom(c, g);
   if (rc) return rc;
@@ -1182,6 +1417,7 @@ int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dou
   DSEE_CHECK_ARG(workspace_bytes >= dsee_conv2d_wgrad_workspace(g));
   WgradArgs a = {};
   wgrad_fill(a, c, in, dout, workspace);
+  a.amax_in = amax_in; a.amax_dout = amax_dout;
   a.korder = (g->korder == 1 && c.Cin % 32 == 0) ? 1 : 0;
   // chunk-major slabs: only the channel chunks [Cin_first/32, ceil((Cin_first+Cin_real)/32)) are computed
   a.Kuse = a.korder == 1 ? (Cin_first + Cin_real + 31) / 32 * 32 * a.KH * a.KW : a.Ktot;
@@ -1196,6 +1432,23 @@ int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dou
       workspace, dw_oihw, S, a.rows, a.Kpad, Cout_real, Cin_real, a.KH, a.KW, a.Cin, a.korder, Cin_first);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
+}
+
+int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
+                      size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
+                      hipStream_t st) {
+  return conv2d_wgrad_impl(g, in, dout, workspace, workspace_bytes, dw_oihw, Cout_real, Cin_first, Cin_real, nullptr,
+                           nullptr, st);
+}
+
+/* dsee_conv2d_wgrad with both operands split into two scaled fp16 terms inside the kernel (see dsee_conv2d_fwd_f16x2);
+ * amax_in / amax_dout: device maxima |in|, |dout| in the 64-line layout dsee_absmax writes. */
+int dsee_conv2d_wgrad_f16x2(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
+                            size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
+                            const float* amax_in, const float* amax_dout, hipStream_t st) {
+  DSEE_CHECK_ARG(amax_in && amax_dout);
+  return conv2d_wgrad_impl(g, in, dout, workspace, workspace_bytes, dw_oihw, Cout_real, Cin_first, Cin_real, amax_in,
+                           amax_dout, st);
 }
 
 // image-aligned split count for the table variant: S = N * sper, each split = P / sper pixels of one image

@@ -209,8 +209,21 @@ def _pack_dgrad(w, cout_s, korder):
     return wp
 
 
+# Direct (non-Winograd) convolutions with >= CONV_F16X2_MIN_FLOP of work run their MFMAs on fp16x2-split operands (the
+# split happens inside the kernel; two small max|.| passes over the input and the packed weights provide the scales).
+# Below the threshold the two extra launches cost more than the shorter MFMA chain saves.  0 disables.
+CONV_F16X2_MIN_FLOP = float(os.environ.get("DSEE_CONV_F16X2_MIN_FLOP", "4e9"))
+
+
 def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
+    if GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and _flops(geom) >= CONV_F16X2_MIN_FLOP:
+        ax, aw = amax_slot(), amax_slot()
+        L.call("absmax", x, x.numel(), ax)
+        L.call("absmax", wp, wp.numel(), aw)
+        with _timed(_variant(geom) + "_f16x2", _flops(geom)):
+            L.call("conv2d_fwd_f16x2", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw)
+        return out
     with _timed(_variant(geom), _flops(geom)):
         L.call("conv2d_fwd", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope))
     return out
@@ -221,6 +234,13 @@ def wgrad_raw(x, dout, geom, cout, cin, kh, kw, cin_first=0):
     ws = scratch(nbytes, "wgrad")
     dw = new(cout, cin, kh, kw)
     flops = _flops(geom) * ((cin + 31) // 32 * 32 if geom.korder else geom.Cin) / geom.Cin
+    if GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and flops >= CONV_F16X2_MIN_FLOP:
+        ax, ad = amax_slot(), amax_slot()
+        L.call("absmax", x, x.numel(), ax)
+        L.call("absmax", dout, dout.numel(), ad)
+        with _timed("conv_wgrad_128x128_f16x2(+slab reduce)", flops):
+            L.call("conv2d_wgrad_f16x2", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin_first, cin, ax, ad)
+        return dw
     with _timed("conv_wgrad_128x128(+slab reduce)", flops):
         L.call("conv2d_wgrad", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin_first, cin)
     return dw

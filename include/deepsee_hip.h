@@ -76,6 +76,12 @@ int dsee_pack_weight_dgrad(const float* w_oihw, const float* scale_num, const fl
  * With the dgrad geometry + dsee_pack_weight_dgrad it is the data gradient of the same convs. */
 int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                     const float* residual, int residual_ld, float* out, int act, float slope, hipStream_t stream);
+/* The same convolution with both operands scaled by powers of two (device maxima amax_in = max |in|, amax_w =
+ * max |w_packed|, 2048-float arrays as written by dsee_absmax) and split into two fp16 terms inside the kernel:
+ * 3 fp16 MFMA products per multiply-add instead of the fp32 MFMA, error vs float64 equal to an sgemm's. */
+int dsee_conv2d_fwd_f16x2(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
+                          const float* residual, int residual_ld, float* out, int act, float slope,
+                          const float* amax_in, const float* amax_w, hipStream_t stream);
 
 /* Winograd F(4x4,3x3) path for 3x3 / stride 1 / pad 1 convolutions (same call sites as dsee_conv2d_fwd):
  *   V = dsee_wino43_input(x)                                [36][T][Cin],  T = N*(H/4)*(W/4)
@@ -214,6 +220,11 @@ size_t dsee_conv2d_wgrad_workspace(const dsee_conv_geom* g);
 int dsee_conv2d_wgrad(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
                       size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
                       hipStream_t stream);
+/* The same with both operands (in, dout) scaled by powers of two from their device maxima and split into two fp16 terms
+ * inside the kernel (LDS transpose reads deliver the pixel-major fragments): 3 fp16 MFMA products per multiply-add. */
+int dsee_conv2d_wgrad_f16x2(const dsee_conv_geom* g, const float* in, const float* dout, float* workspace,
+                            size_t workspace_bytes, float* dw_oihw, int Cout_real, int Cin_first, int Cin_real,
+                            const float* amax_in, const float* amax_dout, hipStream_t stream);
 
 /* wgrad of the SEAN modulate GEMM with a per-image style table (see dsee_conv2d_modulate_fwd): one split-K launch with
  * image-aligned splits; shared columns -> dw_oihw [rows][Cin_shared][KH][KW] (may be NULL), one-hot columns per image ->

@@ -45,10 +45,22 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("f16x2", [False, True], ids=["f32mfma", "f16x2"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_fwd_dgrad_wgrad(case):
+def test_conv_fwd_dgrad_wgrad(case, f16x2):
+    """Every geometry of the path through dsee_conv2d_fwd (forward and data gradient) and dsee_conv2d_wgrad against
+    F.conv2d autograd; f16x2: the same through dsee_conv2d_fwd_f16x2 (operands split into two scaled fp16 terms inside
+    the kernel, maxima from dsee_absmax) -- same 2e-5 bound."""
     from deepsee_amd import lib as L
     n, cin, cout, h, k, stride, pad, ups, act, use_bias, use_res = case
+
+    def fwd(geom_, x_, w_, b_, r_, out_, act_, slope_):
+        if not f16x2:
+            return L.call("conv2d_fwd", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_)
+        ax, aw = torch.zeros(2048, device="cuda"), torch.zeros(2048, device="cuda")
+        L.call("absmax", x_, x_.numel(), ax)
+        L.call("absmax", w_, w_.numel(), aw)
+        return L.call("conv2d_fwd_f16x2", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_, ax, aw)
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(n, cin, h, h, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
@@ -78,7 +90,7 @@ def test_conv_fwd_dgrad_wgrad(case):
         b_d[:cout] = b.to(dev)
     r_d = nhwc(res).to(dev) if use_res else None
     out = torch.empty(n, geom.Ho, geom.Wo, cout_s, device=dev)
-    L.call("conv2d_fwd", C.byref(geom), x_d, wp, b_d, r_d, 0, out, act, 0.2)
+    fwd(geom, x_d, wp, b_d, r_d, out, act, 0.2)
     torch.cuda.synchronize()
     assert geom.Ho == y.shape[2]
     assert rel(nchw(out.cpu(), cout), y.detach()) < 2e-5
@@ -91,7 +103,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     L.call("pack_weight_dgrad", w_d, None, None, wd, cout, cin, k, k, cout_s, gd.korder)
     gy_d = nhwc(gy).to(dev)
     dx = torch.empty(n, gd.Ho, gd.Wo, cin_s, device=dev)
-    L.call("conv2d_fwd", C.byref(gd), gy_d, wd, None, None, 0, dx, 0, 0.0)
+    fwd(gd, gy_d, wd, None, None, dx, 0, 0.0)
     torch.cuda.synchronize()
     dx_ref = xr.grad
     dx_c = nchw(dx.cpu(), cin)
@@ -103,7 +115,13 @@ def test_conv_fwd_dgrad_wgrad(case):
     ws_bytes = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
     ws = torch.empty(ws_bytes // 4, device=dev)
     dw = torch.empty(cout, cin, k, k, device=dev)
-    L.call("conv2d_wgrad", C.byref(geom), x_d, gy_d, ws, C.c_size_t(ws_bytes), dw, cout, 0, cin)
+    if f16x2:
+        ax, ad = torch.zeros(2048, device=dev), torch.zeros(2048, device=dev)
+        L.call("absmax", x_d, x_d.numel(), ax)
+        L.call("absmax", gy_d, gy_d.numel(), ad)
+        L.call("conv2d_wgrad_f16x2", C.byref(geom), x_d, gy_d, ws, C.c_size_t(ws_bytes), dw, cout, 0, cin, ax, ad)
+    else:
+        L.call("conv2d_wgrad", C.byref(geom), x_d, gy_d, ws, C.c_size_t(ws_bytes), dw, cout, 0, cin)
     torch.cuda.synchronize()
     assert rel(dw.cpu(), wr.grad) < 2e-5
 
