@@ -215,12 +215,23 @@ def _pack_dgrad(w, cout_s, korder):
 CONV_F16X2_MIN_FLOP = float(os.environ.get("DSEE_CONV_F16X2_MIN_FLOP", "4e9"))
 
 
-def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0):
+def tensor_amax(t, cache=None):
+    """Device-side max |t| (2048-float slot).  `cache`: a dict shared by the consumers of the same tensors (the data and
+    the weight gradient both read dy, the forward conv and the weight gradient both read x): one pass per tensor."""
+    key = (t.data_ptr(), t.numel())
+    if cache is not None and key in cache:
+        return cache[key]
+    a = amax_slot()
+    L.call("absmax", t, t.numel(), a)
+    if cache is not None:
+        cache[key] = a
+    return a
+
+
+def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0, amax_cache=None):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
     if GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and _flops(geom) >= CONV_F16X2_MIN_FLOP:
-        ax, aw = amax_slot(), amax_slot()
-        L.call("absmax", x, x.numel(), ax)
-        L.call("absmax", wp, wp.numel(), aw)
+        ax, aw = tensor_amax(x, amax_cache), tensor_amax(wp)
         with _timed(_variant(geom) + "_f16x2", _flops(geom)):
             L.call("conv2d_fwd_f16x2", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw)
         return out
@@ -229,15 +240,13 @@ def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE
     return out
 
 
-def wgrad_raw(x, dout, geom, cout, cin, kh, kw, cin_first=0):
+def wgrad_raw(x, dout, geom, cout, cin, kh, kw, cin_first=0, amax_cache=None):
     nbytes = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
     ws = scratch(nbytes, "wgrad")
     dw = new(cout, cin, kh, kw)
     flops = _flops(geom) * ((cin + 31) // 32 * 32 if geom.korder else geom.Cin) / geom.Cin
     if GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and flops >= CONV_F16X2_MIN_FLOP:
-        ax, ad = amax_slot(), amax_slot()
-        L.call("absmax", x, x.numel(), ax)
-        L.call("absmax", dout, dout.numel(), ad)
+        ax, ad = tensor_amax(x, amax_cache), tensor_amax(dout, amax_cache)
         with _timed("conv_wgrad_128x128_f16x2(+slab reduce)", flops):
             L.call("conv2d_wgrad_f16x2", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin_first, cin, ax, ad)
         return dw
@@ -579,7 +588,9 @@ class Conv2d(torch.autograd.Function):
                              res_noise=None if res_noise_w is None else (res_noise_w, res_noise_eps))
             vkeep = keep[0] if keep else None
         else:
-            out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act)
+            ctx.amax_cache = {}   # max |x| found here is reused by the weight gradient
+            out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act,
+                           amax_cache=ctx.amax_cache)
         assert noise_w is None or (ctx.wino and act == L.ACT_NONE and isinstance(noise_eps, PhiloxNormal))
         assert res_noise_w is None or (ctx.wino and res is not None and isinstance(res_noise_eps, PhiloxNormal))
         ctx.geom, ctx.act, ctx.has_bias, ctx.has_res = geom, act, bias is not None, res is not None
@@ -616,7 +627,7 @@ class Conv2d(torch.autograd.Function):
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
         elif ctx.needs_input_grad[0]:
             gd = L.geom_dgrad(geom)
-            dxl = conv_raw(g, _pack_dgrad(w, geom.Cout, gd.korder), gd)
+            dxl = conv_raw(g, _pack_dgrad(w, geom.Cout, gd.korder), gd, amax_cache=getattr(ctx, "amax_cache", None))
             if geom.ups:
                 dx = torch.empty_like(x)
                 L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
@@ -631,7 +642,7 @@ class Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
             dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep)
         elif ctx.needs_input_grad[1]:
-            dw = wgrad_raw(x, g, geom, co, ci, kh, kw)
+            dw = wgrad_raw(x, g, geom, co, ci, kh, kw, amax_cache=getattr(ctx, "amax_cache", None))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = channel_dot(g, None, co).clone()
         if ctx.has_res and ctx.needs_input_grad[3]:
