@@ -232,7 +232,7 @@ def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
     if GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and _flops(geom) >= CONV_F16X2_MIN_FLOP:
         ax, aw = tensor_amax(x, amax_cache), tensor_amax(wp)
-        with _timed(_variant(geom) + "_f16x2", _flops(geom)):
+        with _timed(_variant(geom).replace("halo", "igemm") + "_f16x2", _flops(geom)):   # (the halo kernel is fp32-only)
             L.call("conv2d_fwd_f16x2", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw)
         return out
     with _timed(_variant(geom), _flops(geom)):
