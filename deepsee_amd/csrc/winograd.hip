@@ -780,7 +780,9 @@ extern "C" {
 int dsee_absmax(const float* x, long n, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(x && amax && n > 0);
   DSEE_CHECK_ARG(((uintptr_t)x & 15) == 0);
-  absmax_kernel<<<(int)min(128L, (n / 4 + 255) / 256 + 1), 256, 0, st>>>(x, n, amax);
+  // one atomic per block at most, spread over 64 cache lines: 2048 blocks cost ~32 same-line atomics, and an
+  // activation-sized tensor (the direct convolutions' operands) streams at HBM rate instead of from 128 blocks
+  absmax_kernel<<<(int)min(2048L, (n / 4 + 1023) / 1024 + 1), 256, 0, st>>>(x, n, amax);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
