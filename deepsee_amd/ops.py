@@ -209,10 +209,10 @@ def _pack_dgrad(w, cout_s, korder):
     return wp
 
 
-# Direct (non-Winograd) convolutions with >= CONV_F16X2_MIN_FLOP of work run their MFMAs on fp16x2-split operands (the
+# Direct (non-Winograd) convolutions with >= CONV_F16X2_MIN_FLOP (1 GFLOP) of work run their MFMAs on fp16x2-split operands (the
 # split happens inside the kernel; two small max|.| passes over the input and the packed weights provide the scales).
 # Below the threshold the two extra launches cost more than the shorter MFMA chain saves.  0 disables.
-CONV_F16X2_MIN_FLOP = float(os.environ.get("DSEE_CONV_F16X2_MIN_FLOP", "4e9"))
+CONV_F16X2_MIN_FLOP = float(os.environ.get("DSEE_CONV_F16X2_MIN_FLOP", "1e9"))
 
 
 def tensor_amax(t, cache=None):
