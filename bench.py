@@ -296,6 +296,7 @@ def main():
                               "fp32_matrix_peak_tflops": 157.3 * world,
                               "note": "N * F_iter / t_iter with SURVEY 8(d)'s F_iter; exceeds the fp32 MFMA peak because "
                                       "the wide layers run on the fp16 matrix cores in the Winograd domain"}
+        out["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # of 288 GB (kept V / M tensors included)
         if fused:
             g = fused["gb"] / (fused["ms"] / 1e3)
             out["spade_fused"] = {"kernel": "wino43_output_modulate (output transform of the gamma/beta GEMM + BN-normalise "
