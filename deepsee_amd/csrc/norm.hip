@@ -28,7 +28,7 @@ RedGeom make_geom(int N, int HW, int C, int groups) {
   if (g.ppb < 1) g.ppb = 1;
   g.groups = groups;
   g.P = (N / groups) * HW;
-  long want = ((long)g.P * groups + 2047) / 2048;
+  long want = ((long)g.P * groups + 1023) / 1024;   // <= ~1024 chunks in all: the finalize walks them serially per lane
   long cp = want > (long)g.ppb * 4 ? want : (long)g.ppb * 4;
   cp = (cp + g.ppb - 1) / g.ppb * g.ppb;
   g.chunk_px = (int)cp;
