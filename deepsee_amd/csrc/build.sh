@@ -11,7 +11,10 @@ for f in *.hip *.cpp; do
   mkdir -p build
   if [ ! -e "$o" ] || [ "$f" -nt "$o" ] || [ dsee_common.h -nt "$o" ] || [ dsee_rng.h -nt "$o" ] || [ ../../include/deepsee_hip.h -nt "$o" ]; then
     echo "hipcc $f"
-    if [[ "$f" == *.hip ]]; then hipcc $FLAGS -c "$f" -o "$o"; else hipcc $FLAGS -x hip -c "$f" -o "$o"; fi
+    # spade_fused.hip keeps its 256 output accumulators in AGPRs by hand: the MFMA results must then live in VGPRs
+    EXTRA=""
+    if [[ "$f" == spade_fused.hip ]]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
+    if [[ "$f" == *.hip ]]; then hipcc $FLAGS $EXTRA -c "$f" -o "$o"; else hipcc $FLAGS -x hip -c "$f" -o "$o"; fi
   fi
   OBJS+=("$o")
 done

@@ -303,6 +303,74 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
   }
 }
 
+// The same transform written as the pre-split fp16x2 A operand of the fused SPADE kernel (spade_fused.hip):
+// V2 [C/16][36*T][2][16] fp16 -- per 16-channel slab and row (position, tile) 32 bytes of term 0 then 32 bytes of term 1 --
+// scaled by dsee_pow2_scale(bound * max|x|).  |B^T d B| <= 100 max|d| (absolute row sums of B^T: 10), so the scale is known
+// BEFORE the transform runs: the producer of x supplies max|x| and no second pass over V is needed.  A wave = 16
+// consecutive tiles x one slab, lane = (tile l >> 2, channel quad l & 3); lane pairs swap halves so that every lane stores
+// 16 contiguous bytes and a wave instruction fills 1 KB (16 rows x 64 B) of the image.
+__global__ __launch_bounds__(256) void wino43_input_f16x2_kernel(const float* __restrict__ x, unsigned char* __restrict__ V2,
+                                                                 int N, int H, int W, int C,
+                                                                 const float* __restrict__ amax, float bound) {
+  const float sc = dsee_pow2_scale(bound * dsee_amax_read(amax));
+  const int nkb = C >> 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = (T >> 4) * nkb * 64;
+  const size_t slab = (size_t)36 * T * 64;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long w = i >> 6;
+    const int l = (int)(i & 63);
+    const int kb = (int)(w % nkb);
+    const long t = (w / nkb) * 16 + (l >> 2);
+    const int q = kb * 4 + (l & 3);
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    f32x4 tmp[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int xx = tx * 4 - 1 + j;
+      f32x4 col[6], o[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int yy = ty * 4 - 1 + k;
+        const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H;
+        col[k] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + yy) * W + xx) * C + q * 4)
+                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      bt6(col, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
+    }
+    const bool odd = (l & 1) != 0;
+    unsigned char* rowp = V2 + (size_t)kb * slab + (size_t)t * 64 + (odd ? 32 + ((l & 3) - 1) * 8 : (l & 3) * 8);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      f32x4 o[6];
+      bt6(tmp[k], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        _Float16 h0[4], h1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = o[j][e] * sc;
+          h0[e] = (_Float16)v;
+          h1[e] = (_Float16)(v - (float)h0[e]);
+        }
+        auto pk = [](_Float16 a, _Float16 b) {
+          return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+        };
+        const unsigned p0a = pk(h0[0], h0[1]), p0b = pk(h0[2], h0[3]), p1a = pk(h1[0], h1[1]), p1b = pk(h1[2], h1[3]);
+        // the even lane hands its term-1 half to the odd lane and receives the odd lane's term-0 half
+        const unsigned sa = odd ? p0a : p1a, sb = odd ? p0b : p1b;
+        const unsigned ra = (unsigned)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        const unsigned rb = (unsigned)__builtin_amdgcn_mov_dpp((int)sb, 0xB1, 0xF, 0xF, true);
+        const u32x4 wv = odd ? (u32x4){ra, rb, p1a, p1b} : (u32x4){p0a, p0b, ra, rb};
+        *reinterpret_cast<u32x4*>(rowp + (size_t)(k * 6 + j) * T * 64) = wv;
+      }
+    }
+  }
+}
+
 // A d : 4 -> 6   (adjoint of at4)
 __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
   const f32x4 s02 = d[0] + d[2], s13 = d[1] + d[3], t02 = d[0] + 4.f * d[2], t13 = 2.f * d[1] + 8.f * d[3];
@@ -791,6 +859,18 @@ int dsee_absmax(const float* x, long n, float* amax, hipStream_t st) {
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(x && V && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   wino43_input_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C, amax);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* same transform, output as the pre-split fp16x2 operand of dsee_spade_fused_fwd: V2 [C/16][36*T][2][16] fp16 scaled by
+ * dsee_pow2_scale(bound * *amax_x) with amax_x >= max |x| (device maximum, 64-line form) and bound >= 100 */
+int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C, const float* amax_x, float bound,
+                            hipStream_t st) {
+  DSEE_CHECK_ARG(x && V2 && amax_x && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 100.f);
+  DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 16 == 0);
+  wino43_input_f16x2_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+      x, reinterpret_cast<unsigned char*>(V2), N, H, W, C, amax_x, bound);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

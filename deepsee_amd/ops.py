@@ -1032,6 +1032,18 @@ class SpadeNormAct(torch.autograd.Function):
         return dx, dcat, dw2, db2, None, None, None, None, None, None
 
 
+# The fused SPADE / SEAN forward (dsee_spade_fused_fwd): fp16x2 operands, K = 128 | 160, whole 64-tile groups per image.
+FUSED_NORM = True
+FUSED_V_BOUND = 100.0    # |B^T d B| <= 100 max|d|: the V scale is known before the transform runs
+
+
+def _fused_norm_ok(n, h, w, c, rows, ld):
+    tpi = (h // 4) * (w // 4)
+    return (FUSED_NORM and GEMM_SPLIT and GEMM_F16X2 and GEMM_AF32 and not HALF and ld in (128, 160) and rows == 2 * c
+            and c % 32 == 0 and h % 4 == 0 and w % 4 == 0 and tpi % 64 == 0
+            and 36 * n * tpi * ld * 4 < 0xFFFFFFF0 and 36 * n * rows * ld * 4 < 0xFFFFFFF0)
+
+
 class SeanNormTable(torch.autograd.Function):
     """SPADE / SEAN / PureSEAN norm + LeakyReLU as ONE node, with the SEAN style half as per-image tables.
 
@@ -1080,7 +1092,32 @@ class SeanNormTable(torch.autograd.Function):
         # `scale` is only read by the backward pass: the no-grad generator forward of the D step does not write it
         need_scale = any(ctx.needs_input_grad) or not nb
         out, scale = torch.empty_like(x), (torch.empty_like(x) if need_scale else None)
-        if nb:
+        fused = nb and _fused_norm_ok(n, h, w, c, rows, ld)
+        if fused:
+            # round 3: gamma/beta GEMM + output transform + normalise + modulate + LeakyReLU in ONE kernel
+            # (spade_fused.hip): the Winograd-domain product M never reaches HBM
+            kp = L.kpad(1, 1, ld)
+            t = n * (h // 4) * (w // 4)
+            ac = tensor_amax(cat)
+            v2 = _i16(36 * t * ld * 2)
+            L.call("wino43_input_f16x2", cat, v2, n, h, w, ld, ac, FUSED_V_BOUND)
+            if has_t:
+                ua = weight_amax(w2a if has_a else None, tb)
+                u = _i16(36 * n * rows * kp * 2)
+                L.call("wino43_weights_table", w2a if has_a else None, tb, u, n, rows, ca, 2, ua)
+            else:
+                u, ua = _wino_u(w2a, rows, ca, False, rows, kp, 2)
+            with _timed("spade_fused_fwd", 2.0 * 36 * t * ld * rows,
+                        4.0 * 36 * t * ld + 4.0 * n * h * w * c * (3 if need_scale else 2)):
+                L.call("spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
+                       scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE)
+            keep = None
+            if KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
+                # the weight / table gradient reads the fp32 V as its Q operand
+                vq = (new(36, t, ld), amax_slot())
+                L.call("wino43_input", cat, vq[0], n, h, w, ld, vq[1])
+                keep = [vq]
+        elif nb:
             tpi = (h // 4) * (w // 4)
             kp = L.kpad(1, 1, ld)
             b2c = b2.contiguous()

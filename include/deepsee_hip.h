@@ -160,6 +160,22 @@ int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const 
                                 int rows, float add_one, float slope, const float* mscale, hipStream_t stream);
 int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, int N, int rows, int ca, int split,
                               const float* amax_w, hipStream_t stream);
+/* The fused form (round 3; deepsee_amd/csrc/spade_fused.hip) of the same forward -- normalization.py:107-120 (SPADE),
+ * :167-213 (SEAN), :258-286 (PureSEAN above max_fm_size) + the LeakyReLU of architecture.py:92,114 -- in which the
+ * Winograd-domain product M never reaches HBM: one workgroup walks all 36 transform positions of 64 tiles x 32 channels,
+ * folds every position's MFMA result into the 4x4 output tiles in registers and normalises / modulates / activates in
+ * its epilogue.
+ *   V2 = dsee_wino43_input_f16x2(cat, amax_cat, v_bound)  [K/16][36*T][2][16] fp16: the split transform of the embedding,
+ *        scaled by a power of two known before the transform runs (|B^T d B| <= 100 max|d|; v_bound >= 100)
+ *   U2 = dsee_wino43_weights[_table](..., split = 2, amax_u)   [36*groups][K/16][rows][2][16] fp16
+ *   h [, scale] = dsee_spade_fused_fwd(...)   K = 128 (SPADE / capped) or 160 (SEAN: 128 + 32 one-hot), rows = 2 C,
+ *        C % 32 == 0, (H/4)*(W/4) % 64 == 0, groups = N (per-image style tables) or 1; out_scale may be NULL. */
+int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C, const float* amax_x, float bound,
+                            hipStream_t stream);
+int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
+                         const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
+                         float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
+                         float slope, hipStream_t stream);
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
                             float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,
