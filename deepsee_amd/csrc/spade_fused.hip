@@ -12,15 +12,22 @@
 //   Y = A^T M A  separably:   T[j] += At[j][c] * M[r][c]   (after every position, 4 partial columns)
 //                              Y[i][j] += At[i][r] * T[j]   (after every row r of positions)
 //
-// so M never exists outside the register file.  Per wave: one 32 x 32 MFMA block (rows x tiles), Y = 16 x 16 = 256
-// accumulator registers, T = 64, two ping-pong MFMA accumulators; 4 waves (2 row halves x 2 tile halves), one per SIMD.
-// Operand slabs (16 k's: 64 rows x 64 B of U and of V) travel global -> LDS by buffer_load ... lds into a 4-slot ring
-// of half-position stages (5 slabs of U + 5 of V = 40 KB at K = 160); the LDS image is XOR-swizzled (16-byte chunk c of
-// row r at slot 4r + (c ^ ((r >> 2) & 3))) so that every ds_read_b128 fragment read is conflict free without dummy slots.
-// MFMA orientation: A operand = U rows (packed gamma/beta rows), B operand = V rows (tiles): a lane ends with ONE tile and
-// 8 channels x (gamma, beta) -- the rows of a wave's block are gathered as [16 gamma rows | the 16 beta rows of the same
-// channels], so gamma and beta of a channel meet in the same lane.  The epilogue swaps the block's results through LDS
-// into pixel-major order and reads x / writes h (and scale) as whole 128-byte lines.
+// so M never exists outside the register file.
+//
+// Work split: 8 waves (2 row halves x 4 tile quarters), two per SIMD, so that the LDS-DMA issue, LDS reads and the VALU
+// folds of one wave overlap the partner wave's matrix work (a first version with 4 waves of 32x32 MFMA blocks, one per
+// SIMD, was bound by the in-order issue of a single wave: removing the MFMAs changed nothing, removing DMA / folds /
+// fragment reads saved 0.8 / 0.5 / 0.4 ms of 3.0).  A wave owns two 16x16 blocks of v_mfma_f32_16x16x32_f16 -- the 16
+// gamma rows and the 16 beta rows of the same 16 channels -- for 16 tiles: a lane ends with ONE tile and 4 consecutive
+// channels x (gamma, beta).  Y = 16 outputs x 8 = 128 accumulator registers per wave (AGPRs, updated in place once per row
+// of positions: the VALU cannot address them), T = 32, MFMA accumulators 2 x 8.
+// Operands travel global -> LDS by buffer_load ... lds in 32-k pieces (64 rows x 128 B = 2 terms x 4 k-octets; one
+// instruction per wave and piece) into a ring of two positions; a position is two stages (2 + 2|3 pieces), one barrier
+// each, the requests of stage s + 3 are issued during stage s.  The two waves of a SIMD run each piece in complementary order (MFMAs
+// first / loads and folds first).  The piece image is XOR-swizzled (16-byte chunk cc of row r
+// at slot 8r + (cc ^ ((r >> 1) & 7))): every ds_read_b128 fragment read is conflict free.
+// The epilogue requests the block's x values first (64 KB in flight per CU), swaps the results through LDS into
+// pixel-major order and reads / writes whole 128-byte lines.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -57,7 +64,7 @@ struct FusedArgs {
   int H, W, C, rows;
   int G;                     // weight groups per position: images (per-image tables) or 1
   float v_bound, add_one, slope;
-  int stagger;               // cycles between the start phases of the first workgroup of neighbouring CUs (0: none)
+  float* stamps;             // measurement builds (DSEE_FUSED_ABL & 32): per-wave cycle totals
 };
 
 template <int I>
@@ -78,18 +85,16 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
   return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
 }
 
-template <int NSL, bool WSCALE>
-__global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
+template <int NP, bool WSCALE>
+__global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int PIECE = 4096;                 // one slab of one operand: 64 rows x 64 B
-  constexpr int STAGE = 2 * NSL * PIECE;      // half a transform position: NSL slabs of U, NSL slabs of V
-  constexpr int NI = 2 * NSL;                 // LDS-DMA instructions per wave and stage
-  constexpr int NK = 2 * NSL;                 // slabs per position
-  static_assert(NSL == 4 || NSL == 5, "K = 128 or 160");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 4 * STAGE
+  constexpr int PIECE = 8192;                  // 32 k's of one operand: 64 rows x (2 terms x 4 octets x 16 B)
+  constexpr int UREG = 2 * NP * PIECE;         // LDS: [2 NP pieces of U][2 NP pieces of V]; piece (par, k) in slot par * NP + k
+  static_assert(NP == 4 || NP == 5, "K = 128 or 160");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * POSB (>= 64 KB for the epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wt = wave & 1;
+  const int wq = wave >> 2, wt = wave & 3;     // row half (16 channels), tile quarter (16 tiles)
 
   // ---- workgroup -> (tile group of 64 tiles, row group of 64 packed rows).  Blocks b, b + 8, ... share an XCD (and
   //      its L2): each XCD walks a contiguous range of the list, 32 consecutive entries (one per CU) = 4 tile groups x 8
@@ -112,13 +117,6 @@ __global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
     tg = l / rgn;
     rg = (int)(l % rgn);
   }
-  // The first workgroup of every CU starts up to 3/4 of a tile late (4 phases by CU): all tiles take the same time, and
-  // without this every CU would reach its HBM-bound epilogue (read x, write h / scale) at the same moment while the
-  // memory system idles during the matrix phases.
-  if (a.stagger > 0 && blockIdx.x < 256) {
-    const long long until = (long long)__builtin_readcyclecounter() + (long long)((blockIdx.x >> 3) & 3) * a.stagger;
-    while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
-  }
   const long t0 = tg * 64;                    // first tile (of the batch)
   const int n = (int)(t0 / a.tpi);            // its image
   const int g = a.G > 1 ? n : 0;
@@ -128,103 +126,129 @@ __global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
   const float su = dsee_pow2_scale(dsee_amax_read(a.amax_u));
   const float oscale = 1.f / (sv * su);
 
-  // ---- LDS-DMA: wave w fills rows 16w .. 16w+15 of every piece; lane -> (row 16w + l/4, slot chunk l%4).  The slab
-  //      index rides in the per-lane offset, the (position, half, tile / row group) base in the scalar offset.
-  const int dr = 16 * wave + (lane >> 2);
-  const unsigned voff = (unsigned)(dr * 64 + (((lane & 3) ^ ((dr >> 2) & 3)) * 16));
+  // ---- LDS-DMA: wave w fills rows 8w .. 8w+7 of every piece (64 slots); lane -> (row 8w + l/8, slot chunk l%8) fetches
+  //      chunk cc = (l%8) ^ f(row) = 4 term + octet: bytes (2 term + octet%2) * 16 of the row in 16-k slab 2 piece + octet/2.
+  const int dr = 8 * wave + (lane >> 3);
+  const int dcc = (lane & 7) ^ ((dr >> 1) & 7);
+  const unsigned dlo = (unsigned)(dr * 64 + (2 * (dcc >> 2) + (dcc & 1)) * 16);
+  const unsigned voffu = dlo + (unsigned)((dcc >> 1) & 1) * (unsigned)a.u_slab_bytes;
+  const unsigned voffv = dlo + (unsigned)((dcc >> 1) & 1) * (unsigned)a.v_slab_bytes;
   const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(a.U2), 0, (int)a.u_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(a.V2), 0, (int)a.v_bytes, 0x00020000);
-  unsigned voffu[NSL], voffv[NSL];
-#pragma unroll
-  for (int p = 0; p < NSL; ++p) {
-    voffu[p] = voff + (unsigned)p * (unsigned)a.u_slab_bytes;
-    voffv[p] = voff + (unsigned)p * (unsigned)a.v_slab_bytes;
-  }
   const unsigned PU = (unsigned)(a.G * a.u_group_bytes), PV = (unsigned)(a.T * 64);       // per position
-  const unsigned HU = (unsigned)(NSL * a.u_slab_bytes), HV = (unsigned)(NSL * a.v_slab_bytes);   // second half
-  const unsigned base_u = (unsigned)((long)g * a.u_group_bytes + (long)rg * PIECE), base_v = (unsigned)(t0 * 64);
-  // piece q (q < NSL: U slab q, else V slab q - NSL) of stage (pos, half) into ring slot `slot`
-  auto dma = [&](int slot, int q, unsigned ou, unsigned ov) {
-    unsigned char* dst = smem + slot * STAGE + q * PIECE + wave * 1024;
-    if (q < NSL)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void*)dst, 16, voffu[q], ou, 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)dst, 16, voffv[q - NSL], ov, 0, 0);
+  const unsigned QU = (unsigned)(2 * a.u_slab_bytes), QV = (unsigned)(2 * a.v_slab_bytes);   // per piece
+  const unsigned base_u = (unsigned)((long)g * a.u_group_bytes + (long)rg * 4096), base_v = (unsigned)(t0 * 64);
+  // piece pc of position pos (ring half par): one U and one V instruction per wave
+  auto dma_u = [&](int par, int pc, unsigned opos) {
+    unsigned char* dst = smem + (par * NP + pc) * PIECE + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void*)dst, 16, voffu, opos + pc * QU, 0, 0);
   };
-  auto issue_stage = [&](int s) {
-    const int pos = s >> 1, half = s & 1;
-    const unsigned ou = base_u + pos * PU + half * HU, ov = base_v + pos * PV + half * HV;
-#pragma unroll
-    for (int q = 0; q < 2 * NSL; ++q) dma(s & 3, q, ou, ov);
+  auto dma_v = [&](int par, int pc, unsigned opos) {
+    unsigned char* dst = smem + UREG + (par * NP + pc) * PIECE + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)dst, 16, voffv, opos + pc * QV, 0, 0);
   };
 
-  // ---- fragment addresses.  U rows of this wave's block: lanes 0-15 -> gamma rows 16 wr + i, lanes 16-31 -> the beta
-  //      rows 32 + 16 wr + (i - 16) of the same 16 channels; V rows: tiles 32 wt + i.  k-half = lane >> 5.
-  const int fi = lane & 31, kh = lane >> 5;
-  const int ru = fi < 16 ? 16 * wr + fi : 16 + 16 * wr + fi;
-  const int rv = 32 * wt + fi;
-  const unsigned fu0 = (unsigned)((4 * ru + (kh ^ ((ru >> 2) & 3))) * 16), fu1 = (unsigned)((4 * ru + ((2 + kh) ^ ((ru >> 2) & 3))) * 16);
-  const unsigned fv0 = (unsigned)((4 * rv + (kh ^ ((rv >> 2) & 3))) * 16), fv1 = (unsigned)((4 * rv + ((2 + kh) ^ ((rv >> 2) & 3))) * 16);
+  // ---- fragment addresses (bytes within a piece): row r, chunk 4 term + octet at slot 8r + (chunk ^ f(r)).
+  //      A operand: lane -> (row l%16 of its 16-row block, octet l/16); gamma block rows 16 wq + i, beta block rows
+  //      32 + 16 wq + i of the 64-row group; B operand: tiles 16 wt + i.
+  const int fi = lane & 15, oc = lane >> 4;
+  auto foff = [&](int r, int t) { return (unsigned)((8 * r + ((4 * t + oc) ^ ((r >> 1) & 7))) * 16); };
+  const int rga = 16 * wq + fi, rtv = 16 * wt + fi;
+  // DS instructions address VGPR + 16-bit immediate: two windows (slots 0-6, 7-9) per fragment kind cover each 80 / 64 KB region (the
+  // beta block's rows are the gamma block's + 32: same swizzle, + 4096 bytes)
+  const unsigned au0 = foff(rga, 0), au1 = foff(rga, 1), au0h = au0 + 7 * PIECE, au1h = au1 + 7 * PIECE;
+  const unsigned av0 = UREG + foff(rtv, 0), av1 = UREG + foff(rtv, 1), av0h = av0 + 7 * PIECE, av1h = av1 + 7 * PIECE;
   struct Frag {
-    u32x4 u0, u1, v0, v1;
+    u32x4 g0, g1, b0, b1, v0, v1;
   };
-  auto ldf = [&](Frag& f, int slot, int p) {
-    const unsigned char* b = smem + slot * STAGE + p * PIECE;
-    f.u0 = *reinterpret_cast<const u32x4*>(b + fu0);
-    f.u1 = *reinterpret_cast<const u32x4*>(b + fu1);
-    f.v0 = *reinterpret_cast<const u32x4*>(b + NSL * PIECE + fv0);
-    f.v1 = *reinterpret_cast<const u32x4*>(b + NSL * PIECE + fv1);
+  auto ldf = [&](Frag& f, auto par_c, auto pc_c) {
+    constexpr int so = (decltype(par_c)::value * NP + decltype(pc_c)::value) * PIECE;   // slot offset within the region
+    constexpr bool hi = so >= 7 * PIECE;
+    constexpr int io = hi ? so - 7 * PIECE : so;
+    static_assert(io >= 0 && io + 4096 + PIECE <= 65536, "window");
+    const unsigned char* bu0 = smem + (hi ? au0h : au0);
+    const unsigned char* bu1 = smem + (hi ? au1h : au1);
+    const unsigned char* bv0 = smem + (hi ? av0h : av0);
+    const unsigned char* bv1 = smem + (hi ? av1h : av1);
+    f.g0 = *reinterpret_cast<const u32x4*>(bu0 + io);
+    f.g1 = *reinterpret_cast<const u32x4*>(bu1 + io);
+    f.b0 = *reinterpret_cast<const u32x4*>(bu0 + io + 4096);
+    f.b1 = *reinterpret_cast<const u32x4*>(bu1 + io + 4096);
+    f.v0 = *reinterpret_cast<const u32x4*>(bv0 + io);
+    f.v1 = *reinterpret_cast<const u32x4*>(bv1 + io);
   };
-  // the three products of a slab, alternating between two accumulators (no back-to-back dependent MFMAs)
-  auto mm = [&](const Frag& f, f32x16& p0, f32x16& p1) {
-    const f16x8 u0 = __builtin_bit_cast(f16x8, f.u0), u1 = __builtin_bit_cast(f16x8, f.u1);
+  // the three products of a piece for both blocks, alternating between the two accumulators
+  auto mm = [&](const Frag& f, f32x4& pg, f32x4& pb) {
+    const f16x8 g0 = __builtin_bit_cast(f16x8, f.g0), g1 = __builtin_bit_cast(f16x8, f.g1);
+    const f16x8 b0 = __builtin_bit_cast(f16x8, f.b0), b1 = __builtin_bit_cast(f16x8, f.b1);
     const f16x8 v0 = __builtin_bit_cast(f16x8, f.v0), v1 = __builtin_bit_cast(f16x8, f.v1);
     if constexpr (DSEE_FUSED_ABL & 1) {
-      p0[0] += (float)(u1[0] + v0[1]);
-      p1[1] += (float)(u0[2] + v1[3]);
+      pg[0] += (float)(g1[0] + v0[1]) + (float)(g0[2] + v1[3]);
+      pb[1] += (float)(b1[0] + v0[1]) + (float)(b0[2] + v1[3]);
     } else {
-      p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(u1, v0, p0, 0, 0, 0);
-      p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(u0, v1, p1, 0, 0, 0);
-      p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(u0, v0, p0, 0, 0, 0);
+      pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, v0, pg, 0, 0, 0);
+      pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, v0, pb, 0, 0, 0);
+      pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, v1, pg, 0, 0, 0);
+      pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, v1, pb, 0, 0, 0);
+      pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, v0, pg, 0, 0, 0);
+      pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, v0, pb, 0, 0, 0);
     }
   };
 
-  // Y lives in the accumulator half of the register file (256 AGPRs; the VALU cannot address them, so an update is
-  // v_accvgpr_read -> v_fmac -> v_accvgpr_write, once per row of positions); everything the VALU touches per position
-  // (T, two pairs of MFMA accumulators, fragments) stays below the 256 architectural VGPRs.  The file is compiled with
-  // -mllvm -amdgpu-mfma-vgpr-form so that the MFMA accumulators do not compete for AGPRs.
-  float Y[4][4][16];
-  f32x16 T[4], P[2][2];
+  // Everything from here on exists twice, once per wave group (see `late` below): the accumulator-resident state never
+  // crosses a control-flow merge (the register allocator spilled all of it at the merge otherwise).
+  auto body = [&](auto late_c) {
+  // Y lives in the accumulator half of the register file (128 AGPRs per wave; the VALU cannot address them, so an update
+  // is v_accvgpr_read -> v_fmac -> v_accvgpr_write in place, once per row of positions); everything the VALU touches per
+  // position (T, two pairs of MFMA accumulators, fragments) stays within the 128 architectural VGPRs.  The file is
+  // compiled with -mllvm -amdgpu-mfma-vgpr-form so that the MFMA accumulators do not compete for AGPRs.
+  float Y[4][4][8];      // [output row i][output column j][gamma 0..3 | beta 4..7]
+  f32x4 T[4][2], P[2];
   Frag F[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(Y[i][j][e]));
+  static_for<4>([&](auto i) {
+    static_for<4>([&](auto j) {
+      static_for<8>([&](auto e) {
+        float& yr = Y[decltype(i)::value][decltype(j)::value][decltype(e)::value];
+        asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(yr));
+      });
+    });
+  });
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) T[j][e] = 0.f;
+    for (int b = 0; b < 2; ++b) T[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  issue_stage(0);
-  issue_stage(1);
-  issue_stage(2);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");   // stage 0 landed (this wave's rows)
+  // ---- ring: 2 NP pieces (two positions), piece (pos, k) in slot (pos & 1) * NP + k.  A position is two stages (pieces
+  //      [0, NA) and [NA, NP)), one barrier each; the requests of stage s + 3 are issued during stage s into the slots of
+  //      stage s - 1 (dead: every wave consumed those fragments before it arrived at the barrier that opens s).
+  constexpr int NA = 2;
+  auto issue_stage = [&](int pos, int half) {   // prologue only (run-time indices)
+    for (int k = half ? NA : 0; k < (half ? NP : NA); ++k) {
+      dma_u(pos & 1, k, base_u + pos * PU);
+      dma_v(pos & 1, k, base_v + pos * PV);
+    }
+  };
+  issue_stage(0, 0);
+  issue_stage(0, 1);
+  issue_stage(1, 0);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");   // stage 0 landed (this wave's rows)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  ldf(F[0], 0, 0);
+  ldf(F[0], ic<0>{}, ic<0>{});
+  // (the two waves of a SIMD, w and w + 4, run the same pieces in complementary order: the early one issues its 6 MFMAs
+  // first and its LDS reads / DMA requests / VALU folds afterwards, the late one the other way round -- in lock-step both
+  // wanted the same pipe at the same time and nothing overlapped)
 
-  // Y[i][pair j] += cf[i] * T[j]  for the (i, j) pairs [lo, hi) of the 16
+  // Y[i][j] += cf[i] * T[j] for the (i, j) pairs [LO, HI) of the 16
   auto y_update = [&](auto lo_c, auto hi_c, const float (&cf)[4]) {
     constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     static_for<HI - LO>([&](auto d) {
       constexpr int ij = LO + decltype(d)::value, i = ij >> 2, j = ij & 3;
-      static_for<16>([&](auto ec) {
+      static_for<8>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         float y;   // in place: the accumulator register is both input and output, so Y never moves between AGPRs
         float& yr = Y[i][j][e];
-        const float cc = cf[i], tt = T[j][e];
+        const float cc = cf[i], tt = T[j][e >> 2][e & 3];
         asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_fmac_f32 %1, %2, %3\n\tv_accvgpr_write_b32 %0, %1"
                      : "+a"(yr), "=&v"(y)
                      : "s"(cc), "v"(tt));
@@ -232,106 +256,137 @@ __global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
     });
   };
 
-  // One transform position = 2 stages = NK slabs.  Before the MFMAs of slab k the fragments of slab k + 1 (of the next
-  // stage at a stage end) are requested; the look-ahead stage s + 3 is requested two pieces per slab; `fill(k)` is the
-  // VALU work that hides under this position's matrix work: the fold of the PREVIOUS position's product and, after a row
-  // of positions, the Y update.  pos is wave-uniform; PAR selects the accumulator pair.
-  auto position = [&](int pos, auto par_c, auto&& fill) {
+#if DSEE_FUSED_ABL & 32
+  unsigned long long tw_ = 0, tm_ = 0, tl_ = 0, t0_ = 0, t1_ = 0, tstart_ = __builtin_readcyclecounter();
+#endif
+  // One transform position = NP pieces in two stages.  During piece k the fragments of piece k + 1 (of the next position at
+  // the end) are read, a share of the look-ahead stage s + 3 is requested and `fill(k)` runs (the Y update of the previous
+  // row of positions).  Between barriers the waves drift freely.  pos is wave-uniform, its parity PAR (ring half) a
+  // compile-time constant.
+  auto position = [&](auto late_c, int pos, auto par_c, auto&& fill) {
+    constexpr bool LATE = decltype(late_c)::value != 0;
     constexpr int PAR = decltype(par_c)::value;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      P[PAR][0][e] = 0.f;
-      P[PAR][1][e] = 0.f;
-    }
+    P[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    P[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     static_for<2>([&](auto half_c) {
       constexpr int half = decltype(half_c)::value;
-      const int s = 2 * pos + half;
       // look-ahead stage s + 3 = (pos + 1, second half) | (pos + 2, first half), clamped to the last position (the
-      // surplus requests of the last three stages re-read valid memory into a ring slot nobody reads any more)
+      // surplus requests of the last three stages re-read valid memory into slots nobody reads any more)
       const int pl = min(pos + 1 + half, 35);
-      const unsigned ou = base_u + pl * PU + (1 - half) * HU, ov = base_v + pl * PV + (1 - half) * HV;
-      // stage s + 1 has landed (this wave's rows) when only the NI requests of stage s + 2 are still in flight
+      const unsigned ou = base_u + pl * PU, ov = base_v + pl * PV;
+      constexpr int LPAR = half ? PAR : 1 - PAR;               // ring half of the look-ahead position
+      constexpr int L0 = half ? 0 : NA, L1 = half ? NA : NP;   // its pieces
+      constexpr int C0 = half ? NA : 0, C1 = half ? NP : NA;   // the pieces computed now
+#if DSEE_FUSED_ABL & 32
+      t0_ = __builtin_readcyclecounter();
+#endif
+      // stage s + 1 has landed (this wave's rows) when only the requests of stage s + 2 are still in flight
       if constexpr (DSEE_FUSED_ABL & 8)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (C1 - C0)) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      static_for<NSL>([&](auto p_c) {
-        constexpr int p = decltype(p_c)::value, k = half * NSL + p;
+#if DSEE_FUSED_ABL & 32
+      t1_ = __builtin_readcyclecounter();
+      tw_ += t1_ - t0_;
+#endif
+      static_for<C1 - C0>([&](auto p_c) {
+        constexpr int p = decltype(p_c)::value, k = C0 + p;
+        constexpr int fcur = (k + (NP & 1) * PAR) & 1;   // fragment buffer: parity of the running piece count pos * NP + k
+        auto loads = [&]() {
+          if constexpr (!(DSEE_FUSED_ABL & 2)) {
+            if constexpr (k + 1 < NP)
+              ldf(F[1 - fcur], ic<PAR>{}, ic<k + 1>{});
+            else
+              ldf(F[1 - fcur], ic<1 - PAR>{}, ic<0>{});
+          }
+          if constexpr (!(DSEE_FUSED_ABL & 8)) {
+            // the L1 - L0 look-ahead pieces spread over the C1 - C0 computed ones
+            constexpr int a0 = L0 + p * (L1 - L0) / (C1 - C0), a1 = L0 + (p + 1) * (L1 - L0) / (C1 - C0);
+            static_for<a1 - a0>([&](auto d) {
+              dma_u(LPAR, a0 + decltype(d)::value, ou);
+              dma_v(LPAR, a0 + decltype(d)::value, ov);
+            });
+          }
+          if constexpr (!(DSEE_FUSED_ABL & 4)) fill(ic<k>{});
+        };
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LATE) {
+        loads();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(DSEE_FUSED_ABL & 2)) {
-          if (p + 1 < NSL)
-            ldf(F[(k + 1) & 1], s & 3, p + 1);
-          else
-            ldf(F[(k + 1) & 1], (s + 1) & 3, 0);
-        }
-        if constexpr (!(DSEE_FUSED_ABL & 8)) {
-          dma((s + 3) & 3, p, ou, ov);
-          dma((s + 3) & 3, NSL + p, ou, ov);
-        }
-        if (k & 1) mm(F[1], P[PAR][1], P[PAR][0]); else mm(F[0], P[PAR][0], P[PAR][1]);
-        if constexpr (!(DSEE_FUSED_ABL & 4)) fill(ic<k>{});
+#if DSEE_FUSED_ABL & 32
+        { const unsigned long long tt = __builtin_readcyclecounter(); tl_ += tt - t1_; t1_ = tt; }
+#endif
+        mm(F[fcur], P[0], P[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#if DSEE_FUSED_ABL & 32
+        { const unsigned long long tt = __builtin_readcyclecounter(); tm_ += tt - t1_; t1_ = tt; }
+#endif
+      } else {
+        mm(F[fcur], P[0], P[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#if DSEE_FUSED_ABL & 32
+        { const unsigned long long tt = __builtin_readcyclecounter(); tm_ += tt - t1_; t1_ = tt; }
+#endif
+        loads();
+        __builtin_amdgcn_sched_barrier(0);
+#if DSEE_FUSED_ABL & 32
+        { const unsigned long long tt = __builtin_readcyclecounter(); tl_ += tt - t1_; t1_ = tt; }
+#endif
+      }
       });
     });
-    __builtin_amdgcn_sched_barrier(0);
   };
-  // fold of the product of the previous position (column CP of its row) into T, entries [e0, e1)
-  auto fold = [&](auto cp_c, const f32x16& q0, const f32x16& q1, auto e0_c, auto e1_c) {
-    constexpr int CP = decltype(cp_c)::value, E0 = decltype(e0_c)::value, E1 = decltype(e1_c)::value;
-    static_for<E1 - E0>([&](auto d) {
-        constexpr int e = E0 + decltype(d)::value;
-        const float m = q0[e] + q1[e];
-        if constexpr (CP == 0) {
-          T[0][e] += m;
-        } else if constexpr (CP == 1) {
-          T[0][e] += m; T[1][e] += m; T[2][e] += m; T[3][e] += m;
-        } else if constexpr (CP == 2) {
-          T[0][e] += m; T[1][e] -= m; T[2][e] += m; T[3][e] -= m;
-        } else if constexpr (CP == 3) {
-          T[0][e] += m; T[1][e] += 2.f * m; T[2][e] += 4.f * m; T[3][e] += 8.f * m;
-        } else if constexpr (CP == 4) {
-          T[0][e] += m; T[1][e] -= 2.f * m; T[2][e] += 4.f * m; T[3][e] -= 8.f * m;
-        } else {
-          T[3][e] += m;
-        }
-    });
-  };
-  // Row r of the positions: (r, 0) hides the closing work of row r - 1 (last fold, Y += At[.][r-1] (x) T in slices, T
-  // restarts), (r, c > 0) hides the fold of (r, c - 1).  For r = 0 the "previous row" has all-zero coefficients and a zero
-  // product: the same code runs, so the loop body has no conditional blocks.
+  // fold of the product of a position (column CP of its row) into T
+  auto fold = [&](auto cp_c, const f32x4& qg, const f32x4& qb) {
+    constexpr int CP = decltype(cp_c)::value;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    P[1][0][e] = 0.f;
-    P[1][1][e] = 0.f;
-  }
+    for (int b = 0; b < 2; ++b) {
+      const f32x4 m = b ? qb : qg;
+      if constexpr (CP == 0) {
+        T[0][b] += m;
+      } else if constexpr (CP == 1) {
+        T[0][b] += m; T[1][b] += m; T[2][b] += m; T[3][b] += m;
+      } else if constexpr (CP == 2) {
+        T[0][b] += m; T[1][b] -= m; T[2][b] += m; T[3][b] -= m;
+      } else if constexpr (CP == 3) {
+        T[0][b] += m; T[1][b] += 2.f * m; T[2][b] += 4.f * m; T[3][b] += 8.f * m;
+      } else if constexpr (CP == 4) {
+        T[0][b] += m; T[1][b] -= 2.f * m; T[2][b] += 4.f * m; T[3][b] -= 8.f * m;
+      } else {
+        T[3][b] += m;
+      }
+    }
+  };
+
+  // Row r of the positions: every position folds its product into T when its last MFMA has retired (the partner wave of
+  // the SIMD covers the bubble); (r, 0) additionally hides Y += At[.][r-1] (x) T of the previous row in slices under its
+  // pieces, then T restarts.  For r = 0 the "previous row" has all-zero coefficients: the same code runs, so the loop body
+  // has no conditional blocks.
 #pragma unroll 1
   for (int r = 0; r < 6; ++r) {
     const int q = r - 1;   // At[i][q]
     const float cf[4] = {q < 0 ? 0.f : 1.f, q <= 0 ? 0.f : (q == 1 ? 1.f : (q == 2 ? -1.f : (q == 3 ? 2.f : -2.f))),
                          q <= 0 ? 0.f : (q < 3 ? 1.f : 4.f),
                          q <= 0 ? 0.f : (q == 1 ? 1.f : (q == 2 ? -1.f : (q == 3 ? 8.f : -8.f)))};
-    position(r * 6, ic<0>{}, [&](auto k_c) {
+    position(late_c, r * 6, ic<0>{}, [&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
-      if constexpr (k < 2) {
-        fold(ic<5>{}, P[1][0], P[1][1], ic<8 * k>{}, ic<8 * k + 8>{});
-      } else {
-        constexpr int NY = NK - 2, qq = k - 2;
+      if constexpr (k >= 1) {
+        constexpr int NY = NP - 1, qq = k - 1;
         y_update(ic<qq * 16 / NY>{}, ic<(qq + 1) * 16 / NY>{}, cf);
-        if constexpr (k == NK - 1) {
+        if constexpr (k == NP - 1) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) T[j][e] = 0.f;
+            for (int b = 0; b < 2; ++b) T[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
     });
-#define DSEE_POS(C, PAR)                                                                                                    \
-  position(r * 6 + C, ic<PAR>{}, [&](auto k_c) {                                                                            \
-    constexpr int k = decltype(k_c)::value;                                                                                 \
-    if constexpr (k < 8) fold(ic<C - 1>{}, P[1 - PAR][0], P[1 - PAR][1], ic<2 * k>{}, ic<2 * k + 2>{});                    \
-  });
+    fold(ic<0>{}, P[0], P[1]);
+#define DSEE_POS(C, PAR)                                        \
+  position(late_c, r * 6 + C, ic<PAR>{}, [&](auto) {});         \
+  fold(ic<C>{}, P[0], P[1]);
     DSEE_POS(1, 1)
     DSEE_POS(2, 0)
     DSEE_POS(3, 1)
@@ -339,16 +394,20 @@ __global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
     DSEE_POS(5, 1)
 #undef DSEE_POS
   }
-  // ---- epilogue.  The x values of the whole block tile (4 pixel rows x 8 items per thread) are requested first, so that
-  //      128 KB per CU are in flight while the last fold / Y update and the LDS exchange run.
+
+  // ---- epilogue.  The x values of the whole block tile (4 pixel rows x 4 items per thread) are requested first, so that
+  //      64 KB per CU are in flight while the last Y update and the LDS exchange run.
+#if DSEE_FUSED_ABL & 32
+  const unsigned long long tmain_ = __builtin_readcyclecounter();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the surplus look-ahead requests write LDS too)
   const int chunk_r = tid & 7;                            // read phase: channel quad of the 32-channel group
   const int cq = rg * 32 + chunk_r * 4;
-  size_t xoff[8];
-  f32x4 xr[4][8];
+  size_t xoff[4];
+  f32x4 xr[4][4];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int px = it * 32 + (tid >> 3);
+  for (int it = 0; it < 4; ++it) {
+    const int px = it * 64 + (tid >> 3);
     const int tl = px >> 2, j = px & 3;
     const int tin = (int)(t0 + tl - (long)n * a.tpi);
     const int ty = tin / a.tw, tx = tin - ty * a.tw;
@@ -359,10 +418,10 @@ __global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int it = 0; it < 8; ++it) xr[k][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + xoff[it] + k * rowstride));
+      for (int it = 0; it < 4; ++it)
+        xr[k][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + xoff[it] + k * rowstride));
   }
   __builtin_amdgcn_sched_barrier(0);
-  fold(ic<5>{}, P[1][0], P[1][1], ic<0>{}, ic<16>{});
   {
     const float cf[4] = {0.f, 0.f, 0.f, 1.f};
     y_update(ic<12>{}, ic<16>{}, cf);   // row 5 of the positions: At[.][5] = (0, 0, 0, 1)
@@ -375,38 +434,37 @@ __global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
   asm volatile("" ::: "memory");
   float* const Gs = reinterpret_cast<float*>(smem);
   float* const Bs = reinterpret_cast<float*>(smem + 32768);
-  const int tl_w = 32 * wt + fi;                          // this lane's tile within the block
+  const int tl_w = 16 * wt + fi;                          // this lane's tile within the block
   const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cq), is = *reinterpret_cast<const f32x4*>(a.invstd + cq);
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   const f32x4 bg = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + rg * 64 + chunk_r * 4) : z4;
   const f32x4 bb = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + rg * 64 + 32 + chunk_r * 4) : z4;
-#pragma unroll
-  for (int k = 0; k < ((DSEE_FUSED_ABL & 16) ? 0 : 4); ++k) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+  const int chw = ((wq * 4 + oc) ^ (tl_w & 7)) * 4;       // write phase: this lane's channel quad 16 wq + 4 oc, swizzled
+  static_for<(DSEE_FUSED_ABL & 16) ? 0 : 4>([&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    static_for<4>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
       const int px = tl_w * 4 + j;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {   // the lane's two channel quads: 16 wr + 8 h + 4 kh
-        const int ch = ((wr * 4 + h * 2 + kh) ^ (tl_w & 7)) * 4;
-        f32x4 gv, bv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float yg, yb;
-          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(yg) : "a"(Y[k][j][4 * h + e]));
-          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(yb) : "a"(Y[k][j][8 + 4 * h + e]));
-          gv[e] = yg;
-          bv[e] = yb;
-        }
-        *reinterpret_cast<f32x4*>(Gs + px * 32 + ch) = gv;
-        *reinterpret_cast<f32x4*>(Bs + px * 32 + ch) = bv;
-      }
-    }
+      f32x4 gv, bv;
+      static_for<4>([&](auto e_c) {
+        constexpr int e = decltype(e_c)::value;
+        float yg, yb;
+        float& rg_ = Y[k][j][e];
+        float& rb_ = Y[k][j][4 + e];
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(yg) : "a"(rg_));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(yb) : "a"(rb_));
+        gv[e] = yg;
+        bv[e] = yb;
+      });
+      *reinterpret_cast<f32x4*>(Gs + px * 32 + chw) = gv;
+      *reinterpret_cast<f32x4*>(Bs + px * 32 + chw) = bv;
+    });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int px = it * 32 + (tid >> 3);
+    for (int it = 0; it < 4; ++it) {
+      const int px = it * 64 + (tid >> 3);
       const int tl = px >> 2;
       const size_t off = xoff[it] + k * rowstride;
       const int ch = (chunk_r ^ (tl & 7)) * 4;
@@ -420,18 +478,33 @@ __global__ __launch_bounds__(256, 1) void spade_fused_fwd_kernel(FusedArgs a) {
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
       __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + off));
     }
-    if (k < 3) {
+    if constexpr (k < 3) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
+  });
+#if DSEE_FUSED_ABL & 32
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && blockIdx.x < 64) {   // per wave: stage waits | MFMA parts | load parts | epilogue
+    const unsigned long long tend_ = __builtin_readcyclecounter();
+    float* o = a.stamps + (blockIdx.x * 8 + wave) * 4;
+    o[0] = (float)tw_; o[1] = (float)tm_; o[2] = (float)tl_; o[3] = (float)(tend_ - tmain_);
   }
+#endif
+  };
+  if (wave >= 4) body(ic<1>{}); else body(ic<0>{});
 #endif
 }
 
 }  // namespace
 
+static float* g_fused_stamps = nullptr;
+
 extern "C" {
+
+/* measurement hook (not in the header): device buffer for the cycle stamps of DSEE_FUSED_ABL & 32 builds */
+void dsee_fused_set_stamps(float* p) { g_fused_stamps = p; }
 
 /* The fused SPADE / SEAN normalisation forward (see the head of this file).  V2 = dsee_wino43_input_f16x2(cat, amax_cat,
  * v_bound), U2 = dsee_wino43_weights[_table](..., split = 2, amax_u); groups = images with per-image tables, else 1. */
@@ -474,23 +547,16 @@ int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, 
   a.v_bound = v_bound;
   a.add_one = add_one;
   a.slope = slope;
-  {
-    static int stag = -1;   // experiment knob (cycles); default below
-    if (stag < 0) {
-      const char* e = getenv("DSEE_FUSED_STAGGER");
-      stag = e ? atoi(e) : 0;
-    }
-    a.stagger = stag;
-  }
+  a.stamps = g_fused_stamps;
   const long ntile = (T / 64) * (rows / 64);
   DSEE_CHECK_ARG(ntile < 0x7FFFFFFF);
-  const int nsl = K / 32;
-  const size_t lds = (size_t)4 * 2 * nsl * 4096;
-#define DSEE_FUSED(NSL, WS)                                                                                          \
+  const int np = K / 32;
+  const size_t lds = (size_t)2 * np * 16384;   // ring of two positions: 2 * NP pieces of U and of V, 8 KB each
+#define DSEE_FUSED(NP, WS)                                                                                           \
   do {                                                                                                               \
     static bool attr_done = false;                                                                                   \
     if (!attr_done) {                                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_fwd_kernel<NSL, WS>),           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_fwd_kernel<NP, WS>),            \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e != hipSuccess) {                                                                                         \
         dsee_set_error("hipFuncSetAttribute(%zu bytes of LDS): %s", lds, hipGetErrorString(e));                     \
@@ -498,9 +564,9 @@ int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, 
       }                                                                                                              \
       attr_done = true;                                                                                              \
     }                                                                                                                \
-    spade_fused_fwd_kernel<NSL, WS><<<(int)ntile, 256, lds, st>>>(a);                                                \
+    spade_fused_fwd_kernel<NP, WS><<<(int)ntile, 512, lds, st>>>(a);                                                 \
   } while (0)
-  if (nsl == 5) {
+  if (np == 5) {
     if (out_scale) DSEE_FUSED(5, true); else DSEE_FUSED(5, false);
   } else {
     if (out_scale) DSEE_FUSED(4, true); else DSEE_FUSED(4, false);
