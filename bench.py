@@ -19,9 +19,15 @@ Extra objects on the line:
                  deepsee_amd/csrc/gemm_bf16x3.hip) and HBM (algorithmic bytes / summed duration against 8 TB/s); `bound`
                  / `frac` are the one it sits closer to.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
                  (profiles/r02_pmc_traffic.json, provenance in `traffic_source`).
-  spade_fused  — the HBM-bound fused SPADE/SEAN kernel north_star's 70 % target names (output transform of the
-                 gamma/beta GEMM + BN-normalise + modulate + LeakyReLU): bytes it moves / its time against 8 TB/s.
-  f32_mfma_only— the same step with every GEMM kept on v_mfma_f32_32x32x2_f32 (DSEE_F32_MFMA=1 path), rank 0 / N=1.
+  spade_fused  — the fused SPADE/SEAN kernel north_star's 70 % target names (round 3: gamma/beta Winograd GEMM with the
+                 output transform folded in registers + BN-normalise + modulate + LeakyReLU, dsee_spade_fused_fwd): its
+                 algorithmic HBM bytes / its time against 8 TB/s, and the operand bytes it pulls through the L2 -> LDS
+                 path (the resource that bounds it) against the 34.5 TB/s the guide measured for L2.
+  norm_forward — the WHOLE normalisation forward at the top resolution (statistics, embedding, transforms, fused kernel)
+                 on SURVEY 8(d)'s algorithmic bytes (3.49 GB at N = 8, 256^2) against 8 TB/s.
+  host_enqueue_ms_per_step — wall time the Python thread spends inside step() (launch enqueue; no device sync inside).
+  f32_mfma_only / bf16x3_exact — the same step with every GEMM kept on v_mfma_f32_32x32x2_f32 / on the exact 3-term
+                 bf16 split (6 MFMA products), 3 steps each, rank 0 / N=1.
   cpu_baseline — the oracle (CPU restatement of the reference path, oracle/deepsee_oracle.py) timed on this box's
                  host cores: one G+D iteration at bs=1 of the same workload (rank 0, N=1 only).
 """
@@ -42,6 +48,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2516.6   # dense bf16 / fp16 MFMA (same guide)
 HBM_PEAK_GBPS = 8000.0          # HBM3E spec (same guide; ~6.3 TB/s achievable by a float4 copy)
+L2_PEAK_GBPS = 34500.0          # aggregate L2 -> CU bandwidth measured in the same guide (64 B/clk/CU)
 
 CONFIGS = {
     # name: (preset, per-GPU batch, BASELINE.json reference)
@@ -58,7 +65,7 @@ def kernel_peak(name):
         return F16_MFMA_PEAK_TFLOPS
     if "bf16x3" in name:
         return F16_MFMA_PEAK_TFLOPS / 6.0
-    if "f16x2" in name:
+    if "f16x2" in name or "spade_fused" in name:
         return F16_MFMA_PEAK_TFLOPS / 3.0
     return FP32_MFMA_PEAK_TFLOPS
 
@@ -131,11 +138,12 @@ def spawn_ranks(n):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (counters cannot be read live)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(path):
-        rec = json.load(open(path)).get(kernel)
-        if rec:
-            return rec["bytes_per_launch"], "profiles/r02_pmc_traffic.json: %s" % rec["source"]
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            rec = json.load(open(path)).get(kernel)
+            if rec:
+                return rec["bytes_per_launch"], "profiles/%s: %s" % (name, rec["source"])
     return None, None
 
 
@@ -148,6 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-run", action="store_true", help="skip the extra v_mfma_f32-only measurement")
     ap.add_argument("--batch-per-gpu", type=int, default=0)
+    ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--dtype", choices=["fp32", "fp16"], default="fp32",
                     help="fp16: BASELINE configs[2]'s 16-bit arithmetic (one-term scaled-fp16 matrix-core GEMMs, fp32 master "
                          "weights): a separate line")
@@ -167,7 +176,7 @@ def main():
     preset, n_default, ref = CONFIGS[args.config]
     n = args.batch_per_gpu or n_default
     headline = args.config == "independent_8x_256"
-    opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype)
+    opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype, hip_graphs=not args.no_graphs)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)   # (the no-pretrained-VGG notice: synthetic benchmark)
@@ -187,10 +196,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # hipGraphs: every encoder-branch variant runs eagerly once and is captured on its second occurrence; keep warming up
+    # (untimed) until four consecutive steps were pure replays, so that no capture lands in the timed region
+    extra_warmup, quiet = 0, 0
+    while tm.use_graphs and quiet < 4 and extra_warmup < 96:
+        before = tm.graph_stats["eager"] + tm.graph_stats["captured"]
+        step()
+        extra_warmup += 1
+        quiet = quiet + 1 if tm.graph_stats["eager"] + tm.graph_stats["captured"] == before else 0
     fence()
+    replays_before = tm.graph_stats["replayed"]
+    host = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        th = time.perf_counter()
         step()
+        host += time.perf_counter() - th    # launch enqueue only: nothing inside step() waits for the device
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -209,7 +230,8 @@ def main():
         ms = sum(s.elapsed_time(e) for s, e, _ in recs)
         kernels[name] = {"launches": len(recs), "ms": ms, "tflop": sum(f for _, _, f in recs) / 1e12,
                          "gb": ops.PROFILE_BYTES.get(name, 0.0) / 1e9}
-    fused = kernels.pop("spade_modulate_fused", None)
+    fused = kernels.pop("spade_fused_fwd", None) or kernels.pop("spade_modulate_fused", None)
+    norm_fwd = {k: kernels.pop(k) for k in list(kernels) if k.startswith("norm_forward@")}
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     kd = kernels[dom]
     tf = kd["tflop"] / (kd["ms"] / 1e3)
@@ -218,9 +240,8 @@ def main():
     f_mfma, f_hbm = tf / peak, gbps / HBM_PEAK_GBPS
     mfma_ms = sum(k["ms"] for k in kernels.values())
 
-    f32_only = None
-    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run and headline and not ops.HALF:
-        ops.GEMM_SPLIT = False
+    def short_run(note):
+        tm.use_graphs = False     # (the graphs were captured with the default arithmetic)
         step()
         fence()
         t1 = time.perf_counter()
@@ -228,9 +249,19 @@ def main():
             step()
         fence()
         dt = (time.perf_counter() - t1) / 3
+        return {"value": n / dt, "unit": "img/s", "ms_per_step": dt * 1e3, "steps": 3, "note": note}
+
+    f32_only = bf16x3 = None
+    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run and headline and not ops.HALF:
+        ops.GEMM_SPLIT = False
+        f32_only = short_run("same step, Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 instead of split operands")
         ops.GEMM_SPLIT = True
-        f32_only = {"value": n / dt, "unit": "img/s", "ms_per_step": dt * 1e3, "steps": 3,
-                    "note": "same step, Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 instead of split operands"}
+        if ops.GEMM_F16X2:
+            ops.GEMM_F16X2 = False
+            bf16x3 = short_run("same step, every split GEMM on the EXACT 3-term bf16 split (6 MFMA products per fp32 "
+                               "multiply-add; the SPADE/SEAN forward then takes the round-2 GEMM + output-transform path)")
+            ops.GEMM_F16X2 = True
+        tm.use_graphs = not args.no_graphs
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -283,8 +314,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "arithmetic": arithmetic,
-            "config": {"workload": "%s, 19-class masks, bs=%d per GPU, fp32 G+D train step (BASELINE.json %s)"
-                                   % (args.config.replace("_", " "), n, ref),
+            "config": {"workload": "%s, 19-class masks, bs=%d per GPU, %s G+D train step (BASELINE.json %s)"
+                                   % ({"independent_8x_256": "independent 8x 32->256", "guided_8x_256": "guided 8x 32->256",
+                                       "independent_32x_512": "independent 32x 16->512"}[args.config], n, args.dtype, ref),
                        "global_batch": n * world, "parallelism": "dp%d" % world,
                        "losses": losses},
             "roofline": roof,
@@ -297,16 +329,42 @@ def main():
                               "note": "N * F_iter / t_iter with SURVEY 8(d)'s F_iter; exceeds the fp32 MFMA peak because "
                                       "the wide layers run on the fp16 matrix cores in the Winograd domain"}
         out["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # of 288 GB (kept V / M tensors included)
+        out["host_enqueue_ms_per_step"] = host / args.steps * 1e3
+        out["hip_graphs"] = {"enabled": bool(tm.use_graphs), "captured": sorted("/".join(map(str, k)) for k in tm._graphs),
+                             "extra_warmup_steps": extra_warmup,
+                             "timed_half_steps_replayed": tm.graph_stats["replayed"] - replays_before, "timed_half_steps": 2 * args.steps,
+                             "note": "G and D step replayed as hipGraphs (one per encoder-branch variant; first occurrence "
+                                     "eager, second captured); host_enqueue_ms_per_step is the Python time per step"}
         if fused:
             g = fused["gb"] / (fused["ms"] / 1e3)
-            out["spade_fused"] = {"kernel": "wino43_output_modulate (output transform of the gamma/beta GEMM + BN-normalise "
-                                            "+ SPADE/SEAN modulate + LeakyReLU)", "bound": "hbm",
-                                  "launches": fused["launches"], "ms_per_step": fused["ms"],
-                                  "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
-                                  "bytes_note": "bytes the kernel itself moves: M (36/16 x 2C fp32 per pixel) + x read, h "
-                                                "[+ scale] written"}
+            out["spade_fused"] = {
+                "kernel": "spade_fused_fwd (gamma/beta Winograd GEMM, output transform folded in registers, BN-normalise + "
+                          "SPADE/SEAN modulate + LeakyReLU epilogue; the Winograd-domain product never reaches HBM)",
+                "bound": "l2-lds operand path", "launches": fused["launches"], "ms_per_step": fused["ms"],
+                "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
+                "bytes_note": "algorithmic HBM bytes of the kernel: split V (4 B x 36/16 x K per pixel) read, x read, h [+ "
+                              "scale] written",
+                "mfma_tflops_fp32_equiv": fused["tflop"] / (fused["ms"] / 1e3),
+                "mfma_frac": fused["tflop"] / (fused["ms"] / 1e3) / kernel_peak("spade_fused"),
+                "operand_path": {"gb_per_step": ops.PROFILE_OPERAND_GB, "achieved_gbps": ops.PROFILE_OPERAND_GB / (fused["ms"] / 1e3),
+                                 "peak": L2_PEAK_GBPS, "frac": ops.PROFILE_OPERAND_GB / (fused["ms"] / 1e3) / L2_PEAK_GBPS,
+                                 "note": "a 64 tile x 64 row workgroup pulls 2 x 64 x K x 4 B of split operands per transform "
+                                         "position through the L2 -> LDS path (LDS-DMA, 64 B/clk/CU)"}}
+        if norm_fwd:
+            top = max(norm_fwd, key=lambda k: norm_fwd[k]["gb"] / norm_fwd[k]["launches"])
+            v = norm_fwd[top]
+            g = v["gb"] / (v["ms"] / 1e3)
+            out["roofline"]["norm_forward"] = {
+                "what": "whole SPADE/SEAN normalisation forward (statistics + embedding + transforms + fused kernel) at the top "
+                        "resolution, " + top.split("@")[1],
+                "launches": v["launches"], "ms_per_call": v["ms"] / v["launches"],
+                "algorithmic_gb_per_call": v["gb"] / v["launches"], "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": g / HBM_PEAK_GBPS,
+                "bytes_note": "SURVEY 8(d): 4 N R^2 (C [x, statistics pass] + C [x, apply pass] + C [out] + 128 [embedding]) + N R^2"}
         if f32_only:
             out["f32_mfma_only"] = f32_only
+        if bf16x3:
+            out["bf16x3_exact"] = bf16x3
         if world == 1 and not args.no_cpu_baseline and headline and not ops.HALF:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void dsee_set_error(const char* fmt, ...);
+const uint64_t* dsee_rng_epoch();   // device pointer registered with dsee_rng_set_epoch (NULL: epoch 0), capi_core.cpp
 
 #define DSEE_CHECK_ARG(cond)                                                        \
   do {                                                                              \

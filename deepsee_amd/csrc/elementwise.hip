@@ -369,7 +369,8 @@ __global__ void bicubic_down_kernel(const float* __restrict__ x, float* __restri
 
 // ---- Philox4x32-10 counter RNG: dsee_rng.h
 __global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, long total4, uint64_t seed,
-                                                       uint64_t offset, int normal) {
+                                                       uint64_t offset, int normal, const uint64_t* __restrict__ epoch) {
+  if (epoch) offset += *epoch;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     uint32_t r[4];
     philox4(seed, offset + (uint64_t)i, r);
@@ -387,7 +388,9 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, 
 // identical values to dsee_rng_fill(..., seed, offset, normal = 1) followed by the tensor form, without the tensor
 __global__ __launch_bounds__(256) void up_noise_rng_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nw,
                                                                float* __restrict__ y, int N, int H, int W, int C, int ups,
-                                                               uint64_t seed, uint64_t offset) {
+                                                               uint64_t seed, uint64_t offset,
+                                                               const uint64_t* __restrict__ epoch) {
+  if (epoch) offset += *epoch;
   const long total4 = (long)N * H * W * C / 4;
   const int C4 = C / 4, h0 = H >> ups, w0 = W >> ups;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(256) void up_noise_rng_fwd_kernel(const float* __re
 // part[blk][C] = sum_pixels a * eps(seed, offset)   (gradient of the noise weights without the eps tensor)
 __global__ __launch_bounds__(256) void chdot_rng_partial_kernel(const float* __restrict__ a, float* __restrict__ part,
                                                                 long M, int C, int chunk_px, uint64_t seed,
-                                                                uint64_t offset) {
+                                                                uint64_t offset, const uint64_t* __restrict__ epoch) {
+  if (epoch) offset += *epoch;
   __shared__ f32x4 red[256];
   const int tpp = C / 4, ppb = 256 / tpp > 0 ? 256 / tpp : 1;
   const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
@@ -433,7 +437,7 @@ extern "C" {
 int dsee_upsample_noise_rng_fwd(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
                                 uint64_t seed, uint64_t offset, hipStream_t st) {
   DSEE_CHECK_ARG(x && y && noise_w && C % 4 == 0);
-  up_noise_rng_fwd_kernel<<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset);
+  up_noise_rng_fwd_kernel<<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset, dsee_rng_epoch());
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -445,7 +449,7 @@ int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* works
   long cp = (M + 1023) / 1024;
   if (cp < 64) cp = 64;
   const int parts = (int)((M + cp - 1) / cp);
-  chdot_rng_partial_kernel<<<parts, 256, 0, st>>>(a, workspace, M, C, (int)cp, seed, offset);
+  chdot_rng_partial_kernel<<<parts, 256, 0, st>>>(a, workspace, M, C, (int)cp, seed, offset, dsee_rng_epoch());
   DSEE_LAUNCH_CHECK();
   chdot_finalize_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, parts, C, out);
   DSEE_LAUNCH_CHECK();
@@ -599,7 +603,7 @@ int dsee_bicubic_down(const float* x, float* y, int N, int H, int W, int S, int 
 
 int dsee_rng_fill(float* out, long n, uint64_t seed, uint64_t offset, int normal, hipStream_t st) {
   DSEE_CHECK_ARG(out && n % 4 == 0);
-  rng_fill_kernel<<<egrid(n / 4), 256, 0, st>>>(out, n / 4, seed, offset, normal);
+  rng_fill_kernel<<<egrid(n / 4), 256, 0, st>>>(out, n / 4, seed, offset, normal, dsee_rng_epoch());
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

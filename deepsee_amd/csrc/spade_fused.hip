@@ -36,7 +36,7 @@
 #include "dsee_common.h"
 
 // Measurement builds only (tools/exp/build_fused_abl.sh): bit 1 no MFMAs, 2 no fragment reads, 4 no fold / Y update,
-// 8 no look-ahead LDS-DMA, 16 no epilogue.  The shipped library is built without the macro.
+// 8 no look-ahead LDS-DMA, 16 no epilogue, 32 cycle stamps, 64 all look-ahead requests read the same (cache-hot) piece.  The shipped library is built without the macro.
 #ifndef DSEE_FUSED_ABL
 #define DSEE_FUSED_ABL 0
 #endif
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
       constexpr int half = decltype(half_c)::value;
       // look-ahead stage s + 3 = (pos + 1, second half) | (pos + 2, first half), clamped to the last position (the
       // surplus requests of the last three stages re-read valid memory into slots nobody reads any more)
-      const int pl = min(pos + 1 + half, 35);
+      const int pl = (DSEE_FUSED_ABL & 64) ? 0 : min(pos + 1 + half, 35);   // (64: every request re-reads position 0)
       const unsigned ou = base_u + pl * PU, ov = base_v + pl * PV;
       constexpr int LPAR = half ? PAR : 1 - PAR;               // ring half of the look-ahead position
       constexpr int L0 = half ? 0 : NA, L1 = half ? NA : NP;   // its pieces
@@ -373,8 +373,13 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     position(late_c, r * 6, ic<0>{}, [&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       if constexpr (k >= 1) {
-        constexpr int NY = NP - 1, qq = k - 1;
-        y_update(ic<qq * 16 / NY>{}, ic<(qq + 1) * 16 / NY>{}, cf);
+        // rows of At with a zero in column q need no update: q = -1 (first row of positions) none, q = 0 only i = 0
+        constexpr int NY = NP - 1, qq = k - 1, LO = qq * 16 / NY, HI = (qq + 1) * 16 / NY;
+        if constexpr (NP == 5) {          // slice = one output row i = qq
+          if (q > 0 || (q == 0 && qq == 0)) y_update(ic<LO>{}, ic<HI>{}, cf);
+        } else {
+          if (q >= 0) y_update(ic<LO>{}, ic<HI>{}, cf);
+        }
         if constexpr (k == NP - 1) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)

@@ -443,7 +443,14 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const TM* __restrict
                                                             float slope, const float* __restrict__ noise_w,
                                                             uint64_t seed, uint64_t offset,
                                                             const float* __restrict__ res_nw, uint64_t res_seed,
-                                                            uint64_t res_offset, const float* __restrict__ mscale) {
+                                                            uint64_t res_offset, const float* __restrict__ mscale,
+                                                            const uint64_t* __restrict__ epoch) {
+  if constexpr (NOISE) {
+    if (epoch) {
+      offset += *epoch;
+      res_offset += *epoch;
+    }
+  }
   const float ms = mscale ? *mscale : 1.f;
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
@@ -938,7 +945,7 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
 #define DSEE_OUT(NOISE, PTR)                                                                                       \
   wino43_output_kernel<NOISE><<<grid, 256, 0, st>>>(PTR, bias, residual, residual_ld, y, N, H, W, C, act, slope, \
                                                     noise_w, noise_seed, noise_offset, res_noise_w, res_noise_seed, \
-                                                    res_noise_offset, mscale)
+                                                    res_noise_offset, mscale, dsee_rng_epoch())
   if (mscale) {
     if (nz) DSEE_OUT(true, Mb); else DSEE_OUT(false, Mb);
   } else {

@@ -50,7 +50,18 @@ class BaseManager:
 
 
 class TrainerManager(BaseManager):
-    """trainer_manager.py:6-96."""
+    """trainer_manager.py:6-96.
+
+    opt.hip_graphs (default off): a G step and a D step are each captured ONCE per encoder-branch variant as a hipGraph
+    (zero_grad, preprocessing, forward, backward, clipping, fused Adam: ~1 500 kernel launches each) and replayed
+    afterwards -- one host call instead of ~50 ms of Python launch enqueue per step.  What makes that legal: every
+    shape is static; inputs are copied into static buffers; kernel arguments that change per step do not exist (the
+    Philox streams are offset by a DEVICE-side epoch that a captured add advances, learning rates and Adam step counts
+    live in device memory); the two branch coins of the independent variant are a pure function of the forward index, so
+    the variant to replay is known before it runs.  The first occurrence of a variant runs eagerly (it also sizes every
+    workspace), the second is captured, later ones replay.  All graphs share one memory pool: a replay invalidates the
+    activations of the previous one, which is why losses / the generated image are copied out after every replay.
+    Data-parallel runs capture everything up to the backward pass and keep the all-reduce + Adam eager."""
 
     def __init__(self, opt):
         super().__init__(opt, create_model=True)
@@ -60,6 +71,9 @@ class TrainerManager(BaseManager):
         self.generated = None
         self.logs = {}
         self.g_losses, self.d_losses = {}, {}
+        self.use_graphs = bool(getattr(opt, "hip_graphs", False))
+        self._graphs, self._seen, self._static, self._pool = {}, {}, {}, None
+        self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0}
 
     def get_logs(self):
         return {**self.logs, **self.sr_model_on_one_gpu.get_logs()}
@@ -67,24 +81,118 @@ class TrainerManager(BaseManager):
     def preprocess_input(self, data):
         return super().preprocess(data, from_dataloader=True)
 
-    def run_generator_one_step(self, data):
+    # ---- the two steps, eager form (trainer_manager.py:32-61)
+    def _g_step(self, data, pinned=None, opt_step=True):
         self.optimizer_G.zero_grad()
         d = self.preprocess_input(data)
         g_losses, generated = self.sr_model(d, mode="generator")
         g_loss = sum(g_losses.values()).mean()
         g_loss.backward()
-        self.optimizer_G.step(clip=self.opt.gradient_clip)
-        self.g_losses = g_losses
-        self.generated = generated
+        if opt_step:
+            self.optimizer_G.step(clip=self.opt.gradient_clip, pinned=pinned)
+        # (detached: a kept loss would keep this iteration's autograd graph -- and its AccumulateGrad nodes, which are
+        # bound to the stream they were created on -- alive into a later hipGraph capture on another stream)
+        return {k: v.detach() for k, v in g_losses.items()}, generated.detach()
 
-    def run_discriminator_one_step(self, data):
+    def _d_step(self, data, pinned=None, opt_step=True):
         self.optimizer_D.zero_grad()
         d = self.preprocess_input(data)
         d_losses = self.sr_model(d, mode="discriminator")
         d_loss = sum(d_losses.values()).mean()
         d_loss.backward()
-        self.optimizer_D.step(clip=self.opt.gradient_clip)
-        self.d_losses = d_losses
+        if opt_step:
+            self.optimizer_D.step(clip=self.opt.gradient_clip, pinned=pinned)
+        return {k: v.detach() for k, v in d_losses.items()}, None
+
+    def run_generator_one_step(self, data):
+        if self.use_graphs:
+            self.g_losses, self.generated = self._graphed("G", data)
+        else:
+            self.g_losses, self.generated = self._g_step(data)
+
+    def run_discriminator_one_step(self, data):
+        if self.use_graphs:
+            self.d_losses, _ = self._graphed("D", data)
+        else:
+            self.d_losses, _ = self._d_step(data)
+
+    # ---- hipGraph capture / replay
+    def _static_inputs(self, which, data):
+        """Copy the batch into buffers whose addresses the captured kernels know."""
+        st = self._static.setdefault(which, {})
+        out = {}
+        for k, v in data.items():
+            if isinstance(v, torch.Tensor):
+                v = v.cuda(non_blocking=True) if not v.is_cuda else v
+                if k not in st or st[k].shape != v.shape or st[k].dtype != v.dtype:
+                    if k in st:     # a new shape invalidates every captured graph of this step
+                        self._graphs = {g: r for g, r in self._graphs.items() if g[0] != which}
+                        self._seen = {g: c for g, c in self._seen.items() if g[0] != which}
+                    st[k] = torch.empty_like(v)
+                st[k].copy_(v)
+                if hasattr(v, "dsee_layout"):
+                    st[k].dsee_layout = v.dsee_layout
+                out[k] = st[k]
+            elif isinstance(v, ops.Labels):
+                if k not in st or st[k].t.shape != v.t.shape:
+                    st[k] = ops.Labels(torch.empty_like(v.t), v.nc)
+                st[k].t.copy_(v.t)
+                out[k] = st[k]
+            else:
+                out[k] = v
+        return out
+
+    def _graphed(self, which, data):
+        model = self.sr_model_on_one_gpu
+        optim = self.optimizer_G if which == "G" else self.optimizer_D
+        step_fn = self._g_step if which == "G" else self._d_step
+        hook = optim.reduce_hook
+        multi = hook is not None and hook.active
+        noise = model.noise
+        if not hasattr(noise, "step"):            # (a replayed oracle tape: no graphs)
+            return step_fn(data)
+        key = (which,) + tuple(model.encoder_branch(False, step=noise.step + 1))
+        seen = self._seen.get(key, 0)
+        self._seen[key] = seen + 1
+        if seen == 0 or ops.PROFILE is not None:
+            self.graph_stats["eager"] += 1
+            return step_fn(data)                  # first occurrence: eager (sizes every workspace, sets kernel attributes)
+        sd = self._static_inputs(which, data)
+        optim.sync_lr()
+        rec = self._graphs.get(key)
+        if rec is None:
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            pinned = torch.zeros(len(optim.params), dtype=torch.int32).pin_memory()
+            state = (noise.step, noise.offset)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            ops.begin_capture()
+            with torch.cuda.graph(g, pool=self._pool):
+                losses, generated = step_fn(sd, pinned=pinned, opt_step=not multi)
+            ops.begin_capture()                   # (pools created on the capture stream belong to the graph)
+            noise.step, noise.offset = state      # the capture ran the Python side once; the replay below is the real step
+            rec = {"graph": g, "losses": losses, "generated": generated, "pinned": pinned,
+                   "touched": optim.touched.copy(), "full": model.last_encoded_style_is_full,
+                   "noisy": model.last_encoded_style_is_noisy,
+                   "out_losses": {k: torch.empty_like(v) for k, v in losses.items()},
+                   "out_generated": None if generated is None else torch.empty_like(generated)}
+            self._graphs[key] = rec
+            self.graph_stats["captured"] += 1
+        else:
+            self.graph_stats["replayed"] += 1
+        # host-side state a forward leaves behind
+        noise.step += 1
+        model.last_encoded_style_is_full, model.last_encoded_style_is_noisy = rec["full"], rec["noisy"]
+        rec["graph"].replay()
+        if multi:
+            optim.touched[:] = rec["touched"]
+            optim.step(clip=self.opt.gradient_clip)
+        for k, v in rec["losses"].items():
+            rec["out_losses"][k].copy_(v)
+        if rec["generated"] is not None:
+            rec["out_generated"].copy_(rec["generated"])
+        return rec["out_losses"], rec["out_generated"]
 
     def get_latest_losses(self):
         return {**self.g_losses, **self.d_losses}

@@ -83,21 +83,49 @@ class Conv1dP(nn.Module):
 
 
 # ------------------------------------------------------------------------------------ noise / randomness
+_EPOCH = None
+EPOCH_STRIDE = 1 << 36          # stream positions reserved per forward (a forward draws < 2^31 float4s)
+_COIN_TAGS = {"enc_full": 0, "enc_noise": 1}
+
+
+def rng_epoch():
+    """The device-side epoch every Philox stream of the library is offset by (dsee_rng_set_epoch): one int64 in HBM,
+    advanced by a device-side add at the start of every training forward -- so that a captured hipGraph, whose kernel
+    arguments (seed, offset) are frozen, still draws fresh noise on every replay."""
+    global _EPOCH
+    if _EPOCH is None:
+        import ctypes
+        from . import lib as L
+        _EPOCH = torch.zeros(1, dtype=torch.int64, device="cuda")
+        L.lib().dsee_rng_set_epoch(ctypes.c_void_p(_EPOCH.data_ptr()))
+    return _EPOCH
+
+
 class DeviceNoise:
     """Production source of the path's random draws: Philox counter RNG on the device for N(0,1)/U(0,1)
-    tensors; the two per-forward branch coins (sr_model.py:616,643: python ``random`` in the reference) come from
-    this object's OWN ``random.Random(coin_seed)``.  Under data-parallel training every rank must take the same
+    tensors; the two per-forward branch coins (sr_model.py:616,643: python ``random`` in the reference) are a pure
+    function of (coin_seed, forward index, tag).  Under data-parallel training every rank must take the same
     encoder branch (the unused branch gets no gradient): `coin_seed` is therefore the same on all ranks
     (it never depends on the rank, unlike `seed`, which parallel.attach offsets per rank for the noise tensors), and
-    nothing else in the process -- a dataset drawing from the global ``random``, say -- can desynchronise it."""
+    nothing else in the process -- a dataset drawing from the global ``random``, say -- can desynchronise it.  Being
+    stateless, the coins of the NEXT forward can be looked at before it runs (the hipGraph variant to replay is chosen
+    by them, managers.TrainerManager)."""
 
     def __init__(self, seed=0, coin_seed=None):
-        import random as _r
-        self.seed, self.offset = int(seed), 0
-        self._r = _r.Random(int(seed) if coin_seed is None else int(coin_seed))
+        self.seed, self.offset, self.step = int(seed), 0, 0
+        self.coin_seed = int(seed) if coin_seed is None else int(coin_seed)
+        rng_epoch()
 
-    def coin(self, tag):
-        return self._r.random()
+    def begin_step(self):
+        """Start of a training forward: stream offsets restart at 0 and the device epoch advances."""
+        self.step += 1
+        self.offset = 0
+        rng_epoch().add_(EPOCH_STRIDE)
+
+    def coin(self, tag, step=None):
+        import random as _r
+        s = self.step if step is None else int(step)
+        return _r.Random((self.coin_seed * 2654435761 + s) * 4 + _COIN_TAGS[tag]).random()
 
     def _fill(self, shape_nhwc, normal):
         n = 1
@@ -130,6 +158,9 @@ class ReplayNoise:
 
     def __init__(self, tape):
         self.tape, self.pos = list(tape), 0
+
+    def begin_step(self):
+        pass
 
     def _next(self, kind, tag):
         k, t, v = self.tape[self.pos]

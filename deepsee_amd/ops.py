@@ -24,6 +24,7 @@ _scratch = {}
 # PROFILE[kernel_name] = [(start_event, end_event, algorithmic_flops), ...]; PROFILE_BYTES[kernel_name] = algorithmic HBM bytes
 PROFILE = None
 PROFILE_BYTES = {}
+PROFILE_OPERAND_GB = 0.0   # operand bytes the fused SPADE kernel pulls through the L2 -> LDS path in the profiled step
 
 
 def _variant(geom, modulate=False):
@@ -354,6 +355,12 @@ def amax_slot():
     t = st[0][st[1]:st[1] + AMAX_FLOATS]
     st[1] += AMAX_FLOATS
     return t
+
+
+def begin_capture():
+    """Called right before a hipGraph capture starts: the zero-fill of an operand-maximum pool must be part of the graph
+    that uses its slots (a replay has to find them zeroed), so pools handed out earlier are dropped."""
+    _amax_pools.clear()
 
 
 def weight_amax(*tensors):
@@ -1054,8 +1061,15 @@ class SeanNormTable(torch.autograd.Function):
     gradient rows.  `table` None -> SPADE (128 channels); `w2a` None -> PureSEAN (one-hot only)."""
 
     @staticmethod
-    def forward(ctx, x, w_sh, b_sh, w2a, table, b2, running_mean, running_var, labels, shift, training, add_one,
-                grad_sink=None, cat_ups=0):
+    def forward(ctx, x, *args):
+        n, h, w, c = x.shape
+        # bench.py: the whole forward on SURVEY 8(d)'s algorithmic bytes (x twice, out, the 128-channel embedding, labels)
+        with _timed("norm_forward@%dx%d" % (h, w), 0.0, 4.0 * n * h * w * (3 * c + NHIDDEN) + n * h * w):
+            return SeanNormTable._forward(ctx, x, *args)
+
+    @staticmethod
+    def _forward(ctx, x, w_sh, b_sh, w2a, table, b2, running_mean, running_var, labels, shift, training, add_one,
+                 grad_sink=None, cat_ups=0):
         """`cat_ups` > 0 (the reference's max_fm_size cap, normalization.py:188-190 / 275-277): the 128-channel
         embedding is computed at the capped resolution (`shift` refers to IT) and nearest-upsampled by 2^cat_ups to x's
         resolution before the gamma/beta convolution; there is no style table then."""
@@ -1107,6 +1121,9 @@ class SeanNormTable(torch.autograd.Function):
                 L.call("wino43_weights_table", w2a if has_a else None, tb, u, n, rows, ca, 2, ua)
             else:
                 u, ua = _wino_u(w2a, rows, ca, False, rows, kp, 2)
+            if PROFILE is not None:
+                global PROFILE_OPERAND_GB
+                PROFILE_OPERAND_GB += (t // 64) * (rows // 64) * 36 * 2 * 64 * ld * 4.0 / 1e9
             with _timed("spade_fused_fwd", 2.0 * 36 * t * ld * rows,
                         4.0 * 36 * t * ld + 4.0 * n * h * w * c * (3 if need_scale else 2)):
                 L.call("spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,

@@ -115,25 +115,38 @@ class FlatAdam:
         L.call("adam_step_range", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.desc_dev, self.block_tensor,
                b0, b1 - b0, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale), float(clip))
 
-    def step(self, clip=-1.0):
-        hook = self.reduce_hook
-        multi = hook is not None and hook.active
-        # learning rates: uploaded only when a param_group's lr changed (TrainerManager.update_learning_rate)
+    def sync_lr(self):
+        """Upload the learning rates if a param_group's lr changed (TrainerManager.update_learning_rate).  A blocking
+        host-to-device copy: never inside a hipGraph capture (managers call it before capturing / replaying)."""
         lrs = [self.param_groups[g]["lr"] for g in self.group_of]
         if lrs != self._lr_sent:
             self._dlr.copy_(torch.tensor(lrs, dtype=torch.float32))
             self._lr_sent = lrs
+
+    def step(self, clip=-1.0, pinned=None):
+        """`pinned`: a pinned int32 staging tensor owned by the caller -- required while a hipGraph is being captured (the
+        captured host-to-device copy reads it on every replay, so it must hold this step's `touched` flags for good)."""
+        hook = self.reduce_hook
+        multi = hook is not None and hook.active
+        capturing = self.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.sync_lr()
         # active flags: this rank's `touched`, MAX over the ranks (a rank whose encoder coin differed would otherwise
         # update a different parameter subset with a different step count -- parameters would silently diverge)
-        slot = self._ring[self._ring_pos]
-        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-        if slot[1] is not None:
-            slot[1].synchronize()
-        slot[0].copy_(torch.from_numpy(self.touched))
-        self._active_dev.copy_(slot[0], non_blocking=True)
-        if self._active_dev.is_cuda:
-            slot[1] = torch.cuda.Event()
-            slot[1].record()
+        if capturing:
+            assert pinned is not None and not multi, "graph capture: caller-owned staging buffer, single rank"
+            pinned.copy_(torch.from_numpy(self.touched))
+            self._active_dev.copy_(pinned, non_blocking=True)
+        else:
+            slot = self._ring[self._ring_pos]
+            self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+            if slot[1] is not None:
+                slot[1].synchronize()
+            slot[0].copy_(torch.from_numpy(self.touched))
+            self._active_dev.copy_(slot[0], non_blocking=True)
+            if self._active_dev.is_cuda:
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
         if multi:
             hook.reduce_active(self._active_dev)
         self._d32[:, _ACTIVE].copy_(self._active_dev)

@@ -25,6 +25,7 @@ DEFAULTS = dict(
     sync_bn=False,           # data-parallel: BatchNorm statistics over the global batch; default sync-free
     sync_bn_clamp=True,      # ... with the reference DP branch's clamp(var, eps) (batchnorm.py:145) instead of var + eps
     preprocess_mode="resize_and_crop", no_flip=False,
+    hip_graphs=False,        # capture the G and the D step as hipGraphs (one per encoder-branch variant) and replay them
     precision="fp32",        # "fp16": one-term scaled-fp16 matrix-core GEMMs + fp16 Winograd-domain products (BASELINE configs[2])
 )
 

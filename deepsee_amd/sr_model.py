@@ -124,6 +124,8 @@ class SRModel(nn.Module):
 
     def forward(self, data, mode, **kwargs):
         d = self._native(data)
+        if mode in ("generator", "discriminator"):
+            self.noise.begin_step()     # fresh Philox positions / branch coins for this forward
         if mode == "generator":
             g_loss, generated = self.compute_generator_loss(d)
             self.logs["image/downsized"] = d["image_lr"]
@@ -316,27 +318,35 @@ class SRModel(nn.Module):
         fake = self.netSR(d["image_lr"], d["labels"], style, self.noise, self.training)
         return fake, style
 
+    def encoder_branch(self, no_noise=False, step=None):
+        """('full' | 'mini', no_noise) of a forward (sr_model.py:601-650): the guided variant always encodes the full
+        image; the independent variant flips two coins per training forward.  `step`: look at the coins of that forward
+        index instead of the current one (DeviceNoise only)."""
+        opt = self.opt
+        kw = {} if step is None else {"step": step}
+        if self.model_variant == "guided":
+            return "full", no_noise
+        full = opt.full_style_image or (self.training and self.noise.coin("enc_full", **kw) < 0.5)
+        if not no_noise:
+            no_noise = self.noise.coin("enc_noise", **kw) < 0.5
+        return ("full" if full else "mini"), no_noise
+
     def encode_style(self, d, no_noise):
         opt = self.opt
         labels, img = d["labels"], d["image_lr"]
+        mode, nn_ = self.encoder_branch(no_noise)
         if self.model_variant == "guided":
-            mode = "full"
             if opt.guiding_style_image:
                 labels, img = d["guiding_labels"], d["guiding_image"]
             else:
                 img = d["image_hr"]
             return self.netE(img, labels, mode, no_noise, self.noise, self.training)
-        if opt.full_style_image or (self.training and self.noise.coin("enc_full") < 0.5):
-            mode = "full"
-            self.last_encoded_style_is_full = True
+        self.last_encoded_style_is_full = mode == "full"
+        if mode == "full":
             if opt.guiding_style_image:
                 labels, img = d["guiding_labels"], d["guiding_image"]
             else:
                 img = d["image_hr"]
-        else:
-            mode = "mini"
-            self.last_encoded_style_is_full = False
         if not no_noise:
-            no_noise = self.noise.coin("enc_noise") < 0.5
-            self.last_encoded_style_is_noisy = not no_noise
-        return self.netE(img, labels, mode, no_noise, self.noise, self.training)
+            self.last_encoded_style_is_noisy = not nn_
+        return self.netE(img, labels, mode, nn_, self.noise, self.training)

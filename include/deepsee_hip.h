@@ -367,6 +367,12 @@ int dsee_build_d_input(const uint8_t* lab, const float* img, float* out, long pi
 int dsee_extract_image_grad(const float* din, float* dimg, long pixels, int L, int Cs, int img_cs, hipStream_t stream);
 /* Philox4x32-10 fill: N(0,1) (normal != 0) or U[0,1) — replaces tensor.normal_() / torch.rand_like on device */
 int dsee_rng_fill(float* out, long n, uint64_t seed, uint64_t offset, int normal, hipStream_t stream);
+/* Device-side epoch added to the offset of EVERY Philox stream drawn by the library (dsee_rng_fill,
+ * dsee_upsample_noise_rng_fwd, dsee_channel_dot_rng, the noise forms of dsee_wino43_output): epoch_dev points to one
+ * uint64 in device memory (NULL: epoch 0).  The (seed, offset) arguments travel by value and are frozen in a captured
+ * hipGraph; advancing *epoch_dev between replays (a device-side add, itself part of the graph) gives every replayed
+ * training step fresh NoiseInjection draws (normalization.py:299-304 draws a new tensor per forward). */
+int dsee_rng_set_epoch(const uint64_t* epoch_dev);
 
 /* ------------------------------------------------------------------ losses (loss.py:68-79,114-119; sr_model.py:529-539)
  * mode 0: L1(a,b)  1: -x (hinge, generator)  2: -min(x-1,0) (D, real)  3: -min(-x-1,0) (D, fake).

@@ -460,3 +460,80 @@ def test_pipelined_gemms_with_poisoned_lds(mode):
             if first is None:
                 first = out
             assert torch.equal(out, first)
+
+
+@pytest.mark.parametrize("n,h,c,per_image,with_scale", [(2, 32, 64, True, True), (1, 64, 128, False, True),
+                                                        (3, 32, 128, True, False), (2, 64, 64, False, False)])
+def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale):
+    """dsee_spade_fused_fwd (round 3: gamma/beta Winograd GEMM with the output transform folded in registers, normalise +
+    modulate + LeakyReLU epilogue; normalization.py:107-120, 167-213) through the C ABI against a float64 restatement
+    of the same layer on the CPU: direct 3x3 convolution over [embedding | one-hot] with shared weights and per-image
+    table weights, packed gamma/beta row order, BN with given statistics, modulate, LeakyReLU(0.2).  Operands: the
+    pre-split fp16x2 transform of dsee_wino43_input_f16x2 (scale from max|cat| x 100, known before the transform) and
+    dsee_wino43_weights[_table].  Every launch runs on NaN-poisoned LDS (a fragment read of a ring slot whose LDS-DMA
+    has not landed would show) and must be bit-identical to the first."""
+    from deepsee_amd import lib as L, ops
+    g = torch.Generator().manual_seed(100 * n + h + c)
+    K, rows, ca = (160 if per_image else 128), 2 * c, 128
+    cat = torch.rand(n, h, h, K, generator=g)
+    if per_image:
+        cat[..., ca:] = 0.0
+        lab = torch.randint(0, 19, (n, h, h), generator=g)
+        cat[..., ca:].scatter_(3, lab[..., None], 1.0)                      # one-hot label channels
+    x = torch.randn(n, h, h, c, generator=g) * 3 + 0.5
+    mean, invstd = torch.randn(c, generator=g) * 0.3, torch.rand(c, generator=g) + 0.5
+    wg, wb = torch.randn(c, ca, 3, 3, generator=g) * 0.05, torch.randn(c, ca, 3, 3, generator=g) * 0.05
+    bg, bb = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    idx, prow = ops.packed_perm(c, "cpu")
+    assert prow == rows
+    w2a = torch.cat([wg, wb, torch.zeros(1, ca, 3, 3)]).index_select(0, idx).contiguous()
+    b2 = torch.cat([bg, bb, torch.zeros(1)]).index_select(0, idx).contiguous()
+    tg = tb = None
+    if per_image:
+        tg, tb = torch.randn(n, 9, c, 19, generator=g) * 0.05, torch.randn(n, 9, c, 19, generator=g) * 0.05
+        t2 = torch.cat([tg, tb, torch.zeros(n, 9, 1, 19)], 2).index_select(2, idx)
+        table = F.pad(t2, (0, 13)).contiguous()                               # [N, 9, rows, 32]
+    # ---- float64 reference
+    catn = cat.double().permute(0, 3, 1, 2)
+    gam = F.conv2d(catn[:, :ca], wg.double(), bg.double(), padding=1)
+    bet = F.conv2d(catn[:, :ca], wb.double(), bb.double(), padding=1)
+    if per_image:
+        for i in range(n):
+            w_g = tg[i].double().permute(1, 2, 0).reshape(c, 19, 3, 3)        # [c][r][tap]
+            w_b = tb[i].double().permute(1, 2, 0).reshape(c, 19, 3, 3)
+            gam[i:i + 1] += F.conv2d(catn[i:i + 1, ca:ca + 19], w_g, None, padding=1)
+            bet[i:i + 1] += F.conv2d(catn[i:i + 1, ca:ca + 19], w_b, None, padding=1)
+    add_one = 1.0
+    xh = (x.double().permute(0, 3, 1, 2) - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    sc_ref = gam + add_one
+    ref = F.leaky_relu(xh * sc_ref + bet, 0.2)
+    # ---- HIP
+    catd, xd = cat.cuda(), x.cuda()
+    t = n * (h // 4) ** 2
+    ac = ops.tensor_amax(catd)
+    v2 = ops._i16(36 * t * K * 2)
+    L.call("wino43_input_f16x2", catd, v2, n, h, h, K, ac, 100.0)
+    if per_image:
+        ua = ops.weight_amax(w2a.cuda(), table.cuda())
+        u = ops._i16(36 * n * rows * K * 2)
+        L.call("wino43_weights_table", w2a.cuda(), table.cuda(), u, n, rows, ca, 2, ua)
+    else:
+        u, ua = ops._wino_u(w2a.cuda(), rows, ca, False, rows, K, 2)
+    out, sc = torch.empty_like(xd), (torch.empty_like(xd) if with_scale else None)
+    sink = torch.zeros(1, device="cuda")
+    first = None
+    for it in range(4):
+        L.call("selftest_lds_poison", sink)
+        out.fill_(float("nan"))
+        L.call("spade_fused_fwd", v2, u, ac, 100.0, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), out, sc, n, h, h, c, rows, K,
+               n if per_image else 1, add_one, 0.2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), "NaN from a poisoned LDS stage (launch %d)" % it
+        if first is None:
+            first = out.clone()
+        assert torch.equal(out, first)
+    e_h = rel(out.cpu().double().permute(0, 3, 1, 2), ref)
+    print("fused SPADE forward N=%d %dx%d C=%d K=%d vs float64: h %.1e" % (n, h, h, c, K, e_h))
+    assert e_h < 2e-6
+    if with_scale:
+        assert rel(sc.cpu().double().permute(0, 3, 1, 2), sc_ref) < 2e-6
