@@ -143,6 +143,21 @@ int dsee_spectral_norm_bwd(const float* dw, const float* w_sn, const float* u, c
 namespace {
 
 // One block-range per tensor: blocks [first_block, first_block + nblocks) work on tensor t.
+// grad_flat[offset(t) ..] <- the gradient tensor of parameter t (zeros where autograd delivered none), active[t] <- 0 / 1:
+// ONE launch instead of one AccumulateGrad add per parameter
+__global__ __launch_bounds__(256) void grad_gather_kernel(const int64_t* __restrict__ ptrs,
+                                                          const dsee_adam_tensor* __restrict__ tensors,
+                                                          const int* __restrict__ block_tensor,
+                                                          float* __restrict__ grad_flat, int* __restrict__ active) {
+  const int blk = (int)blockIdx.x;
+  const int t = block_tensor[blk];
+  const dsee_adam_tensor d = tensors[t];
+  const float* src = reinterpret_cast<const float*>(ptrs[t]);
+  const long b0 = (long)(blk - d.first_block) * 1024;
+  if (blk == d.first_block && threadIdx.x == 0) active[t] = src != nullptr;
+  for (long i = b0 + threadIdx.x; i < d.numel && i < b0 + 1024; i += 256) grad_flat[d.offset + i] = src ? src[i] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                    const dsee_adam_tensor* __restrict__ tensors,
@@ -188,6 +203,18 @@ int dsee_adam_step_range(float* param, const float* grad, float* exp_avg, float*
   DSEE_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && tensors && block_tensor && first_block >= 0 && nblocks > 0);
   adam_kernel<<<nblocks, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, tensors, block_tensor, first_block, beta1,
                                        beta2, eps, grad_scale, clip);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* Collects the per-parameter gradient tensors autograd produced (grad_ptrs[t]: device address of a contiguous fp32
+ * tensor of tensors[t].numel elements, or 0 = "p.grad is None") into the flat gradient buffer the all-reduce and the
+ * Adam kernel work on, and writes the per-tensor active flags.  Replaces the ~290 AccumulateGrad `grad += new` kernels of
+ * a backward pass into persistent .grad views (and the zero fill of the flat buffer) by one launch. */
+int dsee_grad_gather(const int64_t* grad_ptrs, const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks,
+                     float* grad_flat, int* active, hipStream_t st) {
+  DSEE_CHECK_ARG(grad_ptrs && tensors && block_tensor && grad_flat && active && nblocks > 0);
+  grad_gather_kernel<<<nblocks, 256, 0, st>>>(grad_ptrs, tensors, block_tensor, grad_flat, active);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -163,7 +163,7 @@ class TrainerManager(BaseManager):
         if rec is None:
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
-            pinned = torch.zeros(len(optim.params), dtype=torch.int32).pin_memory()
+            pinned = optim.staging()
             state = (noise.step, noise.offset)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -173,7 +173,7 @@ class TrainerManager(BaseManager):
             ops.begin_capture()                   # (pools created on the capture stream belong to the graph)
             noise.step, noise.offset = state      # the capture ran the Python side once; the replay below is the real step
             rec = {"graph": g, "losses": losses, "generated": generated, "pinned": pinned,
-                   "touched": optim.touched.copy(), "full": model.last_encoded_style_is_full,
+                   "grads": [p.grad for p in optim.params], "full": model.last_encoded_style_is_full,
                    "noisy": model.last_encoded_style_is_noisy,
                    "out_losses": {k: torch.empty_like(v) for k, v in losses.items()},
                    "out_generated": None if generated is None else torch.empty_like(generated)}
@@ -186,7 +186,8 @@ class TrainerManager(BaseManager):
         model.last_encoded_style_is_full, model.last_encoded_style_is_noisy = rec["full"], rec["noisy"]
         rec["graph"].replay()
         if multi:
-            optim.touched[:] = rec["touched"]
+            for p, g in zip(optim.params, rec["grads"]):   # the gradient tensors this graph writes (static addresses)
+                p.grad = g
             optim.step(clip=self.opt.gradient_clip)
         for k, v in rec["losses"].items():
             rec["out_losses"][k].copy_(v)

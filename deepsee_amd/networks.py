@@ -83,22 +83,9 @@ class Conv1dP(nn.Module):
 
 
 # ------------------------------------------------------------------------------------ noise / randomness
-_EPOCH = None
 EPOCH_STRIDE = 1 << 36          # stream positions reserved per forward (a forward draws < 2^31 float4s)
 _COIN_TAGS = {"enc_full": 0, "enc_noise": 1}
-
-
-def rng_epoch():
-    """The device-side epoch every Philox stream of the library is offset by (dsee_rng_set_epoch): one int64 in HBM,
-    advanced by a device-side add at the start of every training forward -- so that a captured hipGraph, whose kernel
-    arguments (seed, offset) are frozen, still draws fresh noise on every replay."""
-    global _EPOCH
-    if _EPOCH is None:
-        import ctypes
-        from . import lib as L
-        _EPOCH = torch.zeros(1, dtype=torch.int64, device="cuda")
-        L.lib().dsee_rng_set_epoch(ctypes.c_void_p(_EPOCH.data_ptr()))
-    return _EPOCH
+_REGISTERED_EPOCH = None
 
 
 class DeviceNoise:
@@ -114,13 +101,28 @@ class DeviceNoise:
     def __init__(self, seed=0, coin_seed=None):
         self.seed, self.offset, self.step = int(seed), 0, 0
         self.coin_seed = int(seed) if coin_seed is None else int(coin_seed)
-        rng_epoch()
+        # The device-side epoch every Philox stream drawn through this object is offset by (dsee_rng_set_epoch): one int64
+        # in HBM, advanced by a device-side add at the start of every training forward -- so that a captured hipGraph,
+        # whose kernel arguments (seed, offset) are frozen, still draws fresh noise on every replay.
+        self.epoch = torch.zeros(1, dtype=torch.int64, device="cuda")
+        self._register()
+
+    def _register(self):
+        """Tell the library which epoch the kernels launched from now on read (a captured graph keeps the pointer it was
+        captured with).  The registered tensor is pinned by a module-level reference: the library must never be left
+        with the address of freed memory."""
+        import ctypes
+        from . import lib as L
+        global _REGISTERED_EPOCH
+        _REGISTERED_EPOCH = self.epoch
+        L.lib().dsee_rng_set_epoch(ctypes.c_void_p(self.epoch.data_ptr()))
 
     def begin_step(self):
         """Start of a training forward: stream offsets restart at 0 and the device epoch advances."""
         self.step += 1
         self.offset = 0
-        rng_epoch().add_(EPOCH_STRIDE)
+        self.epoch.add_(EPOCH_STRIDE)
+        self._register()
 
     def coin(self, tag, step=None):
         import random as _r
@@ -222,27 +224,24 @@ class SpadeNorm(nn.Module):
         if capped or (self.kind != "spade" and (h * w) % 128 != 0):
             return self._forward_dense(x, labels, style, training, fm, grad_sink)
         shift = labels.shift_for(h)
-        # ---- table path: one fused autograd node per norm
+        # ---- table path: one fused autograd node per norm; its packed / blended weight set comes from ONE kernel
+        P = ops.SeanPack.apply
         if self.kind == "spade":
-            w2a, b2 = ops.pack_gamma_beta(self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_gamma.bias,
-                                          self.mlp_beta.bias)
+            w2a, _, b2 = P(0, self.mlp_gamma.weight, self.mlp_beta.weight, None, None, self.mlp_gamma.bias,
+                           self.mlp_beta.bias, None, None, None, None)
             return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, None, b2, st.running_mean, st.running_var,
                                            labels, shift, training, 1.0, grad_sink)
-        zero_b = torch.zeros_like(self.mlp_style_gamma.bias)
         if self.kind == "sean":
-            wg, wb = torch.sigmoid(self.alpha_gamma), torch.sigmoid(self.alpha_beta)
-            bg = (1.0 - wg) * self.mlp_gamma.bias + wg * self.mlp_style_gamma.bias
-            bb = (1.0 - wb) * self.mlp_beta.bias + wb * self.mlp_style_beta.bias
-            w2a, b2 = ops.pack_gamma_beta((1.0 - wg) * self.mlp_gamma.weight, (1.0 - wb) * self.mlp_beta.weight, bg, bb)
-            ws2, _ = ops.pack_gamma_beta(wg * self.mlp_style_gamma.weight, wb * self.mlp_style_beta.weight, zero_b,
-                                         zero_b)
-            table = ops.style_table(style, ws2)
+            w2a, wst, b2 = P(1, self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_style_gamma.weight,
+                             self.mlp_style_beta.weight, self.mlp_gamma.bias, self.mlp_beta.bias,
+                             self.mlp_style_gamma.bias, self.mlp_style_beta.bias, self.alpha_gamma, self.alpha_beta)
+            table = ops.style_table_packed(style, wst, b2.shape[0])
             return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, table, b2, st.running_mean, st.running_var,
                                            labels, shift, training, 1.0, grad_sink)
         # puresean: out = xhat * gamma_s + beta_s
-        ws2, b2 = ops.pack_gamma_beta(self.mlp_style_gamma.weight, self.mlp_style_beta.weight,
-                                      self.mlp_style_gamma.bias, self.mlp_style_beta.bias)
-        table = ops.style_table(style, ws2)
+        _, wst, b2 = P(2, None, None, self.mlp_style_gamma.weight, self.mlp_style_beta.weight, None, None,
+                       self.mlp_style_gamma.bias, self.mlp_style_beta.bias, None, None)
+        table = ops.style_table_packed(style, wst, b2.shape[0])
         return ops.SeanNormTable.apply(x, None, None, None, table, b2, st.running_mean, st.running_var, labels, shift,
                                        training, 0.0, grad_sink)
 
@@ -255,16 +254,14 @@ class SpadeNorm(nn.Module):
         sh, st = self.mlp_shared._modules["0"], self.param_free_norm
         ups = int(round(math.log2(h // fm)))
         if self.kind == "sean":
-            wg, wb = torch.sigmoid(self.alpha_gamma), torch.sigmoid(self.alpha_beta)
-            wgam = (1.0 - wg) * self.mlp_gamma.weight + wg * self.mlp_style_gamma.weight
-            wbet = (1.0 - wb) * self.mlp_beta.weight + wb * self.mlp_style_beta.weight
-            bg = (1.0 - wg) * self.mlp_gamma.bias + wg * self.mlp_style_gamma.bias
-            bb = (1.0 - wb) * self.mlp_beta.bias + wb * self.mlp_style_beta.bias
-            w2a, b2 = ops.pack_gamma_beta(wgam, wbet, bg, bb)
+            w2a, _, b2 = ops.SeanPack.apply(3, self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_style_gamma.weight,
+                                            self.mlp_style_beta.weight, self.mlp_gamma.bias, self.mlp_beta.bias,
+                                            self.mlp_style_gamma.bias, self.mlp_style_beta.bias, self.alpha_gamma,
+                                            self.alpha_beta)
             add_one = 1.0
         else:  # puresean: out = xhat * gamma_s + beta_s
-            w2a, b2 = ops.pack_gamma_beta(self.mlp_style_gamma.weight, self.mlp_style_beta.weight,
-                                          self.mlp_style_gamma.bias, self.mlp_style_beta.bias)
+            w2a, _, b2 = ops.SeanPack.apply(0, self.mlp_style_gamma.weight, self.mlp_style_beta.weight, None, None,
+                                            self.mlp_style_gamma.bias, self.mlp_style_beta.bias, None, None, None, None)
             add_one = 0.0
         return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, None, b2, st.running_mean, st.running_var, labels,
                                        labels.shift_for(fm), training, add_one, grad_sink, ups)

@@ -926,6 +926,73 @@ def pack_gamma_beta(w_gamma, w_beta, b_gamma, b_beta):
     return w2, b2
 
 
+class SeanPack(torch.autograd.Function):
+    """(w2a, wst, b2) = the packed, sigmoid-blended weight set of one SPADE / SEAN / PureSEAN norm layer in ONE kernel
+    (dsee_sean_pack_fwd; backward: one kernel + a 2-thread finalize), replacing ~30 + ~45 ATen launches of sigmoid,
+    blends, cat, index_select, zeros, permute and their autograd backwards per layer and pass.
+    mode 0 spade (w2a, b2) | 1 sean (w2a, wst, b2) | 2 puresean (wst, b2) | 3 sean above max_fm_size (folded w2a, b2).
+    wst [(tap, row)][S] is the B operand of the style-table GEMM."""
+
+    @staticmethod
+    def forward(ctx, mode, wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab):
+        ref = wg if wg is not None else wsg
+        c = ref.shape[0]
+        k = wg.shape[1] if wg is not None else 0
+        sdim = wsg.shape[1] if wsg is not None else 0
+        rows = L.lib().dsee_sean_pack_rows(c)
+        w2a = new(rows, k, 3, 3) if mode != 2 else None
+        wst = new(9 * rows, sdim) if mode in (1, 2) else None
+        b2 = new(rows)
+        L.call("sean_pack_fwd", wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab, int(mode), c, k, sdim, w2a, wst, b2)
+        ctx.mode, ctx.dims = int(mode), (c, k, sdim, rows)
+        ctx.save_for_backward(wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab)
+        return w2a, wst, b2
+
+    @staticmethod
+    def backward(ctx, dw2a, dwst, db2):
+        wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab = ctx.saved_tensors
+        c, k, sdim, rows = ctx.dims
+        mode = ctx.mode
+        if mode != 2 and dw2a is None:
+            dw2a = torch.zeros(rows, k, 3, 3, dtype=torch.float32, device=db2.device if db2 is not None else wg.device)
+        if mode in (1, 2) and dwst is None:
+            dwst = torch.zeros(9 * rows, sdim, dtype=torch.float32, device=wsg.device)
+        outs = [torch.empty_like(t) if (t is not None and ctx.needs_input_grad[i + 1]) else None
+                for i, t in enumerate((wg, wb, wsg, wsb, bg, bb, bsg, bsb))]
+        dalpha = new(2) if (mode in (1, 3) and (ctx.needs_input_grad[9] or ctx.needs_input_grad[10])) else None
+        ws = scratch(L.lib().dsee_sean_pack_bwd_workspace(), "seanpack")
+        L.call("sean_pack_bwd", wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab, mode, c, k, sdim,
+               None if dw2a is None else dw2a.contiguous(), None if dwst is None else dwst.contiguous(),
+               None if db2 is None else db2.contiguous(), *outs, dalpha, ws)
+        da = (dalpha[0:1], dalpha[1:2]) if dalpha is not None else (None, None)
+        return (None, *outs, da[0] if ctx.needs_input_grad[9] else None, da[1] if ctx.needs_input_grad[10] else None)
+
+
+class TableLayout(torch.autograd.Function):
+    """[N*L][9*rows] (the style-table GEMM's result) <-> the [N][9][rows][32] per-image table the kernels read."""
+
+    @staticmethod
+    def forward(ctx, t, n, nc, rows):
+        ctx.dims = (n, nc, rows)
+        out = new(n, 9, rows, 32)
+        L.call("style_table_layout", t.contiguous(), out, n, nc, rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, nc, rows = ctx.dims
+        dt = new(n * nc, 9 * rows)
+        L.call("style_table_layout_bwd", dout.contiguous(), dt, n, nc, rows)
+        return dt, None, None, None
+
+
+def style_table_packed(style, wst, rows):
+    """T[n][tap][row][r(32)] = sum_s wst[tap*rows + row][s] * style[n][r][s]: one GEMM on parameter-sized operands
+    (rocBLAS through torch.matmul, see _style_gemm) + the layout kernel."""
+    n, nc, s = style.shape
+    return TableLayout.apply(_style_gemm(style.reshape(n * nc, s), wst), n, nc, rows)
+
+
 class SyncBNConfig:
     """SyncBN-over-RCCL option: BatchNorm statistics over the GLOBAL batch of all data-parallel ranks, the
     reference's DataParallel branch (sync_batchnorm/batchnorm.py:70-145) with its clamp(var, eps).  Off by default:

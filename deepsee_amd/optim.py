@@ -21,9 +21,11 @@ BLOCK = 1024                        # elements per Adam block (a block never str
 
 
 class FlatAdam:
-    """Owns flat param / grad / exp_avg / exp_avg_sq buffers; every nn.Parameter handed in is re-pointed to a view
-    of the flat param buffer and gets a persistent .grad view of the flat grad buffer (autograd accumulates in
-    place), so the RCCL all-reduce and the Adam kernel see one contiguous tensor each."""
+    """Owns flat param / grad / exp_avg / exp_avg_sq buffers; every nn.Parameter handed in is re-pointed to a view of
+    the flat param buffer.  Gradients: zero_grad() sets every .grad to None, so autograd's AccumulateGrad simply keeps
+    the tensor a backward pass produced (no `grad += new` kernel per parameter); step() hands the addresses of those
+    tensors to ONE gather kernel (dsee_grad_gather) that fills the flat gradient buffer -- zeros for parameters without a
+    gradient -- and the per-tensor active flags, so the RCCL all-reduce and the Adam kernel see one contiguous tensor."""
 
     def __init__(self, groups, betas=(0.0, 0.9), eps=1e-8):
         # groups: list of dict(params=[(name, Parameter)], lr=float)
@@ -52,7 +54,7 @@ class FlatAdam:
             n = p.numel()
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
-            p.grad = self.grad[o:o + n].view(p.shape)
+            p.grad = None
             nb = (n + BLOCK - 1) // BLOCK
             desc[i] = (o, n, fb, 0, self.param_groups[self.group_of[i]]["lr"], 1)
             blocks += [i] * nb
@@ -68,31 +70,30 @@ class FlatAdam:
         self.offsets = offs
         self.reduce_hook = None   # parallel.GradAllReduce, installed by parallel.attach
         # "p.grad is None -> skipped" (torch.optim.Adam after zero_grad(set_to_none=True)): a tensor is active in
-        # a step iff autograd delivered a gradient for it since the last zero_grad().
+        # a step iff autograd delivered a gradient for it since the last zero_grad().  `touched`: host copy of that.
         self.touched = np.zeros(len(self.params), dtype=np.int32)
-        # ring of pinned staging buffers for the asynchronous upload of `touched` (the host runs ahead of the GPU: a
-        # buffer is reused only after the copy that read it has executed)
+        # ring of pinned staging buffers for the asynchronous upload of the gradient addresses (the host runs ahead of
+        # the GPU: a buffer is reused only after the copy that read it has executed)
         self._ring, self._ring_pos = [], 0
         for _ in range(4 if dev.type == "cuda" else 1):
-            t = torch.zeros(len(self.params), dtype=torch.int32)
+            t = torch.zeros(len(self.params), dtype=torch.int64)
             self._ring.append([t.pin_memory() if dev.type == "cuda" else t, None])
+        self._ptr_dev = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
         self._active_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self._ranges = {}
-        for i, p in enumerate(self.params):
-            p.register_hook(self._make_hook(i))
+        self._held = None
 
-    def _make_hook(self, i):
-        def hook(grad):
-            self.touched[i] = 1
-            return None
-        return hook
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
 
-    def zero_grad(self, set_to_none=False):
-        self.grad.zero_()
-        self.touched[:] = 0
-        for p, o in zip(self.params, self.offsets):  # restore views if something replaced .grad
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+    def staging(self):
+        """A pinned staging tensor for step(pinned=...) (hipGraph capture: allocate BEFORE the capture starts)."""
+        t = torch.zeros(len(self.params), dtype=torch.int64)
+        return t.pin_memory() if self.flat.is_cuda else t
+
+    def _gather(self):
+        L.call("grad_gather", self._ptr_dev, self.desc_dev, self.block_tensor, self.nblocks, self.grad, self._active_dev)
 
     def chunk_ranges(self, chunk_elems):
         """[(first_block, end_block, lo, hi)]: block ranges of about chunk_elems elements whose element spans [lo, hi)
@@ -133,20 +134,30 @@ class FlatAdam:
             self.sync_lr()
         # active flags: this rank's `touched`, MAX over the ranks (a rank whose encoder coin differed would otherwise
         # update a different parameter subset with a different step count -- parameters would silently diverge)
+        grads = []
+        for p in self.params:
+            g = p.grad
+            if g is not None and not (g.is_contiguous() and g.dtype == torch.float32):
+                g = g.contiguous().float()
+            grads.append(g)
+        ptrs = np.array([0 if g is None else g.data_ptr() for g in grads], dtype=np.int64)
+        self.touched = (ptrs != 0).astype(np.int32)
         if capturing:
             assert pinned is not None and not multi, "graph capture: caller-owned staging buffer, single rank"
-            pinned.copy_(torch.from_numpy(self.touched))
-            self._active_dev.copy_(pinned, non_blocking=True)
+            pinned.copy_(torch.from_numpy(ptrs))
+            self._ptr_dev.copy_(pinned, non_blocking=True)
         else:
             slot = self._ring[self._ring_pos]
             self._ring_pos = (self._ring_pos + 1) % len(self._ring)
             if slot[1] is not None:
                 slot[1].synchronize()
-            slot[0].copy_(torch.from_numpy(self.touched))
-            self._active_dev.copy_(slot[0], non_blocking=True)
-            if self._active_dev.is_cuda:
+            slot[0].copy_(torch.from_numpy(ptrs))
+            self._ptr_dev.copy_(slot[0], non_blocking=True)
+            if self._ptr_dev.is_cuda:
                 slot[1] = torch.cuda.Event()
                 slot[1].record()
+        self._gather()           # flat gradient + active flags in one launch
+        self._held = grads       # (the gradient tensors stay referenced until the next step has been enqueued)
         if multi:
             hook.reduce_active(self._active_dev)
         self._d32[:, _ACTIVE].copy_(self._active_dev)

@@ -385,6 +385,27 @@ int dsee_loss_fwd_bwd(int mode, const float* a, const float* b, float* grad, lon
 int dsee_loss_bwd(int mode, const float* a, const float* b, float* grad, long rows, int ld, int valid_c, float weight,
                   const float* upstream, hipStream_t stream);
 
+/* ------------------------------------------------------------------ SPADE / SEAN parameter packing
+ * normalization.py:208-213 (SEAN), :119 (SPADE), :286 (PureSEAN): scale / offset are linear in the gamma / beta / style
+ * convolutions, so the layer's GEMM reads ONE blended weight set in the packed [32 gamma rows | 32 beta rows] order.
+ * These kernels replace the ~30 (forward) + ~45 (backward) ATen launches that sigmoid / blend / cat / index_select / pad
+ * cost per norm layer and pass (deepsee_amd/csrc/sean_pack.hip).  rows = dsee_sean_pack_rows(C). */
+int dsee_sean_pack_rows(int C);
+int dsee_sean_pack_fwd(const float* w_gamma, const float* w_beta, const float* ws_gamma, const float* ws_beta,
+                       const float* b_gamma, const float* b_beta, const float* bs_gamma, const float* bs_beta,
+                       const float* alpha_gamma, const float* alpha_beta, int mode, int C, int K, int S, float* w2a,
+                       float* wst, float* b2, hipStream_t stream);
+size_t dsee_sean_pack_bwd_workspace(void);
+int dsee_sean_pack_bwd(const float* w_gamma, const float* w_beta, const float* ws_gamma, const float* ws_beta,
+                       const float* b_gamma, const float* b_beta, const float* bs_gamma, const float* bs_beta,
+                       const float* alpha_gamma, const float* alpha_beta, int mode, int C, int K, int S,
+                       const float* dw2a, const float* dwst, const float* db2, float* dw_gamma, float* dw_beta,
+                       float* dws_gamma, float* dws_beta, float* db_gamma, float* db_beta, float* dbs_gamma,
+                       float* dbs_beta, float* dalpha, float* workspace, hipStream_t stream);
+/* per-image style tables (normalization.py:182-185 as a table, SURVEY B-7): [N*L][9*rows] GEMM result <-> [N][9][rows][32] */
+int dsee_style_table_layout(const float* t, float* table, int N, int L, int rows, hipStream_t stream);
+int dsee_style_table_layout_bwd(const float* dtable, float* dt, int N, int L, int rows, hipStream_t stream);
+
 /* ------------------------------------------------------------------ spectral norm + Adam */
 int dsee_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* sigma, float* w_sn, int R, int K,
                            int power_iter, float eps, float* scratch, hipStream_t stream);
@@ -402,6 +423,12 @@ typedef struct dsee_adam_tensor {
 int dsee_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks, float beta1, float beta2,
                    float eps, float grad_scale, float clip, hipStream_t stream);
+/* grad_flat <- the per-parameter gradient tensors of a backward pass (grad_ptrs[t] = device address of parameter t's
+ * contiguous fp32 gradient, 0 = none: zeros), active[t] <- grad_ptrs[t] != 0.  One launch in place of the per-parameter
+ * AccumulateGrad additions into persistent .grad views (torch's counterpart of optimizer.zero_grad + backward,
+ * trainer_manager.py:33,37). */
+int dsee_grad_gather(const int64_t* grad_ptrs, const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks,
+                     float* grad_flat, int* active, hipStream_t stream);
 /* the same on blocks [first_block, first_block + nblocks) only: one launch per all-reduced gradient chunk, so the
  * update of chunk k overlaps the RCCL all-reduce of chunk k+1 (replaces the reduce-to-GPU0 + optimizer.step() of
  * torch.nn.DataParallel, sync_batchnorm/replicate.py:50-94, trainer_manager.py:37-42) */

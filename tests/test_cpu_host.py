@@ -244,6 +244,13 @@ def _flat_adam_worker(rank, world, port, q):
     class CpuAdam(FlatAdam):
         launches = 0
 
+        def _gather(self):      # torch emulation of dsee_grad_gather: flat gradient (zeros without a gradient) + active flags
+            self.grad.zero_()
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                if p.grad is not None:
+                    self.grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                self._active_dev[i] = 0 if p.grad is None else 1
+
         def _launch(self, b0, b1, grad_scale, clip):
             CpuAdam.launches += 1
             desc = np.frombuffer(self.desc_dev.numpy().tobytes(), dtype=ADAM_DT)

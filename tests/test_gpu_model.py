@@ -39,6 +39,12 @@ def load_oracle_state(tm, orc):
     tm.sr_model.load_states({net: {k: v.detach().clone() for k, v in orc.S[net].items()} for net in ("SR", "D", "E")})
 
 
+def _grad_or_zero(p):
+    """FlatAdam.zero_grad() sets .grad to None (torch's set_to_none): a parameter the backward pass did not reach has no
+    gradient tensor -- the reference's zero-filled .grad."""
+    return (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().clone()
+
+
 def run_case(over, seed, iters=1, sync_before_d=True):
     """One or more G+D iterations on both sides.  `sync_before_d`: after the G step the oracle's post-step state is
     loaded into the HIP model, so the D step starts from IDENTICAL weights/buffers on both sides and its gradients can
@@ -72,7 +78,7 @@ def run_case(over, seed, iters=1, sync_before_d=True):
         tm.sr_model.noise = N.ReplayNoise(ctl.tape[start:])
         tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
         torch.cuda.synchronize()
-        hg = {nm: p.grad.detach().cpu().clone() for nm, p in zip(tm.optimizer_G.names, tm.optimizer_G.params)}
+        hg = {nm: _grad_or_zero(p) for nm, p in zip(tm.optimizer_G.names, tm.optimizer_G.params)}
         touched_g = {nm for nm, t in zip(tm.optimizer_G.names, tm.optimizer_G.touched) if t}
         hgl = {k: float(v) for k, v in tm.g_losses.items()}
         hfake = tm.get_latest_generated().detach().cpu()
@@ -82,7 +88,7 @@ def run_case(over, seed, iters=1, sync_before_d=True):
             load_oracle_state(tm, orc_state_after_g)
         tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
         torch.cuda.synchronize()
-        hd = {nm: p.grad.detach().cpu().clone() for nm, p in zip(tm.optimizer_D.names, tm.optimizer_D.params)}
+        hd = {nm: _grad_or_zero(p) for nm, p in zip(tm.optimizer_D.names, tm.optimizer_D.params)}
         hdl = {k: float(v) for k, v in tm.d_losses.items()}
         assert tm.sr_model.noise.pos == len(tm.sr_model.noise.tape)
         out.append(dict(gl={k: float(v.detach()) for k, v in gl.items()}, fake=fake.detach(), ggrads=ggrads,
@@ -239,7 +245,7 @@ def smooth_loss_errors(over, seed=555, plain_f32=True):
         loss = loss + (ops.ToNCHW.apply(t, R.shape[1]) * R.cuda()).sum() / R[0].numel() ** 0.5
     loss.backward()
     torch.cuda.synchronize()
-    hg = {nm: p.grad.detach().cpu() for o in (tm.optimizer_G, tm.optimizer_D) for nm, p in zip(o.names, o.params)}
+    hg = {nm: _grad_or_zero(p) for o in (tm.optimizer_G, tm.optimizer_D) for nm, p in zip(o.names, o.params)}
     assert abs(float(loss) - loss64) <= 1e-4 * abs(loss64)
     dev = rel(ops.to_nchw(fake.detach(), 3).cpu(), fake64)
     assert dev < 1e-5

@@ -12,7 +12,6 @@ import bench
 
 
 def run(graphs, iters, over):
-    N._EPOCH = None if N._EPOCH is None else N._EPOCH.zero_()
     opt = make_opt("independent_8x_256", seed=3, hip_graphs=graphs, **over)
     tm = TrainerManager(opt)
     batch = bench.synthetic_batch(opt, opt.batchSize, 77, torch.device("cuda"))
