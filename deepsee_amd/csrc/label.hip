@@ -21,34 +21,46 @@ __global__ __launch_bounds__(256) void onehot_conv_fwd_kernel(const uint8_t* __r
                                                               const float* __restrict__ wt,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int N, int H, int W, int shift, int R, int Rw, int L,
-                                                              int Co, int out_ld, int coff, int relu) {
+                                                              int Co, int out_ld, int coff, int relu, int onehot_coff,
+                                                              float* __restrict__ amax, float amax_floor) {
   const int tpp = Co / 4, ppb = 256 / tpp;
   const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
-  if (s >= ppb) return;
   const long M = (long)N * R * Rw;
-  const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (long m = (long)blockIdx.x * ppb + s; m < M; m += (long)gridDim.x * ppb) {
-    const int w = (int)(m % Rw);
-    const long t = m / Rw;
-    const int h = (int)(t % R), n = (int)(t / R);
-    f32x4 acc = b;
+  float vmax = amax_floor;   // max |out| for the fp16 operand scale of the consumer (the one-hot channels contribute 1)
+  if (s < ppb) {
+    const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long m = (long)blockIdx.x * ppb + s; m < M; m += (long)gridDim.x * ppb) {
+      const int w = (int)(m % Rw);
+      const long t = m / Rw;
+      const int h = (int)(t % R), n = (int)(t / R);
+      f32x4 acc = b;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+      for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int hh = h + dy, ww = w + dx;
-        if (hh >= 0 && hh < R && ww >= 0 && ww < Rw) {
-          const int r = lab_at(lab, n, H, W, shift, hh, ww);
-          const int tap = (dy + 1) * 3 + (dx + 1);
-          acc += *reinterpret_cast<const f32x4*>(wt + ((size_t)tap * L + r) * Co + q * 4);
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int hh = h + dy, ww = w + dx;
+          if (hh >= 0 && hh < R && ww >= 0 && ww < Rw) {
+            const int r = lab_at(lab, n, H, W, shift, hh, ww);
+            const int tap = (dy + 1) * 3 + (dx + 1);
+            acc += *reinterpret_cast<const f32x4*>(wt + ((size_t)tap * L + r) * Co + q * 4);
+          }
         }
-      }
-    if (relu) {
+      if (relu) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+        for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(out + m * out_ld + coff + q * 4) = acc;
+      vmax = fmaxf(vmax, dsee_absmax4(acc));
+      if (onehot_coff >= 0 && q < 8) {   // the 32 one-hot label channels of the same pixel (dsee_label_onehot)
+        const int r = lab_at(lab, n, H, W, shift, h, w);
+        f32x4 oh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) oh[k] = (q * 4 + k == r) ? 1.f : 0.f;
+        *reinterpret_cast<f32x4*>(out + m * out_ld + onehot_coff + q * 4) = oh;
+      }
     }
-    *reinterpret_cast<f32x4*>(out + m * out_ld + coff + q * 4) = acc;
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);   // (amax is block-uniform; every thread arrives here)
 }
 
 __global__ void onehot_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int L) {
@@ -233,13 +245,16 @@ int dsee_onehot_conv3x3_pack(const float* w_oihw, float* table, int Co, int L, h
 }
 
 int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float* bias, float* out, int N, int H, int W,
-                            int shift, int L, int Co, int out_ld, int coff, int relu, hipStream_t st) {
+                            int shift, int L, int Co, int out_ld, int coff, int relu, int onehot_coff, float* amax,
+                            float amax_floor, hipStream_t st) {
   DSEE_CHECK_ARG(lab && table && out && Co % 4 == 0 && Co <= 1024 && out_ld % 4 == 0 && coff % 4 == 0);
+  DSEE_CHECK_ARG(onehot_coff < 0 || (onehot_coff % 4 == 0 && out_ld >= onehot_coff + 32 && Co >= 32 && L <= 32));
   const int R = H >> shift, Rw = W >> shift;
   const long M = (long)N * R * Rw;
   const int ppb = 256 / (Co / 4);
   onehot_conv_fwd_kernel<<<(int)min(4096L, (M + ppb - 1) / ppb), 256, 0, st>>>(lab, table, bias, out, N, H, W, shift, R,
-                                                                                Rw, L, Co, out_ld, coff, relu);
+                                                                                Rw, L, Co, out_ld, coff, relu, onehot_coff, amax,
+                                                                                amax_floor);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

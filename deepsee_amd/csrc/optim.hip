@@ -140,6 +140,123 @@ int dsee_spectral_norm_bwd(const float* dw, const float* w_sn, const float* u, c
 
 }  // extern "C"
 
+// ---------------------------------------------------------------- spectral norm of ALL layers of a network in five launches
+// The per-layer form above costs 6 launches (+ 2 clones of u, v for the backward pass) per layer and forward: 42 layers x
+// 2 generator / encoder / discriminator passes per training iteration = ~650 launches of sub-microsecond work.  Here the
+// stages run once per network with a device-resident layer table (like the Adam descriptors): every block looks its
+// (layer, piece) up in a small work list.  Same arithmetic and the same summation order per layer as the per-layer
+// kernels (bit-identical results).
+namespace {
+
+__global__ __launch_bounds__(256) void sng_wt_u_kernel(const dsee_sn_layer* __restrict__ layers, const int2* __restrict__ work,
+                                                       float* __restrict__ scratch) {
+  __shared__ float sv[8][32];
+  const int2 wk = work[blockIdx.x];
+  const dsee_sn_layer L = layers[wk.x];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int j = wk.y * 32 + cl;
+  float acc = 0.f;
+  if (j < L.K)
+    for (int i = lane; i < L.R; i += 8) acc += L.w_orig[(size_t)i * L.K + j] * L.u[i];
+  sv[lane][cl] = acc;
+  __syncthreads();
+  if (lane == 0 && j < L.K) {
+    for (int l = 1; l < 8; ++l) acc += sv[l][cl];
+    scratch[L.scratch_off + j] = acc;
+  }
+}
+
+// one block per layer: v = tK / max(||tK||, eps)
+__global__ __launch_bounds__(256) void sng_norm_v_kernel(const dsee_sn_layer* __restrict__ layers,
+                                                         const float* __restrict__ scratch, float eps) {
+  const dsee_sn_layer L = layers[blockIdx.x];
+  const float* in = scratch + L.scratch_off;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < L.K; i += 256) acc += in[i] * in[i];
+  acc = block_sum256(acc);
+  const float d = fmaxf(sqrtf(acc), eps);
+  for (int i = threadIdx.x; i < L.K; i += 256) L.v[i] = in[i] / d;
+}
+
+__global__ __launch_bounds__(256) void sng_w_v_kernel(const dsee_sn_layer* __restrict__ layers, const int2* __restrict__ work,
+                                                      float* __restrict__ scratch) {
+  const int2 wk = work[blockIdx.x];
+  const dsee_sn_layer L = layers[wk.x];
+  const int i = wk.y;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < L.K; j += 256) acc += L.w_orig[(size_t)i * L.K + j] * L.v[j];
+  acc = block_sum256(acc);
+  if (threadIdx.x == 0) scratch[L.scratch_off + L.K + i] = acc;
+}
+
+// one block per layer: (power_iter) u = tR / max(||tR||, eps); sigma = <u, tR>; copies of u, v for the backward pass
+__global__ __launch_bounds__(256) void sng_norm_u_sigma_kernel(const dsee_sn_layer* __restrict__ layers,
+                                                               const float* __restrict__ scratch, float eps,
+                                                               int power_iter, float* __restrict__ sigma,
+                                                               float* __restrict__ saved) {
+  const dsee_sn_layer L = layers[blockIdx.x];
+  const float* tR = scratch + L.scratch_off + L.K;
+  if (power_iter) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < L.R; i += 256) acc += tR[i] * tR[i];
+    acc = block_sum256(acc);
+    const float d = fmaxf(sqrtf(acc), eps);
+    for (int i = threadIdx.x; i < L.R; i += 256) L.u[i] = tR[i] / d;
+    __syncthreads();
+  }
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < L.R; i += 256) dot += L.u[i] * tR[i];
+  dot = block_sum256(dot);
+  if (threadIdx.x == 0) sigma[blockIdx.x] = dot;
+  for (int i = threadIdx.x; i < L.R; i += 256) saved[L.saved_off + i] = L.u[i];
+  for (int i = threadIdx.x; i < L.K; i += 256) saved[L.saved_off + L.R + i] = L.v[i];
+}
+
+// w_sn = w_orig / sigma for a 4096-element piece of a layer; max |w_sn| of the layer for the fp16 operand scales
+__global__ __launch_bounds__(256) void sng_scale_kernel(const dsee_sn_layer* __restrict__ layers, const int2* __restrict__ work,
+                                                        const float* __restrict__ sigma, float* __restrict__ out,
+                                                        float* __restrict__ amax) {
+  const int2 wk = work[blockIdx.x];
+  const dsee_sn_layer L = layers[wk.x];
+  const float s = sigma[wk.x];
+  const long n = (long)L.R * L.K, i0 = (long)wk.y * 4096;
+  float vmax = 0.f;
+  for (long i = i0 + threadIdx.x; i < n && i < i0 + 4096; i += 256) {
+    const float v = L.w_orig[i] / s;
+    out[L.out_off + i] = v;
+    vmax = fmaxf(vmax, fabsf(v));
+  }
+  dsee_block_atomic_absmax(amax + (size_t)wk.x * (DSEE_AMAX_LINES * DSEE_AMAX_STRIDE), vmax);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Spectral normalisation of all `nlayers` layers of a network (torch.nn.utils.spectral_norm hook semantics, call sites
+ * architecture.py:40-44, normalization.py:29-30; SURVEY B-2) in five launches.  layers: device table; work_k / work_r /
+ * work_e: device work lists of (layer, 32-column block) / (layer, row) / (layer, 4096-element piece) with n_k / n_r / n_e
+ * entries; scratch: sum(R + K) floats at the layers' scratch_off; sigma [nlayers]; out: flat w_sn at the layers' out_off;
+ * saved: copies of the (updated) u, v at saved_off for dsee_spectral_norm_bwd; amax: [nlayers][2048] floats, zeroed by
+ * the caller, receives max |w_sn| per layer in the 64-line form of dsee_absmax. */
+int dsee_spectral_norm_group_fwd(const dsee_sn_layer* layers, int nlayers, const int* work_k, int n_k, const int* work_r,
+                                 int n_r, const int* work_e, int n_e, int power_iter, float eps, float* scratch,
+                                 float* sigma, float* out, float* saved, float* amax, hipStream_t st) {
+  DSEE_CHECK_ARG(layers && nlayers > 0 && work_k && work_r && work_e && n_k > 0 && n_r > 0 && n_e > 0);
+  DSEE_CHECK_ARG(scratch && sigma && out && saved && amax);
+  if (power_iter) {
+    sng_wt_u_kernel<<<n_k, 256, 0, st>>>(layers, reinterpret_cast<const int2*>(work_k), scratch);
+    sng_norm_v_kernel<<<nlayers, 256, 0, st>>>(layers, scratch, eps);
+  }
+  sng_w_v_kernel<<<n_r, 256, 0, st>>>(layers, reinterpret_cast<const int2*>(work_r), scratch);
+  sng_norm_u_sigma_kernel<<<nlayers, 256, 0, st>>>(layers, scratch, eps, power_iter, sigma, saved);
+  sng_scale_kernel<<<n_e, 256, 0, st>>>(layers, reinterpret_cast<const int2*>(work_e), sigma, out, amax);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+}  // extern "C"
+
 namespace {
 
 // One block-range per tensor: blocks [first_block, first_block + nblocks) work on tensor t.

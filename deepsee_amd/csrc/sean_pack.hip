@@ -31,7 +31,8 @@ __device__ __forceinline__ void unpack_row(int p, int& is_beta, int& ch) {
 }
 
 __global__ __launch_bounds__(256) void sean_pack_fwd_kernel(PackArgs a, float* __restrict__ w2a, float* __restrict__ wst,
-                                                            float* __restrict__ b2) {
+                                                            float* __restrict__ b2, float* __restrict__ amax) {
+  float vmax = 0.f;   // max |w2a| for the fp16 operand scale of the gamma/beta GEMM
   const float sg = a.mode == 1 || a.mode == 3 ? sigm(a.ag) : 0.f, sb = a.mode == 1 || a.mode == 3 ? sigm(a.ab) : 0.f;
   const long na = w2a ? (long)a.rows * a.K : 0, ns = wst ? (long)a.rows * a.S : 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < na + ns + a.rows;
@@ -59,7 +60,10 @@ __global__ __launch_bounds__(256) void sean_pack_fwd_kernel(PackArgs a, float* _
         }
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) w2a[i * 9 + t] = v[t];
+      for (int t = 0; t < 9; ++t) {
+        w2a[i * 9 + t] = v[t];
+        vmax = fmaxf(vmax, fabsf(v[t]));
+      }
     } else if (i < na + ns) {   // (row, s): 9 taps of the style weights, written (tap, row)-major
       const long j = i - na;
       const int p = (int)(j / a.S), sidx = (int)(j % a.S);
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(256) void sean_pack_fwd_kernel(PackArgs a, float* _
       b2[p] = v;
     }
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);   // (amax is block-uniform)
 }
 
 // gradients of the parameters + per-block partial sums of the two alpha gradients
@@ -177,19 +182,30 @@ __global__ __launch_bounds__(256) void sean_pack_bwd_kernel(PackArgs a, const fl
   }
 }
 
-__global__ void sean_alpha_finalize_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ ag,
-                                           const float* __restrict__ ab, float* __restrict__ dalpha) {
-  if (threadIdx.x < 2) {
-    float s = 0.f;
-    for (int i = 0; i < nblk; ++i) s += partial[2 * i + threadIdx.x];
-    const float sg = sigm(threadIdx.x ? ab : ag);
-    dalpha[threadIdx.x] = s * sg * (1.f - sg);
+__global__ __launch_bounds__(256) void sean_alpha_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                                  const float* __restrict__ ag, const float* __restrict__ ab,
+                                                                  float* __restrict__ dalpha) {
+  // 2 x 128 threads, fixed summation order (deterministic)
+  __shared__ float red[256];
+  const int which = threadIdx.x >> 7, t = threadIdx.x & 127;
+  float s = 0.f;
+  for (int i = t; i < nblk; i += 128) s += partial[2 * i + which];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (t < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float sg = sigm(which ? ab : ag);
+    dalpha[which] = red[threadIdx.x] * sg * (1.f - sg);
   }
 }
 
 // out[n][tap][row][r < 32] = r < L ? t[n*L + r][tap*rows + row] : 0      (and the adjoint)
 __global__ __launch_bounds__(256) void table_layout_kernel(const float* __restrict__ t, float* __restrict__ out, int N,
-                                                           int L, int rows, int bwd) {
+                                                           int L, int rows, int bwd, float* __restrict__ amax) {
+  float vmax = 0.f;
   const long total = (long)N * 9 * rows * 32;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i & 31);
@@ -198,11 +214,14 @@ __global__ __launch_bounds__(256) void table_layout_kernel(const float* __restri
     const long q2 = q / rows;
     const int tap = (int)(q2 % 9), n = (int)(q2 / 9);
     if (!bwd) {
-      out[i] = r < L ? t[((size_t)n * L + r) * (9 * rows) + tap * rows + row] : 0.f;
+      const float v = r < L ? t[((size_t)n * L + r) * (9 * rows) + tap * rows + row] : 0.f;
+      out[i] = v;
+      vmax = fmaxf(vmax, fabsf(v));
     } else if (r < L) {
       out[((size_t)n * L + r) * (9 * rows) + tap * rows + row] = t[i];
     }
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);
 }
 
 inline int pgrid(long n) { return (int)min(4096L, (n + 255) / 256); }
@@ -213,13 +232,15 @@ extern "C" {
 
 int dsee_sean_pack_rows(int C) { return (C + 63) / 64 * 128; }
 
-/* Packed, blended weights of one SPADE / SEAN / PureSEAN norm layer (see the head of this file).  mode 0 spade (w2a, b2),
+/* Packed, blended weights of one SPADE / SEAN / PureSEAN norm layer (see the head of this file).  amax_w2a (optional, zeroed
+ * by the caller, 64-line form of dsee_absmax) receives max |w2a|; dsee_style_table_layout's `amax` max |table|: pointing both
+ * at one slot gives the operand bound of dsee_wino43_weights_table without a pass of its own.  mode 0 spade (w2a, b2),
  * 1 sean (w2a, wst, b2; alpha_* = the two learnable scalars BEFORE the sigmoid), 2 puresean (wst, b2), 3 sean above
  * max_fm_size (w2a = (1 - s) W + s W_style, b2; needs K == S).  Unused pointers NULL. */
 int dsee_sean_pack_fwd(const float* w_gamma, const float* w_beta, const float* ws_gamma, const float* ws_beta,
                        const float* b_gamma, const float* b_beta, const float* bs_gamma, const float* bs_beta,
                        const float* alpha_gamma, const float* alpha_beta, int mode, int C, int K, int S, float* w2a,
-                       float* wst, float* b2, hipStream_t st) {
+                       float* wst, float* b2, float* amax_w2a, hipStream_t st) {
   DSEE_CHECK_ARG(mode >= 0 && mode <= 3 && C > 0 && b2);
   DSEE_CHECK_ARG(mode == 2 || (w_gamma && w_beta && b_gamma && b_beta && w2a && K > 0));
   DSEE_CHECK_ARG(mode == 0 || (ws_gamma && ws_beta && bs_gamma && bs_beta && S > 0));
@@ -231,7 +252,7 @@ int dsee_sean_pack_fwd(const float* w_gamma, const float* w_beta, const float* w
   float* wo = mode == 2 ? nullptr : w2a;
   float* so = (mode == 1 || mode == 2) ? wst : nullptr;
   const long n = (wo ? (long)a.rows * K : 0) + (so ? (long)a.rows * S : 0) + a.rows;
-  sean_pack_fwd_kernel<<<pgrid(n), 256, 0, st>>>(a, wo, so, b2);
+  sean_pack_fwd_kernel<<<pgrid(n), 256, 0, st>>>(a, wo, so, b2, amax_w2a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -258,22 +279,22 @@ int dsee_sean_pack_bwd(const float* w_gamma, const float* w_beta, const float* w
   sean_pack_bwd_kernel<<<grid, 256, 0, st>>>(a, ga, gs, db2, dw_gamma, dw_beta, dws_gamma, dws_beta, db_gamma, db_beta,
                                              dbs_gamma, dbs_beta, workspace);
   if (dalpha && (mode == 1 || mode == 3))
-    sean_alpha_finalize_kernel<<<1, 64, 0, st>>>(workspace, grid, alpha_gamma, alpha_beta, dalpha);
+    sean_alpha_finalize_kernel<<<1, 256, 0, st>>>(workspace, grid, alpha_gamma, alpha_beta, dalpha);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
 /* table [N][9][rows][32] <- t [N*L][9*rows] (the style-table GEMM's result, L <= 32 regions; columns >= L zero) */
-int dsee_style_table_layout(const float* t, float* table, int N, int L, int rows, hipStream_t st) {
+int dsee_style_table_layout(const float* t, float* table, int N, int L, int rows, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(t && table && N > 0 && L > 0 && L <= 32 && rows > 0);
-  table_layout_kernel<<<pgrid((long)N * 9 * rows * 32), 256, 0, st>>>(t, table, N, L, rows, 0);
+  table_layout_kernel<<<pgrid((long)N * 9 * rows * 32), 256, 0, st>>>(t, table, N, L, rows, 0, amax);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
 int dsee_style_table_layout_bwd(const float* dtable, float* dt, int N, int L, int rows, hipStream_t st) {
   DSEE_CHECK_ARG(dtable && dt && N > 0 && L > 0 && L <= 32 && rows > 0);
-  table_layout_kernel<<<pgrid((long)N * 9 * rows * 32), 256, 0, st>>>(dtable, dt, N, L, rows, 1);
+  table_layout_kernel<<<pgrid((long)N * 9 * rows * 32), 256, 0, st>>>(dtable, dt, N, L, rows, 1, nullptr);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

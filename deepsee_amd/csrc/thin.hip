@@ -142,6 +142,65 @@ __global__ void thin_wgrad_reduce_kernel(const float* __restrict__ partial, floa
 
 constexpr int NWALK = 1024;  // row-segment walkers of the weight gradient (4 per block)
 
+// ---- the same layer as a 1x1 GEMM + a 9-point gather (round 3): z[p][tap*Cout + co] = sum_c x[p][c] w[co][c][tap] is a
+// plain [pixels x C] x [C x 9 Cout] product (fp32 MFMA implicit-GEMM kernel, reads x ONCE at HBM rate), and
+// out[p][co] = act(bias[co] + sum_tap z[p + d(tap)][tap*Cout + co]) with zero padding outside the image.
+__global__ __launch_bounds__(256) void thin_gather_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                              float* __restrict__ out, int N, int H, int W, int ldz,
+                                                              int Cout, int act, float slope) {
+  const long total = (long)N * H * W;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(p % W);
+    const long r = p / W;
+    const int y = (int)(r % H);
+    float acc[TCO] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float* zp = z + (p + (long)(t / 3 - 1) * W + (t % 3 - 1)) * ldz + t * Cout;
+#pragma unroll
+        for (int co = 0; co < TCO; ++co)
+          if (co < Cout) acc[co] += zp[co];
+      }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int co = 0; co < TCO; ++co) o[co] = co < Cout ? dsee_act(acc[co] + (bias ? bias[co] : 0.f), act, slope) : 0.f;
+    *reinterpret_cast<f32x4*>(out + p * TCO) = o;
+  }
+}
+
+// dz[p][tap*Cout + co] = g[p - d(tap)][co], g = dout * act'(out)   (every element of dz is written, padding columns 0)
+__global__ __launch_bounds__(256) void thin_gather_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                              float* __restrict__ dz, int N, int H, int W, int ldz, int Cout,
+                                                              int act, float slope) {
+  const long total = (long)N * H * W;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(p % W);
+    const long r = p / W;
+    const int y = (int)(r % H);
+    float* zp = dz + p * ldz;
+    for (int k = 9 * Cout; k < ldz; ++k) zp[k] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const long q = p - (long)(t / 3 - 1) * W - (t % 3 - 1);
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        g = *reinterpret_cast<const f32x4*>(dout + q * TCO);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(out + q * TCO);
+#pragma unroll
+        for (int co = 0; co < TCO; ++co) g[co] *= dsee_act_grad_from_out(o[co], act, slope);
+      }
+#pragma unroll
+      for (int co = 0; co < TCO; ++co)
+        if (co < Cout) zp[t * Cout + co] = g[co];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -153,6 +212,27 @@ int dsee_conv3x3_thin_fwd(const float* x, const float* w_oihw, const float* bias
   DSEE_CHECK_ARG(x && w_oihw && out && Cout >= 1 && Cout <= TCO && C % 256 == 0 && C <= 1024 && W % 64 == 0);
   thin_fwd_kernel<<<(unsigned)((long)N * H * (W / 64)), C / 4, 0, st>>>(x, w_oihw, bias, out, N, H, W, C, Cout, act,
                                                                        slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* to-RGB convolution (sr.py:94-95) as GEMM + gather: out [N,H,W,4] = act(bias + 9-point gather of z [N,H,W,ldz]), z = the
+ * 1x1 convolution of x with the [9*Cout][C] weights (row tap*Cout + co); ldz >= 9*Cout.  The backward form writes dz from
+ * dout (the gradient w.r.t. the activated output) and out. */
+int dsee_thin_gather_fwd(const float* z, const float* bias, float* out, int N, int H, int W, int ldz, int Cout, int act,
+                         float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(z && out && Cout >= 1 && Cout <= TCO && ldz >= 9 * Cout);
+  thin_gather_fwd_kernel<<<(int)min(8192L, ((long)N * H * W + 255) / 256), 256, 0, st>>>(z, bias, out, N, H, W, ldz, Cout,
+                                                                                         act, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_thin_gather_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int ldz, int Cout, int act,
+                         float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(dout && out && dz && Cout >= 1 && Cout <= TCO && ldz >= 9 * Cout);
+  thin_gather_bwd_kernel<<<(int)min(8192L, ((long)N * H * W + 255) / 256), 256, 0, st>>>(dout, out, dz, N, H, W, ldz, Cout,
+                                                                                         act, slope);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

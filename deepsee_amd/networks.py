@@ -55,7 +55,12 @@ class SNConvP(nn.Module):
         self.register_buffer("weight_u", torch.zeros(cout))
         self.register_buffer("weight_v", torch.zeros(cin * k * k))
 
+    _pre = None   # this forward's normalised weight when the network ran its layers as one group (ops.SNGroup)
+
     def weight(self, power_iter):
+        if self._pre is not None:
+            w, self._pre = self._pre, None
+            return w
         return ops.SpectralNorm.apply(self.weight_orig, self.weight_u, self.weight_v, bool(power_iter))
 
 
@@ -226,22 +231,25 @@ class SpadeNorm(nn.Module):
         shift = labels.shift_for(h)
         # ---- table path: one fused autograd node per norm; its packed / blended weight set comes from ONE kernel
         P = ops.SeanPack.apply
+        am = ops.amax_slot()     # max |packed weights| (and |style table|), written by the producers themselves
         if self.kind == "spade":
             w2a, _, b2 = P(0, self.mlp_gamma.weight, self.mlp_beta.weight, None, None, self.mlp_gamma.bias,
-                           self.mlp_beta.bias, None, None, None, None)
+                           self.mlp_beta.bias, None, None, None, None, am)
+            w2a.dsee_amax = am
             return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, None, b2, st.running_mean, st.running_var,
                                            labels, shift, training, 1.0, grad_sink)
         if self.kind == "sean":
             w2a, wst, b2 = P(1, self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_style_gamma.weight,
                              self.mlp_style_beta.weight, self.mlp_gamma.bias, self.mlp_beta.bias,
-                             self.mlp_style_gamma.bias, self.mlp_style_beta.bias, self.alpha_gamma, self.alpha_beta)
-            table = ops.style_table_packed(style, wst, b2.shape[0])
+                             self.mlp_style_gamma.bias, self.mlp_style_beta.bias, self.alpha_gamma, self.alpha_beta, am)
+            w2a.dsee_amax = am
+            table = ops.style_table_packed(style, wst, b2.shape[0], am)
             return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, table, b2, st.running_mean, st.running_var,
                                            labels, shift, training, 1.0, grad_sink)
         # puresean: out = xhat * gamma_s + beta_s
         _, wst, b2 = P(2, None, None, self.mlp_style_gamma.weight, self.mlp_style_beta.weight, None, None,
-                       self.mlp_style_gamma.bias, self.mlp_style_beta.bias, None, None)
-        table = ops.style_table_packed(style, wst, b2.shape[0])
+                       self.mlp_style_gamma.bias, self.mlp_style_beta.bias, None, None, None)
+        table = ops.style_table_packed(style, wst, b2.shape[0], am)
         return ops.SeanNormTable.apply(x, None, None, None, table, b2, st.running_mean, st.running_var, labels, shift,
                                        training, 0.0, grad_sink)
 
@@ -253,16 +261,18 @@ class SpadeNorm(nn.Module):
         n, h, w, c = x.shape
         sh, st = self.mlp_shared._modules["0"], self.param_free_norm
         ups = int(round(math.log2(h // fm)))
+        am = ops.amax_slot()
         if self.kind == "sean":
             w2a, _, b2 = ops.SeanPack.apply(3, self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_style_gamma.weight,
                                             self.mlp_style_beta.weight, self.mlp_gamma.bias, self.mlp_beta.bias,
                                             self.mlp_style_gamma.bias, self.mlp_style_beta.bias, self.alpha_gamma,
-                                            self.alpha_beta)
+                                            self.alpha_beta, am)
             add_one = 1.0
         else:  # puresean: out = xhat * gamma_s + beta_s
             w2a, _, b2 = ops.SeanPack.apply(0, self.mlp_style_gamma.weight, self.mlp_style_beta.weight, None, None,
-                                            self.mlp_style_gamma.bias, self.mlp_style_beta.bias, None, None, None, None)
+                                            self.mlp_style_gamma.bias, self.mlp_style_beta.bias, None, None, None, None, am)
             add_one = 0.0
+        w2a.dsee_amax = am
         return ops.SeanNormTable.apply(x, sh.weight, sh.bias, w2a, None, b2, st.running_mean, st.running_var, labels,
                                        labels.shift_for(fm), training, add_one, grad_sink, ups)
 
@@ -358,11 +368,15 @@ class DeepSEESR(nn.Module):
         self.G_middle_1 = SPADEResnetBlock(c, opt, plan[2][1])
         self.up_list = nn.ModuleList([SPADEResnetBlock(c, opt, k) for _, k in plan[3:]])
         self.conv_img = ConvP(3, c, 3)
+        self._sn = None
 
     def forward(self, image_lr, labels, style, noise, training):
-        x = ops.conv2d(image_lr, self.initial.weight, self.initial.bias)
         blocks = [("head_0", self.head_0, 0), ("G_middle_0", self.G_middle_0, 1), ("G_middle_1", self.G_middle_1, 0)]
         blocks += [("up_list.%d" % i, b, 1) for i, b in enumerate(self.up_list)]
+        if self._sn is None:      # all spectral-normalised convolutions of the generator: one group launch per forward
+            self._sn = ops.SNGroup([c for _, b, _ in blocks for c in (b.conv_0, b.conv_1)])
+        self._sn.run(training)
+        x = ops.conv2d(image_lr, self.initial.weight, self.initial.bias)
         for i, (tag, blk, ups) in enumerate(blocks):
             # the LeakyReLU in front of conv_img (sr.py:94) rides in the last block's epilogue
             last = i == len(blocks) - 1
@@ -404,6 +418,7 @@ class StyleEncoder(nn.Module):
     def __init__(self, opt):
         super().__init__()
         nf, s = opt.nef, opt.regional_style_size
+        self._sn = {}
         self.combined = opt.netE == "combinedstyle"
         self.scale = opt.noisy_style_scale
         self.dist = opt.noisy_style_dist
@@ -430,6 +445,16 @@ class StyleEncoder(nn.Module):
         return m
 
     def forward(self, x, labels, mode, no_noise, noise, training):
+        # the spectral-normalised layers THIS forward uses (the other branch's u / v must not advance: the reference's
+        # hook only runs for modules that are called), as one group launch
+        if mode not in self._sn:
+            if self.combined:
+                br = self.encoder_full if mode == "full" else self.encoder_mini
+                layers = [br.layer(nm) for nm in br.names]
+            else:
+                layers = [self._root_layer(nm) for nm in FULL_NAMES]
+            self._sn[mode] = ops.SNGroup(layers + [self._root_layer("final.0.0")])
+        self._sn[mode].run(training)
         if self.combined:
             x = (self.encoder_full if mode == "full" else self.encoder_mini).forward_main(x, training)
         else:
@@ -489,10 +514,16 @@ class MultiscaleDiscriminator(nn.Module):
     def __init__(self, opt):
         super().__init__()
         self.num_d = opt.num_D
+        self._sn = None
         for i in range(opt.num_D):
             self.add_module("discriminator_%d" % i, NLayerD(opt))
 
     def forward(self, x, training):
+        if self._sn is None:
+            self._sn = ops.SNGroup([getattr(getattr(self, "discriminator_%d" % i), "model%d" % n)._modules["0"]._modules["0"]
+                                    for i in range(self.num_d)
+                                    for n in range(1, getattr(self, "discriminator_%d" % i).nl)])
+        self._sn.run(training)
         res = []
         for i in range(self.num_d):
             res.append(getattr(self, "discriminator_%d" % i)(x, training))

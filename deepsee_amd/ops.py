@@ -200,6 +200,7 @@ def _pack_fwd(w, cin_s, korder):
     co, ci, kh, kw = w.shape
     wp = new(L.wrows(L.pad4(co)), L.kpad(kh, kw, cin_s))
     L.call("pack_weight_fwd", w, None, None, wp, co, ci, kh, kw, cin_s, korder)
+    wp.dsee_amax = getattr(w, "dsee_amax", None)     # (a permutation + zero padding of w: same maximum)
     return wp
 
 
@@ -207,6 +208,7 @@ def _pack_dgrad(w, cout_s, korder):
     co, ci, kh, kw = w.shape
     wp = new(L.wrows(L.pad4(ci)), L.kpad(kh, kw, cout_s))
     L.call("pack_weight_dgrad", w, None, None, wp, co, ci, kh, kw, cout_s, korder)
+    wp.dsee_amax = getattr(w, "dsee_amax", None)
     return wp
 
 
@@ -219,6 +221,8 @@ CONV_F16X2_MIN_FLOP = float(os.environ.get("DSEE_CONV_F16X2_MIN_FLOP", "1e9"))
 def tensor_amax(t, cache=None):
     """Device-side max |t| (2048-float slot).  `cache`: a dict shared by the consumers of the same tensors (the data and
     the weight gradient both read dy, the forward conv and the weight gradient both read x): one pass per tensor."""
+    if getattr(t, "dsee_amax", None) is not None:      # carried by its producer (spectral-norm group launch)
+        return t.dsee_amax
     key = (t.data_ptr(), t.numel())
     if cache is not None and key in cache:
         return cache[key]
@@ -229,9 +233,9 @@ def tensor_amax(t, cache=None):
     return a
 
 
-def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0, amax_cache=None):
+def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0, amax_cache=None, exact=False):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
-    if GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and _flops(geom) >= CONV_F16X2_MIN_FLOP:
+    if not exact and GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and _flops(geom) >= CONV_F16X2_MIN_FLOP:
         ax, aw = tensor_amax(x, amax_cache), tensor_amax(wp)
         with _timed(_variant(geom).replace("halo", "igemm") + "_f16x2", _flops(geom)):   # (the halo kernel is fp32-only)
             L.call("conv2d_fwd_f16x2", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw)
@@ -241,12 +245,12 @@ def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE
     return out
 
 
-def wgrad_raw(x, dout, geom, cout, cin, kh, kw, cin_first=0, amax_cache=None):
+def wgrad_raw(x, dout, geom, cout, cin, kh, kw, cin_first=0, amax_cache=None, exact=False):
     nbytes = L.lib().dsee_conv2d_wgrad_workspace(C.byref(geom))
     ws = scratch(nbytes, "wgrad")
     dw = new(cout, cin, kh, kw)
     flops = _flops(geom) * ((cin + 31) // 32 * 32 if geom.korder else geom.Cin) / geom.Cin
-    if GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and flops >= CONV_F16X2_MIN_FLOP:
+    if not exact and GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and flops >= CONV_F16X2_MIN_FLOP:
         ax, ad = tensor_amax(x, amax_cache), tensor_amax(dout, amax_cache)
         with _timed("conv_wgrad_128x128_f16x2(+slab reduce)", flops):
             L.call("conv2d_wgrad_f16x2", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin_first, cin, ax, ad)
@@ -365,7 +369,12 @@ def begin_capture():
 
 def weight_amax(*tensors):
     """max |w| over the given weight tensors (device scalar): |G g G^T| <= max |g|, so it bounds the Winograd-domain
-    weights built from them."""
+    weights built from them.  A weight that carries its maximum (`.dsee_amax`, written by the spectral-norm group launch)
+    needs no pass of its own."""
+    live = [t for t in tensors if t is not None]
+    carried = [getattr(t, "dsee_amax", None) for t in live]
+    if live and carried[0] is not None and all(c is carried[0] for c in carried):
+        return carried[0]                 # every tensor's maximum went into the same slot
     a = amax_slot()
     for t in tensors:
         if t is not None:
@@ -572,17 +581,21 @@ class Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, res, stride, pad, ups, act, noise_w=None, noise_eps=None, res_noise_w=None,
-                res_noise_eps=None, res_sink=None):
+                res_noise_eps=None, res_sink=None, exact=False):
+        """`exact`: keep a direct convolution on the fp32 MFMA (no operand-maximum passes over its activations)."""
+        ctx.exact = bool(exact)
         co, ci, kh, kw = w.shape
         n, hi, wi, cin_s = x.shape
         assert cin_s == L.pad4(ci), (cin_s, ci)
         cout_s = L.pad4(co)
         geom = L.geom_fwd(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
+        w_amax = getattr(w, "dsee_amax", None)      # carried by a spectral-norm group launch
         w = w.contiguous()
+        w.dsee_amax = ctx.w_amax = w_amax
         vkeep = None
         ctx.wino = _wino_ok(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
-        ctx.thin = (kh == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and cin_s % 256 == 0 and cin_s <= 1024
-                    and wi % 64 == 0 and res is None)
+        ctx.thin = (not THIN_GEMM and kh == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and cin_s % 256 == 0
+                    and cin_s <= 1024 and wi % 64 == 0 and res is None)
         if ctx.thin:
             out = new(n, hi, wi, cout_s)
             L.call("conv3x3_thin_fwd", x, w, bias, out, n, hi, wi, cin_s, co, act, LRELU_SLOPE)
@@ -597,7 +610,7 @@ class Conv2d(torch.autograd.Function):
         else:
             ctx.amax_cache = {}   # max |x| found here is reused by the weight gradient
             out = conv_raw(x, _pack_fwd(w, cin_s, geom.korder), geom, pad_vec(bias, cout_s), res, act,
-                           amax_cache=ctx.amax_cache)
+                           amax_cache=ctx.amax_cache, exact=ctx.exact)
         assert noise_w is None or (ctx.wino and act == L.ACT_NONE and isinstance(noise_eps, PhiloxNormal))
         assert res_noise_w is None or (ctx.wino and res is not None and isinstance(res_noise_eps, PhiloxNormal))
         ctx.geom, ctx.act, ctx.has_bias, ctx.has_res = geom, act, bias is not None, res is not None
@@ -610,6 +623,7 @@ class Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, out, vk, vk_amax = ctx.saved_tensors
+        w.dsee_amax = ctx.w_amax
         vkeep = (vk, vk_amax) if vk is not None else None
         geom = ctx.geom
         co, ci, kh, kw = w.shape
@@ -634,7 +648,8 @@ class Conv2d(torch.autograd.Function):
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
         elif ctx.needs_input_grad[0]:
             gd = L.geom_dgrad(geom)
-            dxl = conv_raw(g, _pack_dgrad(w, geom.Cout, gd.korder), gd, amax_cache=getattr(ctx, "amax_cache", None))
+            dxl = conv_raw(g, _pack_dgrad(w, geom.Cout, gd.korder), gd, amax_cache=getattr(ctx, "amax_cache", None),
+                           exact=ctx.exact)
             if geom.ups:
                 dx = torch.empty_like(x)
                 L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
@@ -649,7 +664,7 @@ class Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
             dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep)
         elif ctx.needs_input_grad[1]:
-            dw = wgrad_raw(x, g, geom, co, ci, kh, kw, amax_cache=getattr(ctx, "amax_cache", None))
+            dw = wgrad_raw(x, g, geom, co, ci, kh, kw, amax_cache=getattr(ctx, "amax_cache", None), exact=ctx.exact)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = channel_dot(g, None, co).clone()
         if ctx.has_res and ctx.needs_input_grad[3]:
@@ -668,7 +683,7 @@ class Conv2d(torch.autograd.Function):
 
         dnw = noise_wgrad(ctx.noise) if (ctx.noise is not None and ctx.needs_input_grad[8]) else None
         drnw = noise_wgrad(ctx.res_noise) if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None
-        return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None
+        return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None, None
 
 
 class GradSink:
@@ -699,11 +714,54 @@ def _fusable_noise(x, w, stride, pad, ups, eps):
             and _wino_ok(n, hi, wi, cin_s, L.pad4(w.shape[0]), 3, stride, pad, ups))
 
 
+# The generator's to-RGB layer (512 -> 3 channels at full resolution, sr.py:94-95) as a 1x1 GEMM with 27 outputs on the fp32
+# MFMA + a 9-point gather (ThinGather) instead of the VALU / cross-lane-reduction kernels of thin.hip: x is read once at HBM
+# rate forward, and the data / weight gradients are plain 1x1 implicit GEMMs (2.0 + 3.3 ms -> see DESIGN 5).
+THIN_GEMM = True
+
+
+class ThinGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, bias, co, act):
+        n, h, w, ldz = z.shape
+        out = new(n, h, w, 4)
+        L.call("thin_gather_fwd", z, bias, out, n, h, w, ldz, co, act, LRELU_SLOPE)
+        ctx.save_for_backward(out)
+        ctx.meta = (co, act, ldz, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        co, act, ldz, has_bias = ctx.meta
+        n, h, w, _ = out.shape
+        dout = dout.contiguous()
+        dz = new(n, h, w, ldz)
+        L.call("thin_gather_bwd", dout, out, dz, n, h, w, ldz, co, act, LRELU_SLOPE)
+        db = None
+        if has_bias and ctx.needs_input_grad[1]:
+            g = torch.empty_like(dout)
+            L.call("act_bwd", dout, out, g, C.c_long(dout.numel()), act, LRELU_SLOPE)
+            db = channel_dot(g, None, co).clone()
+        return dz, db, None, None
+
+
+def _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
+    co, ci, kh, kw = w.shape
+    return (THIN_GEMM and kh == 3 and kw == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and res is None
+            and noise is None and res_noise is None and x.shape[3] >= 128 and x.shape[3] % 32 == 0)
+
+
 def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, noise=None, res_noise=None, res_sink=None):
     """`noise` = (noise_w, eps): the NoiseInjection that follows the conv; `res_noise` = (noise_w, eps): the
     NoiseInjection on the residual (the shortcut x_s = noise_skip(x)).  PhiloxNormal draws on a Winograd layer ride in
     the output transform; anything else (a replayed tensor, a non-Winograd layer) runs as its own UpNoise pass.
     `res_sink` (GradSink): the residual's gradient is handed to the norm backward instead of the autograd engine."""
+    if _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
+        co, ci = w.shape[0], w.shape[1]
+        w27 = w.permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1)          # row tap*co_n + co (55 KB of parameter glue)
+        z = Conv2d.apply(x, w27, None, None, 1, 0, 0, L.ACT_NONE, None, None, None, None, None, True)
+        return ThinGather.apply(z, bias, co, act)
     if res_noise is not None and not _fusable_noise(x, w, stride, pad, ups, res_noise[1]):
         # (the shortcut's own node must see its gradient: no sink)
         res, res_noise, res_sink = UpNoise.apply(res, res_noise[0], res_noise[1], 0), None, None
@@ -739,6 +797,83 @@ class SpectralNorm(torch.autograd.Function):
         dwo = torch.empty_like(w_sn)
         L.call("spectral_norm_bwd", dw.contiguous(), w_sn, u, v, sigma, dwo, r, k, scratch(1024, "sn"))
         return dwo, None, None, None
+
+
+class _SpectralNormPre(torch.autograd.Function):
+    """Autograd node of ONE layer of a spectral-norm group: the forward value was computed by the group launch
+    (spectral_norm_group), the backward is the per-layer dW_orig = (dW - <dW, W> u v^T) / sigma."""
+
+    @staticmethod
+    def forward(ctx, w_orig, w_sn, u, v, sigma):
+        ctx.save_for_backward(w_sn, u, v, sigma)
+        return w_sn.view_as(w_orig)
+
+    @staticmethod
+    def backward(ctx, dw):
+        w_sn, u, v, sigma = ctx.saved_tensors
+        r = u.numel()
+        k = v.numel()
+        dwo = torch.empty_like(dw, memory_format=torch.contiguous_format)
+        L.call("spectral_norm_bwd", dw.contiguous(), w_sn, u, v, sigma, dwo, r, k, scratch(1024, "sn"))
+        return dwo, None, None, None, None
+
+
+_SN_DT = None
+
+
+class SNGroup:
+    """The spectral-normalised layers one network uses in a forward pass, with the device-resident tables of
+    dsee_spectral_norm_group_fwd (built once; rebuilt if a parameter or buffer moved)."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self.key = None
+
+    def _build(self):
+        import numpy as np
+        global _SN_DT
+        if _SN_DT is None:
+            _SN_DT = np.dtype([("w", "<u8"), ("u", "<u8"), ("v", "<u8"), ("out_off", "<i8"), ("saved_off", "<i8"),
+                               ("R", "<i4"), ("K", "<i4"), ("scratch_off", "<i4"), ("pad", "<i4")])
+        desc = np.zeros(len(self.layers), dtype=_SN_DT)
+        wk, wr, we = [], [], []
+        out_off = saved_off = sc_off = 0
+        self.slices = []
+        for i, m in enumerate(self.layers):
+            w = m.weight_orig
+            r = w.shape[0]
+            k = w.numel() // r
+            assert w.is_contiguous() and m.weight_u.numel() == r and m.weight_v.numel() == k
+            desc[i] = (w.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(), out_off, saved_off, r, k, sc_off, 0)
+            wk += [(i, j) for j in range((k + 31) // 32)]
+            wr += [(i, j) for j in range(r)]
+            we += [(i, j) for j in range((r * k + 4095) // 4096)]
+            self.slices.append((out_off, r * k, saved_off, r, k))
+            out_off += (r * k + 3) // 4 * 4
+            saved_off += (r + k + 3) // 4 * 4
+            sc_off += r + k
+        dev = self.layers[0].weight_orig.device
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self.wk, self.wr, self.we = (torch.tensor(t, dtype=torch.int32, device=dev).reshape(-1) for t in (wk, wr, we))
+        self.n = (len(wk), len(wr), len(we))
+        self.out_total, self.saved_total, self.scratch_total = out_off, saved_off, sc_off
+        self.key = tuple(int(v) for d in desc for v in (d["w"], d["u"], d["v"]))
+
+    def run(self, power_iter):
+        key = tuple(p for m in self.layers for p in (m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr()))
+        if key != self.key:
+            self._build()
+        nl = len(self.layers)
+        out, saved, sigma = new(self.out_total), new(self.saved_total), new(nl)
+        amax = torch.zeros(nl, AMAX_FLOATS, dtype=torch.float32, device=out.device)
+        with torch.no_grad():
+            L.call("spectral_norm_group_fwd", self.desc, nl, self.wk, self.n[0], self.wr, self.n[1], self.we, self.n[2],
+                   int(bool(power_iter)), SN_EPS, scratch(self.scratch_total * 4, "sng"), sigma, out, saved, amax)
+        for i, (m, (oo, n, so, r, k)) in enumerate(zip(self.layers, self.slices)):
+            w = _SpectralNormPre.apply(m.weight_orig, out[oo:oo + n], saved[so:so + r], saved[so + r:so + r + k],
+                                       sigma[i:i + 1])
+            w.dsee_amax = amax[i]           # max |W_sn| (64-line form): no stand-alone absmax pass over the weight
+            m._pre = w
 
 
 # ------------------------------------------------------------------------------------ instance norm + act
@@ -841,7 +976,7 @@ class SeanInput(torch.autograd.Function):
         if want_actv:
             table = new(9, nc, NHIDDEN)
             L.call("onehot_conv3x3_pack", w_sh.contiguous(), table, NHIDDEN, nc)
-            L.call("onehot_conv3x3_fwd", labels.t, table, b_sh, cat, n, h, w, shift, nc, NHIDDEN, ld, 0, 1)
+            L.call("onehot_conv3x3_fwd", labels.t, table, b_sh, cat, n, h, w, shift, nc, NHIDDEN, ld, 0, 1, -1, None, 0.0)
             coff = NHIDDEN
         if want_style:
             L.call("label_gather", labels.t, style.contiguous(), cat, n, h, w, shift, nc, style.shape[2], ld, coff, 1.0)
@@ -934,7 +1069,7 @@ class SeanPack(torch.autograd.Function):
     wst [(tap, row)][S] is the B operand of the style-table GEMM."""
 
     @staticmethod
-    def forward(ctx, mode, wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab):
+    def forward(ctx, mode, wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab, amax=None):
         ref = wg if wg is not None else wsg
         c = ref.shape[0]
         k = wg.shape[1] if wg is not None else 0
@@ -943,7 +1078,7 @@ class SeanPack(torch.autograd.Function):
         w2a = new(rows, k, 3, 3) if mode != 2 else None
         wst = new(9 * rows, sdim) if mode in (1, 2) else None
         b2 = new(rows)
-        L.call("sean_pack_fwd", wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab, int(mode), c, k, sdim, w2a, wst, b2)
+        L.call("sean_pack_fwd", wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab, int(mode), c, k, sdim, w2a, wst, b2, amax)
         ctx.mode, ctx.dims = int(mode), (c, k, sdim, rows)
         ctx.save_for_backward(wg, wb, wsg, wsb, bg, bb, bsg, bsb, ag, ab)
         return w2a, wst, b2
@@ -965,17 +1100,17 @@ class SeanPack(torch.autograd.Function):
                None if dw2a is None else dw2a.contiguous(), None if dwst is None else dwst.contiguous(),
                None if db2 is None else db2.contiguous(), *outs, dalpha, ws)
         da = (dalpha[0:1], dalpha[1:2]) if dalpha is not None else (None, None)
-        return (None, *outs, da[0] if ctx.needs_input_grad[9] else None, da[1] if ctx.needs_input_grad[10] else None)
+        return (None, *outs, da[0] if ctx.needs_input_grad[9] else None, da[1] if ctx.needs_input_grad[10] else None, None)
 
 
 class TableLayout(torch.autograd.Function):
     """[N*L][9*rows] (the style-table GEMM's result) <-> the [N][9][rows][32] per-image table the kernels read."""
 
     @staticmethod
-    def forward(ctx, t, n, nc, rows):
+    def forward(ctx, t, n, nc, rows, amax=None):
         ctx.dims = (n, nc, rows)
         out = new(n, 9, rows, 32)
-        L.call("style_table_layout", t.contiguous(), out, n, nc, rows)
+        L.call("style_table_layout", t.contiguous(), out, n, nc, rows, amax)
         return out
 
     @staticmethod
@@ -983,14 +1118,17 @@ class TableLayout(torch.autograd.Function):
         n, nc, rows = ctx.dims
         dt = new(n * nc, 9 * rows)
         L.call("style_table_layout_bwd", dout.contiguous(), dt, n, nc, rows)
-        return dt, None, None, None
+        return dt, None, None, None, None
 
 
-def style_table_packed(style, wst, rows):
+def style_table_packed(style, wst, rows, amax=None):
     """T[n][tap][row][r(32)] = sum_s wst[tap*rows + row][s] * style[n][r][s]: one GEMM on parameter-sized operands
-    (rocBLAS through torch.matmul, see _style_gemm) + the layout kernel."""
+    (rocBLAS through torch.matmul, see _style_gemm) + the layout kernel.  `amax`: slot that receives max |T| (on top of
+    what it holds: max |w2a| from SeanPack) -- the operand bound of the gamma/beta GEMM's weights."""
     n, nc, s = style.shape
-    return TableLayout.apply(_style_gemm(style.reshape(n * nc, s), wst), n, nc, rows)
+    t = TableLayout.apply(_style_gemm(style.reshape(n * nc, s), wst), n, nc, rows, amax)
+    t.dsee_amax = amax
+    return t
 
 
 class SyncBNConfig:
@@ -1149,6 +1287,7 @@ class SeanNormTable(torch.autograd.Function):
         ld = ca + (32 if has_t else 0)
         cat = new(n, h, w, ld)
         actv_low = None
+        cat_amax = amax_slot()     # max |cat|, written by the kernel that produces the embedding (>= 1: one-hot channels)
         if has_a:
             tab = new(9, nc, NHIDDEN)
             L.call("onehot_conv3x3_pack", w_sh.contiguous(), tab, NHIDDEN, nc)
@@ -1156,13 +1295,15 @@ class SeanNormTable(torch.autograd.Function):
                 assert not has_t and ld == NHIDDEN
                 actv_low = new(n, h >> cat_ups, w >> cat_ups, NHIDDEN)
                 L.call("onehot_conv3x3_fwd", labels.t, tab, b_sh, actv_low, n, labels.h, labels.w, shift, nc, NHIDDEN,
-                       NHIDDEN, 0, 1)
+                       NHIDDEN, 0, 1, -1, cat_amax, 0.0)   # (the nearest upsample below keeps the maximum)
                 L.call("upsample_noise_fwd", actv_low, None, None, cat, n, h, w, NHIDDEN, cat_ups)
             else:
+                # ... and, with a style table, the 32 one-hot label channels behind the embedding in the same launch
                 L.call("onehot_conv3x3_fwd", labels.t, tab, b_sh, cat, n, labels.h, labels.w, shift, nc, NHIDDEN, ld, 0,
-                       1)
-        if has_t:
+                       1, ca if has_t else -1, cat_amax, 1.0 if has_t else 0.0)
+        elif has_t:
             L.call("label_onehot", labels.t, cat, n, labels.h, labels.w, shift, ld, ca)
+            cat_amax = None
         mean, invstd, ctx.sync = bn_stats(x, running_mean, running_var, training)
         geom = L.geom_fwd(n, h, w, ld, rows, 3, 1, 1, 0)
         assert geom.korder == 1
@@ -1179,7 +1320,7 @@ class SeanNormTable(torch.autograd.Function):
             # (spade_fused.hip): the Winograd-domain product M never reaches HBM
             kp = L.kpad(1, 1, ld)
             t = n * (h // 4) * (w // 4)
-            ac = tensor_amax(cat)
+            ac = cat_amax if cat_amax is not None else tensor_amax(cat)
             v2 = _i16(36 * t * ld * 2)
             L.call("wino43_input_f16x2", cat, v2, n, h, w, ld, ac, FUSED_V_BOUND)
             if has_t:
@@ -1231,12 +1372,15 @@ class SeanNormTable(torch.autograd.Function):
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
         ctx.cat_ups = cat_ups
         vcat = keep[0] if (nb and keep) else (None, None)
+        ctx.w_amax = getattr(w2a, "dsee_amax", None) if has_a else None
         ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, *vcat, actv_low)
         return out
 
     @staticmethod
     def backward(ctx, dh):
         x, cat, w2a, out, scale, mean, invstd, vc, vc_amax, actv_low = ctx.saved_tensors
+        if w2a is not None:
+            w2a.dsee_amax = ctx.w_amax     # (an upper bound: the slot also holds max |style table|)
         vcat = (vc, vc_amax) if vc is not None else None
         geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
         n, h, w, c = x.shape

@@ -206,6 +206,12 @@ int dsee_gemm_bf16x3_tn(const void* P3t, const void* Q3t, float* C, int groups, 
 /* 3x3 / stride 1 / pad 1 convolution with <= 4 output channels (the generator's to-RGB layer + tanh, sr.py:65,94-95)
  * and its weight gradient, laid out along the input channels on the fp32 VALU (deepsee_amd/csrc/thin.hip): as an
  * implicit GEMM its N dimension would fill 3 of 32 MFMA columns.  out / dout are [N,H,W,4]; C % 256 == 0, W % 64 == 0. */
+/* round 3: the same layer as a 1x1 GEMM (z = x . W^T with the [9*Cout][C] weights, row tap*Cout + co; dsee_conv2d_fwd on
+ * the fp32 MFMA, x read once at HBM rate) + a 9-point gather with bias and activation, and its adjoint */
+int dsee_thin_gather_fwd(const float* z, const float* bias, float* out, int N, int H, int W, int ldz, int Cout, int act,
+                         float slope, hipStream_t stream);
+int dsee_thin_gather_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int ldz, int Cout, int act,
+                         float slope, hipStream_t stream);
 int dsee_conv3x3_thin_fwd(const float* x, const float* w_oihw, const float* bias, float* out, int N, int H, int W, int C,
                           int Cout, int act, float slope, hipStream_t stream);
 size_t dsee_conv3x3_thin_wgrad_workspace(int C);
@@ -307,8 +313,12 @@ int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, con
 /* ------------------------------------------------------------------ label-map kernels (uint8 [N][H][W])
  * mlp_shared = ReLU(conv3x3(one-hot)) (normalization.py:98-101) as a 9-tap gather-sum of weight columns. */
 int dsee_onehot_conv3x3_pack(const float* w_oihw, float* table, int Co, int L, hipStream_t stream);
+/* onehot_coff >= 0: also writes the 32 one-hot label channels of every pixel at that column offset (= dsee_label_onehot);
+ * amax (optional, zeroed by the caller): receives max(amax_floor, max |out|) in the 64-line form of dsee_absmax -- the
+ * operand bound of the consumer's fp16 scale without a pass over the embedding. */
 int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float* bias, float* out, int N, int H, int W,
-                            int shift, int L, int Co, int out_ld, int coff, int relu, hipStream_t stream);
+                            int shift, int L, int Co, int out_ld, int coff, int relu, int onehot_coff, float* amax,
+                            float amax_floor, hipStream_t stream);
 size_t dsee_onehot_conv3x3_wgrad_workspace(int N, int H, int W, int shift, int L);
 int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, int dact_ld, const float* act, int act_ld, int N,
                               int H, int W, int shift, int L, float* dw_oihw, float* dbias, float* workspace,
@@ -394,7 +404,7 @@ int dsee_sean_pack_rows(int C);
 int dsee_sean_pack_fwd(const float* w_gamma, const float* w_beta, const float* ws_gamma, const float* ws_beta,
                        const float* b_gamma, const float* b_beta, const float* bs_gamma, const float* bs_beta,
                        const float* alpha_gamma, const float* alpha_beta, int mode, int C, int K, int S, float* w2a,
-                       float* wst, float* b2, hipStream_t stream);
+                       float* wst, float* b2, float* amax_w2a, hipStream_t stream);
 size_t dsee_sean_pack_bwd_workspace(void);
 int dsee_sean_pack_bwd(const float* w_gamma, const float* w_beta, const float* ws_gamma, const float* ws_beta,
                        const float* b_gamma, const float* b_beta, const float* bs_gamma, const float* bs_beta,
@@ -403,7 +413,7 @@ int dsee_sean_pack_bwd(const float* w_gamma, const float* w_beta, const float* w
                        float* dws_gamma, float* dws_beta, float* db_gamma, float* db_beta, float* dbs_gamma,
                        float* dbs_beta, float* dalpha, float* workspace, hipStream_t stream);
 /* per-image style tables (normalization.py:182-185 as a table, SURVEY B-7): [N*L][9*rows] GEMM result <-> [N][9][rows][32] */
-int dsee_style_table_layout(const float* t, float* table, int N, int L, int rows, hipStream_t stream);
+int dsee_style_table_layout(const float* t, float* table, int N, int L, int rows, float* amax, hipStream_t stream);
 int dsee_style_table_layout_bwd(const float* dtable, float* dt, int N, int L, int rows, hipStream_t stream);
 
 /* ------------------------------------------------------------------ spectral norm + Adam */
@@ -411,6 +421,21 @@ int dsee_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* sigma
                            int power_iter, float eps, float* scratch, hipStream_t stream);
 int dsee_spectral_norm_bwd(const float* dw, const float* w_sn, const float* u, const float* v, const float* sigma,
                            float* dw_orig, int R, int K, float* scratch, hipStream_t stream);
+
+/* all spectral-normalised layers of a network at once (5 launches instead of 6 + 2 per layer) */
+typedef struct dsee_sn_layer {
+  const float* w_orig; /* [R][K] */
+  float* u;            /* [R], updated in place when power_iter */
+  float* v;            /* [K] */
+  int64_t out_off;     /* first element of this layer's w_sn in the flat output */
+  int64_t saved_off;   /* u at saved_off, v at saved_off + R in the `saved` buffer */
+  int32_t R, K;
+  int32_t scratch_off; /* K + R floats of scratch */
+  int32_t pad_;
+} dsee_sn_layer;
+int dsee_spectral_norm_group_fwd(const dsee_sn_layer* layers, int nlayers, const int* work_k, int n_k, const int* work_r,
+                                 int n_r, const int* work_e, int n_e, int power_iter, float eps, float* scratch,
+                                 float* sigma, float* out, float* saved, float* amax, hipStream_t stream);
 
 typedef struct dsee_adam_tensor {
   int64_t offset;      /* first element in the flat buffers */
