@@ -132,7 +132,8 @@ def spawn_ranks(n):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, effective_cores() // n))))   # each rank pins itself to its own core
+    # set (deepsee_amd.parallel.pin_rank_cores)
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 

@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(const int64_t* __restr
   const dsee_adam_tensor d = tensors[t];
   const float* src = reinterpret_cast<const float*>(ptrs[t]);
   const long b0 = (long)(blk - d.first_block) * 1024;
-  if (blk == d.first_block && threadIdx.x == 0) active[t] = src != nullptr;
+  if (blk == d.first_block && threadIdx.x == 0) {
+    active[t] = src != nullptr;
+    grad_flat[t] = src ? 1.f : 0.f;   // header of the flat buffer: the flag travels with the first all-reduced chunk
+  }
   for (long i = b0 + threadIdx.x; i < d.numel && i < b0 + 1024; i += 256) grad_flat[d.offset + i] = src ? src[i] : 0.f;
 }
 
@@ -326,7 +329,8 @@ int dsee_adam_step_range(float* param, const float* grad, float* exp_avg, float*
 
 /* Collects the per-parameter gradient tensors autograd produced (grad_ptrs[t]: device address of a contiguous fp32
  * tensor of tensors[t].numel elements, or 0 = "p.grad is None") into the flat gradient buffer the all-reduce and the
- * Adam kernel work on, and writes the per-tensor active flags.  Replaces the ~290 AccumulateGrad `grad += new` kernels of
+ * Adam kernel work on, and writes the per-tensor active flags -- into active[] and, as 0 / 1 floats, into grad_flat[t]
+ * (the flat buffers start with a header of >= ntensors floats; tensors[t].offset lies behind it).  Replaces the ~290 AccumulateGrad `grad += new` kernels of
  * a backward pass into persistent .grad views (and the zero fill of the flat buffer) by one launch. */
 int dsee_grad_gather(const int64_t* grad_ptrs, const dsee_adam_tensor* tensors, const int* block_tensor, int nblocks,
                      float* grad_flat, int* active, hipStream_t st) {

@@ -766,8 +766,13 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
 //                                                                         convolution with the rotated kernel)
 //                adjoint  row = ci, k = co, g = w[co][ci]                (transpose_flip = 2: the forward U transposed,
 //                                                                         for dV = dM x U^T of the adjoint data gradient)
+// blockIdx.y = layer of a batch of equally shaped layers (w, U, amax advance by w_stride / u_stride / 2048 floats)
 __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows,
-                                     int Kpad, int transpose_flip, int split, const float* __restrict__ amax) {
+                                     int Kpad, int transpose_flip, int split, const float* __restrict__ amax,
+                                     long w_stride, long u_stride) {
+  w += (size_t)blockIdx.y * w_stride;
+  U += (size_t)blockIdx.y * u_stride;
+  if (amax) amax += (size_t)blockIdx.y * (DSEE_AMAX_LINES * DSEE_AMAX_STRIDE);
   const long total = (long)rows * Kpad;
   const float sc = split >= 2 ? dsee_pow2_scale(dsee_amax_read(amax)) : 1.f;
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
@@ -963,7 +968,21 @@ int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int tr
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
   wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip,
-                                                                 split, amax_w);
+                                                                 split, amax_w, 0, 0);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* The same for `layers` equally shaped weights in one launch: w_oihw + i * w_stride floats -> U + i * u_stride floats,
+ * amax_w + i * 2048 floats (the layout of dsee_spectral_norm_group_fwd's flat output and maxima). */
+int dsee_wino43_weights_batch(const float* w_oihw, float* U, int layers, long w_stride, long u_stride, int Cout, int Cin,
+                              int transpose_flip, int split, const float* amax_w, hipStream_t st) {
+  DSEE_CHECK_ARG(w_oihw && U && layers > 0 && layers < 65536 && (split < 2 || amax_w));
+  const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
+  wino43_weight_kernel<<<dim3(wgrid((long)rows * Kpad), layers), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad,
+                                                                               transpose_flip, split, amax_w, w_stride,
+                                                                               u_stride);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

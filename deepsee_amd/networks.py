@@ -376,6 +376,7 @@ class DeepSEESR(nn.Module):
         if self._sn is None:      # all spectral-normalised convolutions of the generator: one group launch per forward
             self._sn = ops.SNGroup([c for _, b, _ in blocks for c in (b.conv_0, b.conv_1)])
         self._sn.run(training)
+        self._sn.wino_weights(torch.is_grad_enabled())
         x = ops.conv2d(image_lr, self.initial.weight, self.initial.bias)
         for i, (tag, blk, ups) in enumerate(blocks):
             # the LeakyReLU in front of conv_img (sr.py:94) rides in the last block's epilogue

@@ -385,6 +385,9 @@ def weight_amax(*tensors):
 def _wino_u(w, co, ci, transpose_flip, rows, kp, split):
     """Winograd-domain weights U [36][rows][kp]: fp32 (split 0), bf16x3-split rows (1) or scaled fp16x2-split rows (2).
     Returns (U, amax) with amax = the device scalar the fp16x2 scale was derived from (None otherwise)."""
+    pre = getattr(w, "dsee_u", None)
+    if pre is not None and (int(transpose_flip), int(split), rows, kp) in pre:
+        return pre[(int(transpose_flip), int(split), rows, kp)]       # transformed with its whole network (SNGroup.wino_weights)
     amax = weight_amax(w) if split >= 2 else None
     u = _i16(36 * rows * kp * {1: 3, 2: 2, 3: 1}[split]) if split else new(36, rows, kp)
     L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split), amax)
@@ -589,9 +592,10 @@ class Conv2d(torch.autograd.Function):
         assert cin_s == L.pad4(ci), (cin_s, ci)
         cout_s = L.pad4(co)
         geom = L.geom_fwd(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
-        w_amax = getattr(w, "dsee_amax", None)      # carried by a spectral-norm group launch
+        w_amax, w_u = getattr(w, "dsee_amax", None), getattr(w, "dsee_u", None)   # carried by a spectral-norm group launch
         w = w.contiguous()
         w.dsee_amax = ctx.w_amax = w_amax
+        w.dsee_u = ctx.w_u = w_u
         vkeep = None
         ctx.wino = _wino_ok(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
         ctx.thin = (not THIN_GEMM and kh == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and cin_s % 256 == 0
@@ -623,7 +627,7 @@ class Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, out, vk, vk_amax = ctx.saved_tensors
-        w.dsee_amax = ctx.w_amax
+        w.dsee_amax, w.dsee_u = ctx.w_amax, ctx.w_u
         vkeep = (vk, vk_amax) if vk is not None else None
         geom = ctx.geom
         co, ci, kh, kw = w.shape
@@ -874,6 +878,32 @@ class SNGroup:
                                        sigma[i:i + 1])
             w.dsee_amax = amax[i]           # max |W_sn| (64-line form): no stand-alone absmax pass over the weight
             m._pre = w
+        self.last = (out, amax)
+
+    def wino_weights(self, with_adjoint):
+        """Winograd-domain weights U = G g G^T of ALL layers of the group in one launch (forward form; with the adjoint
+        form for the backward pass in a second one) when the layers are equally shaped 3x3 convolutions on the fp16x2 split
+        path; attached to the normalised weights so that ops._wino_u finds them."""
+        w0 = self.layers[0].weight_orig
+        co, ci = w0.shape[0], w0.shape[1]
+        same = all(tuple(m.weight_orig.shape) == tuple(w0.shape) for m in self.layers) and tuple(w0.shape[2:]) == (3, 3)
+        if not (same and WINOGRAD and GEMM_SPLIT and GEMM_F16X2 and GEMM_AF32 and not HALF and ci % 32 == 0 and co % 128 == 0
+                and ci % 128 == 0 and ci >= 128):
+            return
+        out, amax = self.last
+        nl = len(self.layers)
+        stride = self.slices[1][0] - self.slices[0][0] if nl > 1 else co * ci * 9
+        for flip in ((0, 2) if with_adjoint else (0,)):
+            r_s, k_s = (ci, co) if flip else (co, ci)
+            rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
+            per = 36 * rows * kp * 2            # int16 elements per layer (two fp16 terms)
+            u = _i16(nl * per)
+            with torch.no_grad():
+                L.call("wino43_weights_batch", out, u, nl, stride, per // 2, co, ci, flip, 2, amax)
+            for i, m in enumerate(self.layers):
+                d = getattr(m._pre, "dsee_u", None) or {}
+                d[(flip, 2, rows, kp)] = (u[i * per:(i + 1) * per], amax[i])
+                m._pre.dsee_u = d
 
 
 # ------------------------------------------------------------------------------------ instance norm + act

@@ -39,7 +39,11 @@ class FlatAdam:
                 self.params.append(p)
                 self.group_of.append(gi)
         dev = self.params[0].device
-        offs, total = [], 0
+        # header: the first `hdr` floats of the flat buffers carry the per-tensor "has a gradient" flags (as 0 / 1 floats,
+        # written by the gather kernel), so that under data-parallel training they travel INSIDE the first all-reduced
+        # gradient chunk (sum > 0 <=> some rank has a gradient) instead of in a blocking collective of their own
+        self.hdr = (len(self.params) + BLOCK - 1) // BLOCK * BLOCK
+        offs, total = [], self.hdr
         for p in self.params:
             offs.append(total)
             total += (p.numel() + 3) // 4 * 4  # keep every tensor 16 B aligned
@@ -159,15 +163,18 @@ class FlatAdam:
         self._gather()           # flat gradient + active flags in one launch
         self._held = grads       # (the gradient tensors stay referenced until the next step has been enqueued)
         if multi:
-            hook.reduce_active(self._active_dev)
-        self._d32[:, _ACTIVE].copy_(self._active_dev)
-        if multi:
             ranges = self.chunk_ranges(hook.chunk_elems)
             works = hook.start(self.grad, [(lo, hi) for _, _, lo, hi in ranges])
-            for (b0, b1, _, _), w in zip(ranges, works):
+            for i, ((b0, b1, _, _), w) in enumerate(zip(ranges, works)):
                 w.wait()      # the compute stream waits for THIS chunk only; RCCL keeps reducing the later ones
+                if i == 0:
+                    # the flags rode in the header of chunk 0: a tensor is active iff ANY rank has a gradient for it (a
+                    # rank whose encoder coin differed would otherwise update a different parameter subset with a
+                    # different step count -- parameters would silently diverge)
+                    self._d32[:, _ACTIVE].copy_(self.grad[:len(self.params)] > 0.5)
                 self._launch(b0, b1, hook.scale, clip)
         else:
+            self._d32[:, _ACTIVE].copy_(self._active_dev)
             self._launch(0, self.nblocks, 1.0, clip)
         self._d32[:, _STEP] += self._d32[:, _ACTIVE]
 

@@ -11,8 +11,9 @@ gradient exchange is one chunked collective per optimizer step instead of a redu
 
 Rank consistency: parameters and spectral-norm buffers start identical (broadcast from rank 0) and stay
 identical because every rank applies the same all-reduced gradient; the encoder-branch coins come from
-networks.DeviceNoise's own rank-independent RNG; the per-tensor "has a gradient" flags are MAX-reduced before every
-optimizer step so no rank can update a different parameter subset; the device noise seed is offset per rank.
+networks.DeviceNoise's own rank-independent coin function; the per-tensor "has a gradient" flags ride in the header of the
+first all-reduced gradient chunk (sum > 0), so no rank can update a different parameter subset and no collective of their
+own blocks the step; the device noise seed is offset per rank; every rank pins itself to its own host cores.
 """
 import os
 
@@ -37,12 +38,36 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)          # (whatever the backend: a gloo bring-up run must not pile onto cuda:0)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
+    pin_rank_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     return rank, local, world
+
+
+def rank_core_set(local_rank, local_world, cores=None):
+    """The host cores of one rank: the process's allowed cores split into `local_world` contiguous sets."""
+    cores = sorted(os.sched_getaffinity(0)) if cores is None else sorted(cores)
+    per = max(1, len(cores) // max(1, local_world))
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    return mine or cores
+
+
+def pin_rank_cores(local_rank, local_world):
+    """8 ranks x ~1 500 Python-issued launches per half step on one host: without pinning the launch threads migrate and
+    contend for the same cores.  Every rank takes its own contiguous core set (no-op for a single rank, or when
+    DSEE_NO_PIN=1)."""
+    if local_world <= 1 or os.environ.get("DSEE_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    mine = rank_core_set(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(8, len(mine))))
+    except OSError:
+        return None
+    return mine
 
 
 def chunk_bounds(total, chunk_elems):
@@ -64,12 +89,6 @@ class GradAllReduce:
         self.scale = 1.0 / max(1, self.world)
         # `force`: run the collectives even in a 1-rank process group (exercises the RCCL path on a single GPU)
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
-
-    def reduce_active(self, active):
-        """MAX over the ranks of the per-tensor "autograd delivered a gradient" flags (int32, in place)."""
-        if self.active:
-            dist.all_reduce(active, op=dist.ReduceOp.MAX, group=self.group)
-        return active
 
     def start(self, flat_grad, bounds):
         if not self.active:

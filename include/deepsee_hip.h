@@ -100,6 +100,10 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
                        uint64_t res_noise_offset, const float* mscale, hipStream_t stream);
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
                         const float* amax_w, hipStream_t stream);
+/* ... of `layers` equally shaped weights in ONE launch (the generator's ten 512 -> 512 convolutions: their normalised
+ * weights sit in the flat output of dsee_spectral_norm_group_fwd, w_stride floats apart; amax_w [layers][2048]) */
+int dsee_wino43_weights_batch(const float* w_oihw, float* U, int layers, long w_stride, long u_stride, int Cout, int Cin,
+                              int transpose_flip, int split, const float* amax_w, hipStream_t stream);
 /* fp32-accurate GEMM on the bf16 matrix cores (operands split into three bf16 terms by their producers, six MFMA
  * products accumulated in fp32; see deepsee_amd/csrc/gemm_bf16x3.hip).  With `split` the producers write slab-major
  * [K/16][rows][3][16] bf16 (1.5x the fp32 bytes) instead of fp32 rows:

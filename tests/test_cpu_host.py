@@ -250,6 +250,7 @@ def _flat_adam_worker(rank, world, port, q):
                 if p.grad is not None:
                     self.grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
                 self._active_dev[i] = 0 if p.grad is None else 1
+                self.grad[i] = 0.0 if p.grad is None else 1.0      # header flag (rides in the first all-reduced chunk)
 
         def _launch(self, b0, b1, grad_scale, clip):
             CpuAdam.launches += 1
@@ -508,3 +509,16 @@ def test_style_matrix_csv_roundtrip(tmp_path):
     import pytest
     with pytest.raises(AssertionError):
         save_style_matrix(m[None], p)
+
+
+def test_rank_core_sets_partition_the_allowed_cores():
+    """deepsee_amd.parallel.rank_core_set: the ranks of a node get disjoint, contiguous, equally sized core sets that
+    cover the allowed cores (8 launch threads on one host must not share cores); more ranks than cores degrade to sharing."""
+    from deepsee_amd import parallel
+    cores = list(range(4, 36))
+    sets = [parallel.rank_core_set(r, 8, cores) for r in range(8)]
+    assert all(len(s) == 4 for s in sets)
+    assert sorted(c for s in sets for c in s) == cores
+    assert all(s == list(range(s[0], s[0] + 4)) for s in sets)
+    assert parallel.rank_core_set(5, 8, [0, 1]) == [0, 1]          # fewer cores than ranks: everybody keeps what there is
+    assert parallel.pin_rank_cores(0, 1) is None                   # single rank: untouched
