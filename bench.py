@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--dtype", choices=["fp32", "fp16"], default="fp32",
                     help="fp16: BASELINE configs[2]'s 16-bit arithmetic (one-term scaled-fp16 matrix-core GEMMs, fp32 master "
                          "weights): a separate line")
+    ap.add_argument("--arith", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
+                    help="how the fp32 Winograd-domain GEMMs run on the matrix cores: two-term fp16 split (default), exact "
+                         "3-term bf16 split, or v_mfma_f32")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -174,6 +177,7 @@ def main():
     if world != args.gpus:   # never report a number for a world size other than the one asked for
         raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local)
+    ops.GEMM_SPLIT, ops.GEMM_F16X2 = args.arith != "f32", args.arith == "f16x2"
     preset, n_default, ref = CONFIGS[args.config]
     n = args.batch_per_gpu or n_default
     headline = args.config == "independent_8x_256"
@@ -278,7 +282,7 @@ def main():
             "f16x2": "fp32 storage and accumulation; the wide 3x3 layers run as Winograd F(4x4,3x3) GEMMs on the fp16 "
                      "matrix cores: every fp32 operand is scaled by an exact power of two and split into two fp16 terms "
                      "(residual <= 2^-22, rms 2^-24), 3 MFMA products per multiply-add, fp32 accumulate; error vs float64 "
-                     "equal to a CPU sgemm's (tests/test_gpu_conv.py::test_gemm_f16x2_is_fp32_accurate); DSEE_BF16X3=1 "
+                     "equal to a CPU sgemm's (tests/test_gpu_conv.py::test_gemm_f16x2_is_fp32_accurate); --arith bf16x3 "
                      "selects the exact 3-term bf16 split (6 products)",
             "bf16x3": "fp32 storage and accumulation; Winograd-domain GEMMs from exact 3-term bf16 operand splits (6 bf16 "
                       "MFMA products)",

@@ -75,39 +75,6 @@ def new(*shape):
     return torch.empty(*shape, dtype=torch.float32, device="cuda")
 
 
-# The weight gradient and the data gradient of a layer are independent and can run on two HIP streams (DSEE_STREAMS=1).
-# Off by default: measured 184.5 vs 184.8 ms/step -- the persistent GEMM holds 216 VGPRs x 8 waves per CU, so the
-# 178-VGPR transform kernels of the other stream cannot become resident beside it and nothing overlaps.
-STREAMS = os.environ.get("DSEE_STREAMS", "0") == "1"
-_side_streams = {}
-
-
-class _OnSide:
-    """with _OnSide() as s: ... enqueue on the side stream (ordered after everything already on the current stream);
-    s.join(t0, t1, ...) makes the current stream wait for it and hands the result tensors over."""
-
-    def __enter__(self):
-        self.main = torch.cuda.current_stream()
-        dev = torch.cuda.current_device()
-        if dev not in _side_streams:
-            _side_streams[dev] = torch.cuda.Stream()
-        self.side = _side_streams[dev]
-        self.side.wait_stream(self.main)
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        self.ctx.__exit__(*exc)
-        return False
-
-    def join(self, *tensors):
-        self.main.wait_stream(self.side)
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.main)
-
-
 def pad_vec(v, n):
     """[c] -> [n] zero padded (bias vectors for padded channel counts)."""
     if v is None or v.numel() == n:
@@ -215,7 +182,7 @@ def _pack_dgrad(w, cout_s, korder):
 # Direct (non-Winograd) convolutions with >= CONV_F16X2_MIN_FLOP (1 GFLOP) of work run their MFMAs on fp16x2-split operands (the
 # split happens inside the kernel; two small max|.| passes over the input and the packed weights provide the scales).
 # Below the threshold the two extra launches cost more than the shorter MFMA chain saves.  0 disables.
-CONV_F16X2_MIN_FLOP = float(os.environ.get("DSEE_CONV_F16X2_MIN_FLOP", "1e9"))
+CONV_F16X2_MIN_FLOP = 1e9
 
 
 def tensor_amax(t, cache=None):
@@ -274,14 +241,16 @@ def channel_dot(a, b, c):
 WINOGRAD = True
 WINOGRAD_WGRAD = True
 WINOGRAD_MOD = True
-# fp32 GEMMs of the Winograd domain on the bf16 matrix cores via exact 3-term operand splitting (gemm_bf16x3.hip);
-# DSEE_F32_MFMA=1 keeps them on v_mfma_f32_32x32x2_f32
-GEMM_SPLIT = os.environ.get("DSEE_F32_MFMA", "0") != "1"
+# The switches below select between kernel paths that compute the same function.  They are module attributes (no
+# environment variables); the non-default side of each is exercised by tests/test_gpu_model.py::test_kernel_path_switches.
+# fp32 GEMMs of the Winograd domain on the 16-bit matrix cores via operand splitting (gemm_bf16x3.hip); False keeps them
+# on v_mfma_f32_32x32x2_f32 (bench.py's f32_mfma_exact comparison run)
+GEMM_SPLIT = True
 # A operand of the forward / data-gradient GEMMs kept in fp32 in HBM (4 instead of 6 bytes per element written by the
-# input transform and read by the GEMM) and split inside the GEMM kernel; DSEE_A_PRESPLIT=1 uses pre-split A operands
-GEMM_AF32 = os.environ.get("DSEE_A_PRESPLIT", "0") != "1"
-# keep the forward's fp32 V for the weight gradient (DSEE_KEEP_V=0: transform x again in the backward pass)
-KEEP_V = os.environ.get("DSEE_KEEP_V", "1") != "0"
+# input transform and read by the GEMM) and split inside the GEMM kernel; False uses pre-split bf16x3 A operands
+GEMM_AF32 = True
+# keep the forward's fp32 V for the weight gradient (False: transform x again in the backward pass)
+KEEP_V = True
 
 
 def _wino_chunk(n, h, w, cmax, per_image=False):
@@ -312,8 +281,9 @@ def _wino_ok(n, h, w, cin_s, cout_s, k, stride, pad, ups):
 
 
 # ... and with two-term fp16 splits (3 instead of 6 MFMA products per fp32 multiply-add, operands scaled by exact powers
-# of two; DSEE_BF16X3=1 keeps the 3-term bf16 form).  Needs the fp32-A kernels (the operands are split in the GEMM).
-GEMM_F16X2 = os.environ.get("DSEE_BF16X3", "0") != "1"
+# of two; False keeps the 3-term bf16 form, bench.py's bf16x3_exact comparison run).  Needs the fp32-A kernels (the
+# operands are split in the GEMM).
+GEMM_F16X2 = True
 
 
 def _split_ok(k_s, r_s):
@@ -518,9 +488,9 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
     return v, dm
 
 
-# data gradient in the adjoint form from the dM = A dY A^T the weight gradient needs anyway (DSEE_ADJOINT=0: transform dy
+# data gradient in the adjoint form from the dM = A dY A^T the weight gradient needs anyway (False: transform dy
 # a second time with B^T . B and run the rotated-kernel convolution)
-ADJOINT_DGRAD = os.environ.get("DSEE_ADJOINT", "1") != "0"
+ADJOINT_DGRAD = True
 
 
 def _adjoint_ok(k_s, r_s):
@@ -638,16 +608,11 @@ class Conv2d(torch.autograd.Function):
         else:
             g = dy
         dx = dw = db = dres = None
-        fused = (ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not STREAMS
+        fused = (ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                  and _wgrad_mode(geom.Cin, geom.Cout) != 1 and _adjoint_ok(geom.Cout, geom.Cin))
         if fused:
             # one A dY A^T transform of g serves the weight gradient AND (adjoint form) the data gradient
             dw, dx = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, w_for_dx=w)
-        elif STREAMS and ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            with _OnSide() as sd:
-                dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep)
-            dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
-            sd.join(dw)
         elif ctx.needs_input_grad[0] and ctx.wino:
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
         elif ctx.needs_input_grad[0]:
@@ -708,8 +673,8 @@ class GradSink:
         return g
 
 
-# NoiseInjection draws regenerated inside the consumer's output transform (DSEE_FUSE_NOISE=0: stand-alone UpNoise passes)
-FUSE_NOISE = os.environ.get("DSEE_FUSE_NOISE", "1") != "0"
+# NoiseInjection draws regenerated inside the consumer's output transform (False: stand-alone UpNoise passes)
+FUSE_NOISE = True
 
 
 def _fusable_noise(x, w, stride, pad, ups, eps):
@@ -1194,8 +1159,8 @@ def bn_stats(x, running_mean, running_var, training):
     return mean, invstd, cfg
 
 
-# gamma/beta gradient written by the norm backward directly in the Winograd domain (DSEE_FUSE_DM=0: dgb + wino43_dout)
-FUSE_DM = os.environ.get("DSEE_FUSE_DM", "1") != "0"
+# gamma/beta gradient written by the norm backward directly in the Winograd domain (False: dgb + wino43_dout)
+FUSE_DM = True
 
 
 def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=None):
@@ -1420,7 +1385,7 @@ class SeanNormTable(torch.autograd.Function):
         wino_w = bool(nb) and (ctx.has_t or ctx.needs_input_grad[3])
         # the embedding's data gradient from the weight gradient's dM (adjoint form): no second transform of the
         # 1024-channel gamma/beta gradient
-        fused_d = (wino_w and ctx.has_a and not STREAMS and _wgrad_mode(ld, rows) != 1 and _adjoint_ok(rows, NHIDDEN))
+        fused_d = (wino_w and ctx.has_a and _wgrad_mode(ld, rows) != 1 and _adjoint_ok(rows, NHIDDEN))
         dactv_fused = [None]
         # every consumer of the gamma/beta gradient reads dM: let the norm backward write it directly
         as_dm = (FUSE_DM and wino_w and nb == n and _wgrad_mode(ld, rows) != 1 and (fused_d or not ctx.has_a)
@@ -1466,10 +1431,6 @@ class SeanNormTable(torch.autograd.Function):
                         dactv_fused[0][n0:n0 + nb].copy_(dac)
             return dw2a, dtable
 
-        side = None
-        if wino_w and STREAMS and ctx.has_a:
-            with _OnSide() as side:          # weight / table gradient on the second stream, data gradient below
-                dw2a, dtable = wino_wgrad()
         if fused_d:
             dw2a, dtable = wino_wgrad()
         if ctx.has_a:
@@ -1502,9 +1463,7 @@ class SeanNormTable(torch.autograd.Function):
                     dactv, act_lo, ld_lo = dlow, actv_low, NHIDDEN
                 L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, act_lo, ld_lo, n, lab.h, lab.w, shift, lab.nc,
                        dw_sh, db_sh, wso)
-        if side is not None:
-            side.join(dw2a, dtable)
-        elif wino_w and not fused_d:
+        if wino_w and not fused_d:
             dw2a, dtable = wino_wgrad()
         if wino_w:
             pass

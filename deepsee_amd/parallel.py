@@ -57,9 +57,8 @@ def rank_core_set(local_rank, local_world, cores=None):
 
 def pin_rank_cores(local_rank, local_world):
     """8 ranks x ~1 500 Python-issued launches per half step on one host: without pinning the launch threads migrate and
-    contend for the same cores.  Every rank takes its own contiguous core set (no-op for a single rank, or when
-    DSEE_NO_PIN=1)."""
-    if local_world <= 1 or os.environ.get("DSEE_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+    contend for the same cores.  Every rank takes its own contiguous core set (no-op for a single rank)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     mine = rank_core_set(local_rank, local_world)
     try:

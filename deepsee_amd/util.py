@@ -6,13 +6,20 @@ import torch
 
 
 def save_style_matrix(tensor, path, create_dir=False):
-    """One image's style matrix [label_nc, regional_style_size] as CSV: the file format of util/util.py:150-158
-    (numpy.savetxt, ',' delimiter, '%.18e'), what demo.py:72 writes next to each result image."""
-    if create_dir:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-    assert len(tensor.shape) == 2, "Shape is incorrect: {}".format(tuple(tensor.shape))
-    assert path.endswith(".csv")
-    np.savetxt(path, np.array(tensor.detach().cpu()), delimiter=",")
+    """Write one image's style matrix (rows = semantic regions, columns = style features) as a CSV file next to the result
+    image.  File format of the reference's helper (util/util.py:150-158, called from demo.py:72): one matrix row per
+    line, ',' separated, every value printed as '%.18e', so files written by either side load on the other."""
+    m = tensor.detach().to("cpu", torch.float64).numpy()
+    if m.ndim != 2:
+        raise AssertionError("a style matrix is [label_nc, style_size]; got shape %s" % (tuple(m.shape),))
+    if not str(path).endswith(".csv"):
+        raise AssertionError("style matrices are stored as .csv: %s" % path)
+    folder = os.path.dirname(str(path))
+    if create_dir and folder:
+        os.makedirs(folder, exist_ok=True)
+    with open(path, "w") as fh:
+        for row in m:
+            fh.write(",".join("%.18e" % float(v) for v in row) + "\n")
 
 
 def load_style_matrix(path, device="cuda"):

@@ -537,3 +537,79 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale):
     assert e_h < 2e-6
     if with_scale:
         assert rel(sc.cpu().double().permute(0, 3, 1, 2), sc_ref) < 2e-6
+
+
+@pytest.mark.parametrize("shift", [0, 16, 20])
+def test_small_channel_keeps_its_precision_in_the_winograd_conv(shift):
+    """The fp16x2 operand split uses ONE power-of-two scale per tensor.  A channel whose values sit 2^-20 below the tensor
+    maximum must still come through with fp32-level accuracy: its high term lands in fp16's normal range (2^-5 after
+    scaling), its low term in the subnormals with an absolute step of 2^-24 (relative 2^-19).  Output channel 5 reads
+    ONLY the small input channel 7, gradient channel 9 is 2^-20 below the others; the outputs / weight gradients that
+    depend on the small operands alone are held to 1e-3 relative to THEIR OWN size against float64 (measured ~1e-5)."""
+    from deepsee_amd import ops
+    n, c, h, small = 2, 256, 64, 2.0 ** -shift
+    assert ops._wino_ok(n, h, h, c, c, 3, 1, 1, 0) and ops.GEMM_F16X2 and not ops.HALF
+    g = torch.Generator().manual_seed(2020)
+    x = torch.randn(n, c, h, h, generator=g)
+    x[:, 7] *= small
+    w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    w[5] = 0.0
+    w[5, 7] = torch.randn(3, 3, generator=g)
+    gy = torch.randn(n, c, h, h, generator=g)
+    gy[:, 9] *= small
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    y = F.conv2d(xr, wr, padding=1)
+    y.backward(gy.double())
+    xd, wd = nhwc(x).cuda().requires_grad_(), w.cuda().requires_grad_()
+    yd = ops.conv2d(xd, wd, None, None, 1, 1, 0, 0)
+    yd.backward(nhwc(gy).cuda())
+    torch.cuda.synchronize()
+    yh = nchw(yd.detach().cpu(), c).double()
+    e_out = rel(yh[:, 5], y.detach()[:, 5])                     # output that depends on the small channel only
+    e_dw_x = rel(wd.grad.cpu().double()[:, 7], wr.grad[:, 7])   # dw columns fed by the small input channel
+    e_dw_g = rel(wd.grad.cpu().double()[9], wr.grad[9])         # dw rows fed by the small gradient channel
+    e_all = rel(yh, y.detach())
+    print("channel 2^-%d below the maximum: y[5] %.1e, dw[:,7] %.1e, dw[9] %.1e (whole tensor %.1e)"
+          % (shift, e_out, e_dw_x, e_dw_g, e_all))
+    assert e_all < 1e-4
+    assert e_out < 1e-3 and e_dw_x < 1e-3
+    assert e_dw_g < (1e-3 if shift <= 16 else 1e-2)
+
+
+def test_small_channel_keeps_its_precision_in_the_fused_spade_kernel():
+    """Same question for dsee_spade_fused_fwd, whose V scale is the a-priori bound 100 x max|cat| (about 3 bits more headroom
+    than the measured maximum): beta channel 5 reads only embedding channel 3, which is 2^-20 below the others, and x of that
+    channel equals the batch mean, so out[..., 5] = LeakyReLU(beta_5) alone; held to 1e-3 of its own size vs float64."""
+    from deepsee_amd import lib as L, ops
+    n, h, c, K, ca, small = 1, 64, 64, 128, 128, 2.0 ** -20
+    rows = 2 * c
+    g = torch.Generator().manual_seed(77)
+    cat = torch.rand(n, h, h, K, generator=g)
+    cat[..., 3] *= small
+    x = torch.randn(n, h, h, c, generator=g)
+    mean, invstd = torch.randn(c, generator=g) * 0.3, torch.rand(c, generator=g) + 0.5
+    x[..., 5] = mean[5]
+    wg, wb = torch.randn(c, ca, 3, 3, generator=g) * 0.05, torch.randn(c, ca, 3, 3, generator=g) * 0.05
+    wb[5] = 0.0
+    wb[5, 3] = torch.randn(3, 3, generator=g)
+    idx, prow = ops.packed_perm(c, "cpu")
+    w2a = torch.cat([wg, wb, torch.zeros(1, ca, 3, 3)]).index_select(0, idx).contiguous()
+    b2 = torch.zeros(prow)
+    catn = cat.double().permute(0, 3, 1, 2)
+    gam, bet = F.conv2d(catn, wg.double(), padding=1), F.conv2d(catn, wb.double(), padding=1)
+    xh = (x.double().permute(0, 3, 1, 2) - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    ref = F.leaky_relu(xh * (gam + 1.0) + bet, 0.2)
+    catd, xd = cat.cuda(), x.cuda()
+    ac = ops.tensor_amax(catd)
+    v2 = ops._i16(36 * n * (h // 4) ** 2 * K * 2)
+    L.call("wino43_input_f16x2", catd, v2, n, h, h, K, ac, ops.FUSED_V_BOUND)
+    u, ua = ops._wino_u(w2a.cuda(), rows, ca, False, rows, K, 2)
+    out = torch.empty_like(xd)
+    L.call("spade_fused_fwd", v2, u, ac, ops.FUSED_V_BOUND, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), out, None, n, h, h,
+           c, rows, K, 1, 1.0, 0.2)
+    torch.cuda.synchronize()
+    got = out.cpu().double().permute(0, 3, 1, 2)
+    e5, e_all = rel(got[:, 5], ref[:, 5]), rel(got, ref)
+    print("fused SPADE, embedding channel 2^-20 below the maximum: out[5] %.1e (whole tensor %.1e)" % (e5, e_all))
+    assert float(ref[:, 5].abs().max()) < 1e-4
+    assert e5 < 1e-3 and e_all < 2e-6

@@ -8,7 +8,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench_fp32.json 2> $O/bench_fp32.err
 python bench.py --steps 10 --warmup 3 --dtype fp16 > $O/bench_fp16.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --config guided_8x_256 --no-f32-run --no-cpu-baseline > $O/bench_guided_8x_256.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --config independent_32x_512 --no-f32-run --no-cpu-baseline > $O/bench_independent_32x_512.json 2>/dev/null
-DSEE_BF16X3=1 python bench.py --steps 8 --warmup 2 --no-f32-run --no-cpu-baseline > $O/bench_bf16x3.json 2>/dev/null
+python bench.py --arith bf16x3 --steps 8 --warmup 2 --no-f32-run --no-cpu-baseline > $O/bench_bf16x3.json 2>/dev/null
 python tools/bench_gemm2.py > $O/gemm_shapes_f16x2.txt 2>&1
 BF16X3=1 python tools/bench_gemm2.py > $O/gemm_shapes_bf16x3.txt 2>&1
 for m in 1 2 4 8 16 14; do echo "ablation mask $m"; DSEE_LIB=tools/exp/libabl_$m.so python tools/bench_gemm2.py 2>&1 | grep -E "^conv 512->512 @256.*tile 256|^gamma/beta fwd @256.*tile 256"; done > $O/gemm_ablation.txt
