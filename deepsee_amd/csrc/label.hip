@@ -63,6 +63,66 @@ __global__ __launch_bounds__(256) void onehot_conv_fwd_kernel(const uint8_t* __r
   if (amax) dsee_block_atomic_absmax(amax, vmax);   // (amax is block-uniform; every thread arrives here)
 }
 
+// Same function with the whole tap table [9][L][Co] resident in LDS (<= 150 KB: L = 19..32 classes x 128 channels): the
+// global form is a chain of two dependent loads per tap (label byte -> table row in L2) and ran at 1.1 TB/s of output;
+// here one 1024-thread block per CU copies the table once, walks the pixels with stride gridDim.x and fetches the NEXT
+// pixel's nine labels while it sums the current pixel's rows out of LDS.
+__global__ __launch_bounds__(1024) void onehot_conv_fwd_lds_kernel(const uint8_t* __restrict__ lab,
+                                                                   const float* __restrict__ wt,
+                                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                                   int N, int H, int W, int shift, int R, int Rw, int L,
+                                                                   int Co, int out_ld, int coff, int relu, int onehot_coff,
+                                                                   float* __restrict__ amax, float amax_floor) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  for (int i = threadIdx.x; i < 9 * L * Co / 4; i += 1024)
+    reinterpret_cast<f32x4*>(tab)[i] = reinterpret_cast<const f32x4*>(wt)[i];
+  __syncthreads();
+  const int tpp = Co / 4, ppb = 1024 / tpp;
+  const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
+  const long M = (long)N * R * Rw, stride = (long)gridDim.x * ppb;
+  float vmax = amax_floor;
+  auto labels = [&](long m, int (&r)[9]) {
+    const int w = (int)(m % Rw);
+    const long t = m / Rw;
+    const int h = (int)(t % R), n = (int)(t / R);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      const bool in = hh >= 0 && hh < R && ww >= 0 && ww < Rw;
+      r[tap] = in ? lab_at(lab, n, H, W, shift, hh, ww) : -1;
+    }
+  };
+  if (s < ppb) {
+    const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    long m = (long)blockIdx.x * ppb + s;
+    int cur[9], nxt[9];
+    if (m < M) labels(m, cur);
+    for (; m < M; m += stride) {
+      const bool more = m + stride < M;
+      if (more) labels(m + stride, nxt);
+      f32x4 acc = b;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        if (cur[tap] >= 0) acc += *reinterpret_cast<const f32x4*>(tab + ((size_t)tap * L + cur[tap]) * Co + q * 4);
+      if (relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+      }
+      __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + m * out_ld + coff + q * 4));
+      vmax = fmaxf(vmax, dsee_absmax4(acc));
+      if (onehot_coff >= 0 && q < 8) {   // the 32 one-hot label channels of the same pixel (dsee_label_onehot)
+        f32x4 oh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) oh[k] = (q * 4 + k == cur[4]) ? 1.f : 0.f;
+        *reinterpret_cast<f32x4*>(out + m * out_ld + onehot_coff + q * 4) = oh;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) cur[tap] = nxt[tap];
+    }
+  }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);
+}
+
 __global__ void onehot_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int L) {
   // w [Co][L][3][3] -> wt [9][L][Co]
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,6 +311,23 @@ int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float*
   DSEE_CHECK_ARG(onehot_coff < 0 || (onehot_coff % 4 == 0 && out_ld >= onehot_coff + 32 && Co >= 32 && L <= 32));
   const int R = H >> shift, Rw = W >> shift;
   const long M = (long)N * R * Rw;
+  const size_t lds = (size_t)9 * L * Co * sizeof(float);
+  if (lds <= 150 * 1024 && 1024 % (Co / 4) == 0 && M >= 4096) {
+    static size_t attr_lds = 0;   // (the block also holds 64 bytes of static LDS: ask for what is needed, not for 160 KB)
+    if (lds > attr_lds) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&onehot_conv_fwd_lds_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        DSEE_CHECK_ARG(!"onehot_conv_fwd: cannot reserve the LDS table");
+      }
+      attr_lds = lds;
+    }
+    const int ppb1k = 1024 / (Co / 4);
+    onehot_conv_fwd_lds_kernel<<<(int)min(256L, (M + ppb1k - 1) / ppb1k), 1024, lds, st>>>(
+        lab, table, bias, out, N, H, W, shift, R, Rw, L, Co, out_ld, coff, relu, onehot_coff, amax, amax_floor);
+    DSEE_LAUNCH_CHECK();
+    return DSEE_OK;
+  }
   const int ppb = 256 / (Co / 4);
   onehot_conv_fwd_kernel<<<(int)min(4096L, (M + ppb - 1) / ppb), 256, 0, st>>>(lab, table, bias, out, N, H, W, shift, R,
                                                                                 Rw, L, Co, out_ld, coff, relu, onehot_coff, amax,

@@ -461,6 +461,26 @@ int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps,
   return DSEE_OK;
 }
 
+/* The two halves of dsee_norm_stats as separate calls: several BatchNorms over the SAME tensor (norm_0 and norm_s of a
+ * resblock, architecture.py:98,127) share one pass over x and differ only in the running statistics they update. */
+int dsee_norm_stats_partial(const float* x, int N, int HW, int C, int groups, float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(x && workspace && C % 4 == 0 && C <= 1024 && groups >= 1 && N % groups == 0);
+  RedGeom g = make_geom(N, HW, C, groups);
+  stats_partial_kernel<<<dim3(g.chunks, g.groups), 256, 0, st>>>(x, workspace, g);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_norm_stats_finalize(const float* workspace, int N, int HW, int C, int groups, float eps, float momentum,
+                             float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t st) {
+  DSEE_CHECK_ARG(workspace && mean && invstd && C % 4 == 0 && C <= 1024 && groups >= 1 && N % groups == 0);
+  RedGeom g = make_geom(N, HW, C, groups);
+  stats_finalize_kernel<<<dsee_cdiv((long)g.groups * C, 8), 256, 0, st>>>(workspace, mean, invstd, running_mean,
+                                                                           running_var, g, eps, momentum);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
 /* SyncBN-over-RCCL (option; reference: the DataParallel branch of SynchronizedBatchNorm2d,
  * sync_batchnorm/batchnorm.py:70-145).  dsee_norm_stats_local reduces this rank's shard to local[2][C] = (mean, M2);
  * the caller all-gathers the rows of all ranks (2*C floats each) and dsee_norm_stats_merge folds them in rank order. */

@@ -383,10 +383,28 @@ __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
 }
 
 // dM[xi][t][c] = (A dY A^T)[xi] per 4x4 tile of the output gradient (adjoint of the output transform)
-template <int OUT>
+// SUMS: the passes over dY that accompany this one ride along -- the bias gradient sum_px dY and the gradients of up to two
+// NoiseInjection weights sum_px dY * eps (eps regenerated from its Philox stream, as wino43_output<true> drew it) are
+// accumulated per thread (gridDim.x * 256 is a multiple of C/4: a thread keeps its channel quad for the whole loop), folded
+// per block through LDS and written to part[block][3][C]; chdot_finalize sums the blocks in a fixed order.
+struct DoutSums {
+  float* part;
+  int bias, n0, n1;
+  uint64_t seed0, off0, seed1, off1;
+  const uint64_t* epoch;
+};
+
+template <int OUT, bool SUMS = false>
 __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N,
-                                                          int H, int W, int C, float* __restrict__ amax) {
+                                                          int H, int W, int C, float* __restrict__ amax, DoutSums sm) {
   float vmax = 0.f;
+  f32x4 sb = {0.f, 0.f, 0.f, 0.f}, s0 = sb, s1 = sb;
+  if constexpr (SUMS) {
+    if (sm.epoch) {
+      sm.off0 += *sm.epoch;
+      sm.off1 += *sm.epoch;
+    }
+  }
   __shared__ __attribute__((aligned(16))) float tbuf[OUT == OUT_SPLIT_T ? 4 : 1][16 * 20];
   __shared__ __attribute__((aligned(16))) unsigned lbuf[OUT != OUT_F32 ? 4 : 1][384];
   const int C4 = C / 4, th = H / 4, tw = W / 4;
@@ -408,8 +426,15 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
     for (int j = 0; j < 4; ++j) {
       f32x4 col[4], o[6];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        col[k] = *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + q * 4);
+      for (int k = 0; k < 4; ++k) {
+        const size_t px = ((size_t)n * H + ty * 4 + k) * W + tx * 4 + j;
+        col[k] = *reinterpret_cast<const f32x4*>(dy + px * C + q * 4);
+        if constexpr (SUMS) {
+          sb += col[k];
+          if (sm.n0) s0 += col[k] * philox_normal4(sm.seed0, sm.off0 + (uint64_t)(px * C4 + q));
+          if (sm.n1) s1 += col[k] * philox_normal4(sm.seed1, sm.off1 + (uint64_t)(px * C4 + q));
+        }
+      }
       a6(col, o);
 #pragma unroll
       for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
@@ -431,6 +456,44 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
   }
   if constexpr (OUT == OUT_F32) {
     if (amax) dsee_block_atomic_absmax(amax, vmax);   // (amax is block-uniform)
+  }
+  if constexpr (SUMS) {
+    __shared__ f32x4 red[3][256];
+    red[0][threadIdx.x] = sb;
+    red[1][threadIdx.x] = s0;
+    red[2][threadIdx.x] = s1;
+    __syncthreads();
+    const int per = 256 / C4 > 0 ? 256 / C4 : 1;   // threads of this block that share a channel quad
+    if ((int)threadIdx.x < C4) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        if ((w == 0 && !sm.bias) || (w == 1 && !sm.n0) || (w == 2 && !sm.n1)) continue;
+        f32x4 v = red[w][threadIdx.x];
+        for (int k = 1; k < per; ++k) v += red[w][k * C4 + threadIdx.x];
+        *reinterpret_cast<f32x4*>(sm.part + ((size_t)blockIdx.x * 3 + w) * C + threadIdx.x * 4) = v;
+      }
+    }
+  }
+}
+
+// out_w[c] = sum_blocks part[block][w][c] in a fixed order (blockIdx.y = w; 8 channels x 32 part-lanes per block)
+__global__ __launch_bounds__(256) void dout_sums_finalize_kernel(const float* __restrict__ part, int parts, int C,
+                                                                 float* __restrict__ o0, float* __restrict__ o1,
+                                                                 float* __restrict__ o2) {
+  __shared__ float sv[32][8];
+  const int w = blockIdx.y;
+  float* out = w == 0 ? o0 : (w == 1 ? o1 : o2);
+  if (!out) return;   // (block-uniform)
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  float v = 0.f;
+  if (c < C)
+    for (int p = lane; p < parts; p += 32) v += part[((size_t)p * 3 + w) * C + c];
+  sv[lane][cl] = v;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    for (int l = 1; l < 32; ++l) v += sv[l][cl];
+    out[c] = v;
   }
 }
 
@@ -898,7 +961,30 @@ int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C
 
 int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dM && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_dout_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C, amax);
+  wino43_dout_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C, amax, DoutSums{});
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+constexpr int DOUT_SUMS_GRID = 2048;
+
+size_t dsee_wino43_dout_sums_workspace(int C) { return (size_t)DOUT_SUMS_GRID * 3 * C * sizeof(float); }
+
+/* dsee_wino43_dout + the channel sums that read the same dY (architecture.py:98,111-112,122,127: bias gradient of the
+ * convolution, gradients of the NoiseInjection weights behind it): dbias[c] = sum_px dY, dnoise_k[c] = sum_px dY * eps_k with
+ * eps_k the Philox N(0,1) stream (seed_k, offset_k) dsee_wino43_output drew in the forward pass.  Any of the three outputs
+ * may be NULL.  workspace: dsee_wino43_dout_sums_workspace(C) bytes.  C in {16, 32, ..., 1024} with 256 % (C/4) == 0. */
+int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C, float* amax, float* workspace,
+                          float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0, float* dnoise1, uint64_t seed1,
+                          uint64_t offset1, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dM && workspace && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
+  DSEE_CHECK_ARG(C / 4 <= 256 && 256 % (C / 4) == 0 && (dbias || dnoise0 || dnoise1));
+  const int grid = (int)min((long)DOUT_SUMS_GRID, ((long)N * (H / 4) * (W / 4) * (C / 4) + 255) / 256);
+  DoutSums sm{workspace, dbias != nullptr, dnoise0 != nullptr, dnoise1 != nullptr, seed0, offset0, seed1, offset1,
+              dsee_rng_epoch()};
+  wino43_dout_kernel<OUT_F32, true><<<grid, 256, 0, st>>>(dy, dM, N, H, W, C, amax, sm);
+  DSEE_LAUNCH_CHECK();
+  dout_sums_finalize_kernel<<<dim3(dsee_cdiv(C, 8), 3), 256, 0, st>>>(workspace, grid, C, dbias, dnoise0, dnoise1);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -915,7 +1001,7 @@ int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, in
 int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dM3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
   wino43_dout_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
-      dy, reinterpret_cast<float*>(dM3t), N, H, W, C, nullptr);
+      dy, reinterpret_cast<float*>(dM3t), N, H, W, C, nullptr, DoutSums{});
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

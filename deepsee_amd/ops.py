@@ -468,10 +468,17 @@ def _wgrad_name(mode):
     return "winograd_wgrad_" + {4: "f16_1term", 3: "f16x2"}.get(_wgrad_split(mode), "bf16x3")
 
 
-def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None):
+def _dout_sums_ok(n, nb, cout_s, mode):
+    """The channel sums over dY (bias / noise-weight gradients) can ride in the A dY A^T transform (dsee_wino43_dout_sums)."""
+    return DOUT_SUMS and nb == n and mode != 1 and cout_s // 4 <= 256 and 256 % (cout_s // 4) == 0
+
+
+def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None, sums=None):
     """((V, amax_V), (dM, amax_dM)) of one image chunk for the Winograd-domain weight gradient: fp32 rows (modes 0, 2;
     `v` may be the (V, amax) the forward pass kept, `dm` the (A dY A^T, amax) its producer already wrote) or transposed
-    bf16x3 (mode 1, no maxima)."""
+    bf16x3 (mode 1, no maxima).  `sums`: {"bias": bool, "n0": PhiloxNormal | None, "n1": ...} -- the bias gradient and the
+    NoiseInjection weight gradients of the layer, computed by the pass that transforms dY and returned in the same dict as
+    "dbias" / "dn0" / "dn1"."""
     t = nb * (h // 4) * (wd // 4)
     if mode == 1:
         v, dm = _i16(36 * t * cin_s * 3), _i16(36 * t * cout_s * 3)
@@ -484,9 +491,21 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
         L.call("wino43_input", xc, v[0], nb, h, wd, cin_s, v[1])
     if dm is None:
         dm = (new(36, t, cout_s), amax_slot() if need else None)
-        L.call("wino43_dout", gc, dm[0], nb, h, wd, cout_s, dm[1])
+        if sums:
+            n0, n1 = sums.get("n0"), sums.get("n1")
+            sums["dbias"] = new(cout_s) if sums.get("bias") else None
+            sums["dn0"], sums["dn1"] = (new(cout_s) if n0 is not None else None), (new(cout_s) if n1 is not None else None)
+            ws = scratch(L.lib().dsee_wino43_dout_sums_workspace(cout_s), "doutsums")
+            L.call("wino43_dout_sums", gc, dm[0], nb, h, wd, cout_s, dm[1], ws, sums["dbias"],
+                   sums["dn0"], n0.seed if n0 is not None else 0, n0.offset if n0 is not None else 0,
+                   sums["dn1"], n1.seed if n1 is not None else 0, n1.offset if n1 is not None else 0)
+        else:
+            L.call("wino43_dout", gc, dm[0], nb, h, wd, cout_s, dm[1])
     return v, dm
 
+
+# bias and noise-weight gradients of a Winograd layer inside its A dY A^T pass (False: separate channel_dot passes over dY)
+DOUT_SUMS = True
 
 # data gradient in the adjoint form from the dM = A dY A^T the weight gradient needs anyway (False: transform dy
 # a second time with B^T . B and run the rotated-kernel convolution)
@@ -517,7 +536,7 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
     return dx
 
 
-def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None):
+def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None, sums=None):
     """dw OIHW of conv3x3(x, w) given g = dL/dy, reduced over tiles in the Winograd domain.  `v_fwd`: the (V, amax) of
     x kept by the forward pass (used when the weight gradient takes fp32 operands and runs in one pass).
     `w_for_dx` (the weight): also return dx, computed from the same dM in the adjoint form -> (dw, dx)."""
@@ -535,7 +554,7 @@ def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None
         dx = new(n, h, wd, cin_s) if nb != n else None
     for n0 in range(0, n, nb):
         v, dm = _wino_wgrad_operands(x[n0:n0 + nb], g[n0:n0 + nb], nb, h, wd, cin_s, cout_s, mode,
-                                     v_fwd if (mode == 2 and nb == n) else None)
+                                     v_fwd if (mode == 2 and nb == n) else None, sums=sums)
         dw = new(co, ci, 3, 3)
         with _timed(_wgrad_name(mode), 2.0 * 36 * t * cin_s * cout_s):
             L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci, _wgrad_split(mode), v[1], dm[1])
@@ -610,9 +629,18 @@ class Conv2d(torch.autograd.Function):
         dx = dw = db = dres = None
         fused = (ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                  and _wgrad_mode(geom.Cin, geom.Cout) != 1 and _adjoint_ok(geom.Cout, geom.Cin))
+        sums = None
+        if ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[1]:
+            want = {"bias": bool(ctx.has_bias and ctx.needs_input_grad[2]),
+                    "n0": ctx.noise if (ctx.noise is not None and ctx.needs_input_grad[8]) else None,
+                    "n1": ctx.res_noise if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None}
+            nb_w = _wino_chunk(geom.N, geom.Hi, geom.Wi, max(geom.Cin, geom.Cout))
+            if (want["bias"] or want["n0"] is not None or want["n1"] is not None) and \
+                    _dout_sums_ok(geom.N, nb_w, geom.Cout, _wgrad_mode(geom.Cin, geom.Cout)):
+                sums = want
         if fused:
             # one A dY A^T transform of g serves the weight gradient AND (adjoint form) the data gradient
-            dw, dx = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, w_for_dx=w)
+            dw, dx = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, w_for_dx=w, sums=sums)
         elif ctx.needs_input_grad[0] and ctx.wino:
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
         elif ctx.needs_input_grad[0]:
@@ -631,10 +659,12 @@ class Conv2d(torch.autograd.Function):
             dw = new(co, ci, 3, 3)
             L.call("conv3x3_thin_wgrad", x, g, ws, dw, geom.N, geom.Hi, geom.Wi, geom.Cin, co, ci)
         elif ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
-            dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep)
+            dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, sums=sums)
         elif ctx.needs_input_grad[1]:
             dw = wgrad_raw(x, g, geom, co, ci, kh, kw, amax_cache=getattr(ctx, "amax_cache", None), exact=ctx.exact)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if sums is not None and sums.get("dbias") is not None:
+            db = sums["dbias"][:co]
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = channel_dot(g, None, co).clone()
         if ctx.has_res and ctx.needs_input_grad[3]:
             if ctx.res_sink is not None:
@@ -650,8 +680,11 @@ class Conv2d(torch.autograd.Function):
                    eps.seed, eps.offset)
             return d
 
-        dnw = noise_wgrad(ctx.noise) if (ctx.noise is not None and ctx.needs_input_grad[8]) else None
-        drnw = noise_wgrad(ctx.res_noise) if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None
+        if sums is not None and "dn0" in sums:
+            dnw, drnw = sums["dn0"], sums["dn1"]
+        else:
+            dnw = noise_wgrad(ctx.noise) if (ctx.noise is not None and ctx.needs_input_grad[8]) else None
+            drnw = noise_wgrad(ctx.res_noise) if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None
         return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None, None
 
 
@@ -1138,6 +1171,10 @@ class SyncBNConfig:
 SYNC_BN = None   # set by SRModel / parallel.attach when opt.sync_bn
 
 
+# one statistics pass per tensor, shared by the BatchNorms that normalise it (False: one pass per norm layer)
+SHARE_STATS = True
+
+
 def bn_stats(x, running_mean, running_var, training):
     """(mean, invstd, synced) of the param-free BatchNorm inside SPADE/SEAN."""
     n, h, w, c = x.shape
@@ -1145,11 +1182,19 @@ def bn_stats(x, running_mean, running_var, training):
     if not training:
         L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
         return mean, invstd, None
-    ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
     cfg = SYNC_BN
     if cfg is None:
-        L.call("norm_stats", x, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var, ws)
+        # norm_0 and norm_s of a resblock normalise the same tensor: the partial (mean, M2) rows of the pass over x stay
+        # attached to it, the second layer only folds them (its own running statistics)
+        part = getattr(x, "dsee_stats_part", None)
+        if part is None:
+            part = torch.empty(L.lib().dsee_norm_workspace(n, h * w, c, 1) // 4, dtype=torch.float32, device="cuda")
+            L.call("norm_stats_partial", x, n, h * w, c, 1, part)
+            if SHARE_STATS:
+                x.dsee_stats_part = part
+        L.call("norm_stats_finalize", part, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var)
         return mean, invstd, None
+    ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, 1), "norm")
     from . import parallel
     local = new(2, c)
     L.call("norm_stats_local", x, n, h * w, c, local, ws)

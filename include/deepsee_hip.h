@@ -185,6 +185,15 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
                             float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,
                             const float* amax_dm, hipStream_t stream);
 int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, float* amax, hipStream_t stream);
+/* The same transform with the channel sums that read the same dY riding along: dbias[c] = sum_px dY (bias gradient of the
+ * convolution, architecture.py:98,122) and dnoise_k[c] = sum_px dY * eps_k, the gradients of up to two NoiseInjection
+ * weights (architecture.py:111-112 noise_middle, :127,133-134 noise_skip; normalization.py:289-304) with eps_k the Philox
+ * stream (seed_k, offset_k) dsee_wino43_output drew in the forward pass.  Replaces the separate dsee_channel_dot /
+ * dsee_channel_dot_rng passes over dY.  Any of the three outputs may be NULL (not all); 256 % (C/4) == 0. */
+size_t dsee_wino43_dout_sums_workspace(int C);
+int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C, float* amax, float* workspace,
+                          float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0, float* dnoise1, uint64_t seed1,
+                          uint64_t offset1, hipStream_t stream);
 /* Data gradient from the SAME dM (adjoint form: no second transform of dy): dV = dM x U^T with
  * U^T = dsee_wino43_weights(w, transpose_flip = 2) [36][rows(Cin)][Cout], then dx = sum over tiles of the overlapping
  * 6x6 patches B dV B^T (gather form).  mask != NULL: dx = mask > 0 ? dx : 0 (ReLU backward, like DSEE_ACT_MASK). */
@@ -268,6 +277,12 @@ int dsee_conv2d_wgrad_table(const dsee_conv_geom* g, const float* in, const floa
 size_t dsee_norm_workspace(int N, int HW, int C, int groups);
 int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps, float momentum, float* mean,
                     float* invstd, float* running_mean, float* running_var, float* workspace, hipStream_t stream);
+/* The same in two calls, for several BatchNorms over the SAME tensor (norm_0 and norm_s of a SPADE resblock both normalise
+ * the block input, architecture.py:98,127): one pass over x into `workspace` (dsee_norm_workspace bytes, caller keeps it),
+ * then one finalize per norm layer (own running statistics). */
+int dsee_norm_stats_partial(const float* x, int N, int HW, int C, int groups, float* workspace, hipStream_t stream);
+int dsee_norm_stats_finalize(const float* workspace, int N, int HW, int C, int groups, float eps, float momentum,
+                             float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t stream);
 /* SyncBN over RCCL (option `sync_bn`; reference: the DataParallel branch of SynchronizedBatchNorm2d,
  * sync_batchnorm/batchnorm.py:70-145, which sends (sum, ssum) through Python queue pipes to a master GPU and broadcasts
  * mean / inv_std back).  Here every rank reduces its shard to local[2][C] = (mean, M2) (dsee_norm_stats_local), the
