@@ -59,9 +59,13 @@ class FolderDataset:
     BICUBIC for the image, base_dataset.py:92,107), cropped to crop_size at one random position and flipped with
     p = 0.5 in training (the flip itself happens on the device)."""
 
-    def __init__(self, opt, label_dir, image_dir, seed=0, no_flip=False):
+    def __init__(self, opt, label_dir, image_dir, seed=0, no_flip=None):
         from PIL import Image  # noqa: F401  (fail here, not in a worker)
-        self.opt, self.no_flip = opt, no_flip
+        mode = getattr(opt, "preprocess_mode", "resize_and_crop")
+        if mode != "resize_and_crop":     # (base_dataset.py:76-104 also knows scale_width*, fixed, none: not restated here)
+            raise ValueError("FolderDataset implements preprocess_mode='resize_and_crop' only, got %r" % (mode,))
+        self.opt = opt
+        self.no_flip = bool(getattr(opt, "no_flip", False)) if no_flip is None else bool(no_flip)
         self.rng = random.Random(seed)
         labels = {os.path.splitext(f)[0]: os.path.join(label_dir, f) for f in sorted(os.listdir(label_dir))
                   if f.lower().endswith(IMG_EXT)}
@@ -82,7 +86,10 @@ class FolderDataset:
         y = self.rng.randint(0, max(0, opt.load_size - opt.crop_size))
         flip = int(self.rng.random() > 0.5) if (opt.isTrain and not self.no_flip) else 0
         box = (x, y, x + opt.crop_size, y + opt.crop_size)
-        lab = Image.open(lp).resize((opt.load_size, opt.load_size), Image.NEAREST).crop(box)
+        lab = Image.open(lp)
+        if lab.mode not in ("L", "P"):
+            raise ValueError("%s: label maps are single-channel class-index images, got mode %r" % (lp, lab.mode))
+        lab = lab.resize((opt.load_size, opt.load_size), Image.NEAREST).crop(box)
         img = Image.open(ip).convert("RGB").resize((opt.load_size, opt.load_size), Image.BICUBIC).crop(box)
         return {"label": np.asarray(lab, dtype=np.uint8), "image": np.asarray(img, dtype=np.uint8), "flip": flip,
                 "path": ip}

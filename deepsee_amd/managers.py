@@ -168,7 +168,9 @@ class TrainerManager(BaseManager):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             ops.begin_capture()
-            with torch.cuda.graph(g, pool=self._pool):
+            # thread-local capture mode: RCCL's watchdog thread (event queries, in a data-parallel run) must not
+            # invalidate a capture in progress on this thread
+            with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
                 losses, generated = step_fn(sd, pinned=pinned, opt_step=not multi)
             ops.begin_capture()                   # (pools created on the capture stream belong to the graph)
             noise.step, noise.offset = state      # the capture ran the Python side once; the replay below is the real step

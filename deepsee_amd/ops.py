@@ -190,7 +190,7 @@ def tensor_amax(t, cache=None):
     the weight gradient both read dy, the forward conv and the weight gradient both read x): one pass per tensor."""
     if getattr(t, "dsee_amax", None) is not None:      # carried by its producer (spectral-norm group launch)
         return t.dsee_amax
-    key = (t.data_ptr(), t.numel())
+    key = (t.data_ptr(), t.numel(), t._version)
     if cache is not None and key in cache:
         return cache[key]
     a = amax_slot()
@@ -692,13 +692,21 @@ class GradSink:
     """One-slot mailbox between two autograd nodes of a resblock: the convolution that consumes `x` as its residual puts
     the residual's gradient here instead of returning it, and the backward of the normalisation that ALSO consumes `x`
     (it runs later: its own incoming gradient depends on that convolution's data gradient) adds it to its dx in the
-    same pass -- the autograd engine's separate fan-in addition (3 full-tensor passes) never runs."""
+    same pass -- the autograd engine's separate fan-in addition (3 full-tensor passes) never runs.
+
+
+    A sink lives for ONE forward/backward pair (the resblock creates a new one per forward) and only full backward passes
+    are supported: a partial backward that runs the convolution's node but not the norm's (torch.autograd.grad with
+    `inputs=` restricted to the convolution's weight) would drop the shortcut gradient -- `put` refuses a second gradient
+    instead of silently overwriting the first."""
 
     def __init__(self):
         self.g = None
 
     def put(self, g):
-        assert self.g is None, "gradient sink not drained (backward re-entered?)"
+        if self.g is not None:
+            raise RuntimeError("GradSink holds a gradient nobody took: the previous backward pass did not reach the "
+                               "normalisation that consumes it (partial backward passes are not supported)")
         self.g = g
 
     def take(self):

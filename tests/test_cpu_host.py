@@ -404,6 +404,17 @@ def test_device_input_pipeline_host_side(tmp_path):
     # the crop is the same window of the NEAREST-resized label and the BICUBIC-resized image
     full = np.asarray(Image.open(str(tmp_path / "lab" / "1.png")).resize((40, 40), Image.NEAREST))
     assert any(np.array_equal(it["label"], full[y:y + 32, x:x + 32]) for y in range(9) for x in range(9))
+    # options: opt.no_flip is honoured (an explicit argument overrides it), unsupported preprocess modes and multi-channel
+    # label files are refused instead of silently mis-handled
+    import pytest
+    assert all(D.FolderDataset(make_opt(start_size=4, crop_size=32, load_size=40, no_flip=True), str(tmp_path / "lab"),
+                               str(tmp_path / "img"), seed=s_)[0]["flip"] == 0 for s_ in range(6))
+    assert any(D.FolderDataset(opt, str(tmp_path / "lab"), str(tmp_path / "img"), seed=s_)[0]["flip"] == 1 for s_ in range(6))
+    with pytest.raises(ValueError):
+        D.FolderDataset(make_opt(start_size=4, crop_size=32, load_size=40, preprocess_mode="scale_width"),
+                        str(tmp_path / "lab"), str(tmp_path / "img"))
+    with pytest.raises(ValueError):
+        D.FolderDataset(opt, str(tmp_path / "img"), str(tmp_path / "img"))[0]     # RGB files as label maps
     # sharding: two ranks, disjoint and equally long
     l0 = D.DeviceLoader(ds, opt, shard=(0, 2), seed=5)
     l1 = D.DeviceLoader(ds, opt, shard=(1, 2), seed=5)

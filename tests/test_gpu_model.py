@@ -482,6 +482,50 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
     assert float((plain[1] - dp[1]).abs().mean()) <= 2e-5
 
 
+def test_hip_graphs_with_rccl_group_world1():
+    """The data-parallel step as bench.py --gpus N runs it -- forward + backward + gradient gather replayed as a hipGraph,
+    then the chunked RCCL all-reduce and the per-chunk Adam launches issued eagerly -- on a 1-rank RCCL group (every
+    collective is the identity): capture has to work while RCCL's watchdog thread is alive, and five iterations (eager,
+    capture, three replays) must track the same model stepped eagerly without a process group."""
+    import socket
+    import torch.distributed as dist
+    from deepsee_amd import parallel
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt
+    over = dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8)
+    batch = O.synthetic_batch(O.make_opt(**over), 2, seed=17)
+
+    def steps(tm):
+        out = []
+        for _ in range(5):
+            tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
+            tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
+            out.append({k: float(v) for k, v in tm.get_latest_losses().items()})
+        torch.cuda.synchronize()
+        return out, tm.optimizer_G.flat.detach().cpu().clone(), tm.optimizer_D.flat.detach().cpu().clone()
+
+    plain = steps(TrainerManager(make_opt(seed=5, **over)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        tm = TrainerManager(make_opt(seed=5, hip_graphs=True, **over))
+        parallel.attach(tm, 1, chunk_mb=0.25, force=True)
+        assert tm.use_graphs and tm.optimizer_G.reduce_hook.active
+        dp = steps(tm)
+        stats = dict(tm.graph_stats)
+    finally:
+        dist.destroy_process_group()
+    assert stats["captured"] >= 2 and stats["replayed"] >= 4, stats
+    for it, (a, b) in enumerate(zip(plain[0], dp[0])):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (it, k, a[k], b[k])
+    for x, y in ((plain[1], dp[1]), (plain[2], dp[2])):
+        assert float((x - y).abs().max()) <= 2.5 * 5 * 4e-4           # beta1 = 0 Adam: <= lr per step and element
+        assert float((x - y).abs().mean()) <= 5e-5
+
+
 def _two_gpu_worker(rank, world, port, sync_bn, q):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
