@@ -86,6 +86,60 @@ __device__ __forceinline__ void dsee_block_atomic_absmax(float* amax, float v) {
   }
 }
 
+// BatchNorm statistics in a producer's epilogue (sync_batchnorm/batchnorm.py:65-68): a kernel whose threads keep
+// one channel quad for their whole grid-stride loop (gridDim.x * 256 a multiple of C/4) accumulates shifted sums of what it
+// stores, and the block writes ONE row (count, mean, M2) x C to part[blockIdx.x][3][C]; dsee_norm_stats_finalize_parts
+// folds the rows with Chan's update in block order.  Deterministic: fixed order inside the thread, the block and the fold.
+constexpr int DSEE_STATS_ROWS_MAX = 1024;
+struct DseeStatsAcc {
+  f32x4 shift, a0, a1;
+  float n;
+  __device__ __forceinline__ void init() {
+    shift = a0 = a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    n = 0.f;
+  }
+  __device__ __forceinline__ void add(const f32x4& v) {
+    if (n == 0.f) shift = v;
+    const f32x4 d = v - shift;
+    a0 += d;
+    a1 += d * d;
+    n += 1.f;
+  }
+  // every thread of the 256-thread block must call this (C/4 <= 256, 256 % (C/4) == 0)
+  __device__ __forceinline__ void flush(float* __restrict__ part, int C) {
+    __shared__ f32x4 st_mean[256], st_m2[256];
+    __shared__ float st_n[256];
+    f32x4 mean = shift, m2 = {0.f, 0.f, 0.f, 0.f};
+    if (n > 0.f) {
+      mean = shift + a0 / n;
+      m2 = a1 - a0 * a0 / n;
+    }
+    st_mean[threadIdx.x] = mean;
+    st_m2[threadIdx.x] = m2;
+    st_n[threadIdx.x] = n;
+    __syncthreads();
+    const int C4 = C / 4, per = 256 / C4;
+    if ((int)threadIdx.x < C4) {
+      float nn = n;
+      for (int k = 1; k < per; ++k) {
+        const int j = k * C4 + threadIdx.x;
+        const float nb = st_n[j];
+        if (nb > 0.f) {
+          const f32x4 d = st_mean[j] - mean;
+          const float nt = nn + nb;
+          mean += d * (nb / nt);
+          m2 += st_m2[j] + d * d * (nn * nb / nt);
+          nn = nt;
+        }
+      }
+      float* o = part + (size_t)blockIdx.x * 3 * C + threadIdx.x * 4;
+      *reinterpret_cast<f32x4*>(o) = (f32x4){nn, nn, nn, nn};
+      *reinterpret_cast<f32x4*>(o + C) = mean;
+      *reinterpret_cast<f32x4*>(o + 2 * C) = m2;
+    }
+  }
+};
+
 // the maximum (all 64 lanes of the calling wave must be active; every lane gets the value)
 __device__ __forceinline__ float dsee_amax_read(const float* amax) {
   float v = amax[(threadIdx.x & 63) * DSEE_AMAX_STRIDE];

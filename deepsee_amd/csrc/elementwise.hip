@@ -386,11 +386,15 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* __restrict__ out, 
 
 // same as up_noise_fwd_kernel with eps = the Philox N(0,1) stream (seed, offset + element/4) generated in registers:
 // identical values to dsee_rng_fill(..., seed, offset, normal = 1) followed by the tensor form, without the tensor
+template <bool STATS>
 __global__ __launch_bounds__(256) void up_noise_rng_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nw,
                                                                float* __restrict__ y, int N, int H, int W, int C, int ups,
                                                                uint64_t seed, uint64_t offset,
-                                                               const uint64_t* __restrict__ epoch) {
+                                                               const uint64_t* __restrict__ epoch,
+                                                               float* __restrict__ stats_part) {
   if (epoch) offset += *epoch;
+  DseeStatsAcc sa;
+  sa.init();
   const long total4 = (long)N * H * W * C / 4;
   const int C4 = C / 4, h0 = H >> ups, w0 = W >> ups;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -402,7 +406,9 @@ __global__ __launch_bounds__(256) void up_noise_rng_fwd_kernel(const float* __re
     f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * h0 + (h >> ups)) * w0 + (w >> ups)) * C + q * 4);
     v += *reinterpret_cast<const f32x4*>(nw + q * 4) * philox_normal4(seed, offset + (uint64_t)i);
     *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    if constexpr (STATS) sa.add(v);
   }
+  if constexpr (STATS) sa.flush(stats_part, C);
 }
 
 // part[blk][C] = sum_pixels a * eps(seed, offset)   (gradient of the noise weights without the eps tensor)
@@ -437,7 +443,22 @@ extern "C" {
 int dsee_upsample_noise_rng_fwd(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
                                 uint64_t seed, uint64_t offset, hipStream_t st) {
   DSEE_CHECK_ARG(x && y && noise_w && C % 4 == 0);
-  up_noise_rng_fwd_kernel<<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset, dsee_rng_epoch());
+  up_noise_rng_fwd_kernel<false><<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset,
+                                                                                 dsee_rng_epoch(), nullptr);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* the same pass, also writing the BatchNorm statistics rows of y (the next layer is the param-free BatchNorm of a SPADE/SEAN
+ * norm, architecture.py:98 -> normalization.py:107): stats_part [dsee_stats_part_rows(N*H*W*C/4)][3][C], folded by
+ * dsee_norm_stats_finalize_parts.  256 % (C/4) == 0. */
+int dsee_upsample_noise_rng_fwd_stats(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
+                                      uint64_t seed, uint64_t offset, float* stats_part, hipStream_t st) {
+  DSEE_CHECK_ARG(x && y && noise_w && stats_part && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
+  const long items = (long)N * H * W * C / 4;
+  const int grid = (int)min((long)DSEE_STATS_ROWS_MAX, (items + 255) / 256);
+  up_noise_rng_fwd_kernel<true><<<grid, 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset, dsee_rng_epoch(),
+                                                      stats_part);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

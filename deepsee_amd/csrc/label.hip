@@ -131,9 +131,9 @@ __global__ void onehot_pack_kernel(const float* __restrict__ w, float* __restric
   wt[i] = w[((size_t)co * L + r) * 9 + tap];
 }
 
-// Weight gradient of the one-hot conv.  Block = 128 channels x 2 tap groups; each thread owns its channel's
+// Weight gradient of the one-hot conv.  Block = 128 channels x 8 tap groups; each thread owns its channel's
 // accumulator column in LDS ([9*L][128] floats), so no atomics and a fixed summation order.
-__global__ __launch_bounds__(256) void onehot_conv_wgrad_kernel(const uint8_t* __restrict__ lab,
+__global__ __launch_bounds__(1024) void onehot_conv_wgrad_kernel(const uint8_t* __restrict__ lab,
                                                                 const float* __restrict__ dact, int dld,
                                                                 const float* __restrict__ act, int ald, int N,
                                                                 int H, int W, int shift, int R, int Rw, int L,
@@ -141,11 +141,13 @@ __global__ __launch_bounds__(256) void onehot_conv_wgrad_kernel(const uint8_t* _
   extern __shared__ float accs[];  // [9*L + 1][128]   (last row: bias gradient)
   const int c = threadIdx.x & 127, tg = threadIdx.x >> 7;
   const int rows = 9 * L + 1;
-  for (int i = threadIdx.x; i < rows * 128; i += 256) accs[i] = 0.f;
+  for (int i = threadIdx.x; i < rows * 128; i += 1024) accs[i] = 0.f;
   __syncthreads();
   const long M = (long)N * R * Rw;
   const long m0 = (long)blockIdx.x * chunk_px, m1 = min(M, m0 + chunk_px);
-  const int t0 = tg == 0 ? 0 : 5, t1 = tg == 0 ? 5 : 9;
+  // 8 tap groups x 128 channels (16 waves per CU: the loop is a chain of dependent global -> LDS operations and one block
+  // fills a CU's LDS; with 2 groups = 4 waves it ran at 1.1 TB/s): group g owns tap g, group 7 taps 7 and 8, group 0 the bias
+  const int t0 = tg, t1 = tg == 7 ? 9 : tg + 1;
   // 8 pixels per trip: the global loads of a trip are issued together (the loop is latency-bound otherwise) and
   // the LDS updates are fire-and-forget ds_add_f32 (each address is owned by exactly one thread, program order kept)
   constexpr int U = 8;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void onehot_conv_wgrad_kernel(const uint8_t* _
   }
   __syncthreads();
   float* o = part + (size_t)blockIdx.x * rows * 128;
-  for (int i = threadIdx.x; i < rows * 128; i += 256) o[i] = accs[i];
+  for (int i = threadIdx.x; i < rows * 128; i += 1024) o[i] = accs[i];
 }
 
 __global__ void onehot_wgrad_finalize_kernel(const float* __restrict__ part, int nparts, int L, float* __restrict__ dw,
@@ -356,10 +358,10 @@ int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, int dact_ld
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&onehot_conv_wgrad_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (9 * 32 + 1) * 128 * (int)sizeof(float));
     attr_done = true;
   }
-  onehot_conv_wgrad_kernel<<<parts, 256, lds, st>>>(lab, dact, dact_ld, act, act_ld, N, H, W, shift, R, Rw, L, cp,
+  onehot_conv_wgrad_kernel<<<parts, 1024, lds, st>>>(lab, dact, dact_ld, act, act_ld, N, H, W, shift, R, Rw, L, cp,
                                                     workspace);
   DSEE_LAUNCH_CHECK();
   onehot_wgrad_finalize_kernel<<<dsee_cdiv((long)(9 * L + 1) * 128, 256), 256, 0, st>>>(workspace, parts, L, dw_oihw,

@@ -131,6 +131,50 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   }
 }
 
+// Fold of the (count, mean, M2) rows a producer kernel wrote (DseeStatsAcc::flush): block = 4 channels x 64 row-lanes, lane l
+// merges rows l, l+64, ... then lane 0 merges the lanes in order (fixed order: bit-reproducible).
+__global__ __launch_bounds__(256) void stats_finalize_parts_kernel(const float* __restrict__ part, int rows, int C,
+                                                                   float* __restrict__ mean_out,
+                                                                   float* __restrict__ invstd_out,
+                                                                   float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                   float eps, float momentum) {
+  __shared__ float sn[64][4], sm[64][4], s2[64][4];
+  const int cl = threadIdx.x & 3, lane = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  const bool ok = c < C;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (ok)
+    for (int k = lane; k < rows; k += 64) {
+      const float* r = part + (size_t)k * 3 * C + c;
+      const float nb = r[0];
+      if (nb == 0.f) continue;
+      const float d = r[C] - mean, nt = n + nb;
+      mean += d * nb / nt;
+      m2 += r[2 * C] + d * d * n * nb / nt;
+      n = nt;
+    }
+  sn[lane][cl] = n;
+  sm[lane][cl] = mean;
+  s2[lane][cl] = m2;
+  __syncthreads();
+  if (lane != 0 || !ok) return;
+  for (int l = 1; l < 64; ++l) {
+    const float nb = sn[l][cl];
+    if (nb == 0.f) continue;
+    const float d = sm[l][cl] - mean, nt = n + nb;
+    mean += d * nb / nt;
+    m2 += s2[l][cl] + d * d * n * nb / nt;
+    n = nt;
+  }
+  const float var = m2 / n;  // biased
+  mean_out[c] = mean;
+  invstd_out[c] = 1.0f / sqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+  }
+}
+
 // SyncBN over RCCL, forward half 1: this rank's shard reduced to ONE (mean, M2) row pair per channel (same fixed-order
 // Chan merge as stats_finalize_kernel, no eps / running statistics) -- the 2*C floats that travel.
 __global__ __launch_bounds__(256) void stats_local_kernel(const float* __restrict__ part, float* __restrict__ local,
@@ -477,6 +521,19 @@ int dsee_norm_stats_finalize(const float* workspace, int N, int HW, int C, int g
   RedGeom g = make_geom(N, HW, C, groups);
   stats_finalize_kernel<<<dsee_cdiv((long)g.groups * C, 8), 256, 0, st>>>(workspace, mean, invstd, running_mean,
                                                                            running_var, g, eps, momentum);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* Rows (count, mean, M2) x C written by a producer's epilogue (dsee_upsample_noise_rng_fwd_stats, dsee_wino43_output_stats):
+ * rows = dsee_stats_part_rows(work items of the producer). */
+int dsee_stats_part_rows(long items) { return (int)min((long)DSEE_STATS_ROWS_MAX, (items + 255) / 256); }
+
+int dsee_norm_stats_finalize_parts(const float* part, int rows, int C, float eps, float momentum, float* mean,
+                                   float* invstd, float* running_mean, float* running_var, hipStream_t st) {
+  DSEE_CHECK_ARG(part && mean && invstd && rows >= 1 && C % 4 == 0 && C <= 1024);
+  stats_finalize_parts_kernel<<<dsee_cdiv(C, 4), 256, 0, st>>>(part, rows, C, mean, invstd, running_mean, running_var, eps,
+                                                               momentum);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -499,15 +499,19 @@ __global__ __launch_bounds__(256) void dout_sums_finalize_kernel(const float* __
 
 // noise_w != NULL: y += noise_w[c] * eps with eps = element (pixel, quad) of the Philox N(0,1) stream (seed, offset) --
 // the NoiseInjection that follows the convolution (architecture.py:111-112 noise_middle) without its own pass over y
-template <bool NOISE, typename TM>
-__global__ __launch_bounds__(256) void wino43_output_kernel(const TM* __restrict__ M, const float* __restrict__ bias,
+template <bool NOISE, typename TM, bool STATS = false>
+__global__ __launch_bounds__(256, 2) void wino43_output_kernel(const TM* __restrict__ M, const float* __restrict__ bias,
                                                             const float* __restrict__ res, int res_ld,
                                                             float* __restrict__ y, int N, int H, int W, int C, int act,
                                                             float slope, const float* __restrict__ noise_w,
                                                             uint64_t seed, uint64_t offset,
                                                             const float* __restrict__ res_nw, uint64_t res_seed,
                                                             uint64_t res_offset, const float* __restrict__ mscale,
-                                                            const uint64_t* __restrict__ epoch) {
+                                                            const uint64_t* __restrict__ epoch,
+                                                            float* __restrict__ stats_part = nullptr) {
+  // STATS: shifted sums of what this thread stores (shift = its bias quad: no extra registers for the shift or a counter --
+  // the kernel sits at the 256-VGPR edge of two waves per SIMD)
+  f32x4 sa0 = {0.f, 0.f, 0.f, 0.f}, sa1 = sa0;
   if constexpr (NOISE) {
     if (epoch) {
       offset += *epoch;
@@ -564,8 +568,22 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const TM* __restrict
           if (noise_w) v += nw * philox_normal4(seed, offset + (uint64_t)(px * C4 + q));
         }
         st4b(y + off, v);
+        if constexpr (STATS) {
+          const f32x4 d = v - b;
+          sa0 += d;
+          sa1 += d * d;
+        }
       }
     }
+  }
+  if constexpr (STATS) {
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    DseeStatsAcc sa;
+    sa.shift = bias ? *reinterpret_cast<const f32x4*>(bias + (i0 % C4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sa.a0 = sa0;
+    sa.a1 = sa1;
+    sa.n = i0 < total ? 16.f * (float)((total - i0 + stride - 1) / stride) : 0.f;
+    sa.flush(stats_part, C);
   }
 }
 
@@ -1002,6 +1020,28 @@ int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, i
   DSEE_CHECK_ARG(dy && dM3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
   wino43_dout_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
       dy, reinterpret_cast<float*>(dM3t), N, H, W, C, nullptr, DoutSums{});
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* dsee_wino43_output (fp32 M) that also writes the BatchNorm statistics rows of y for the SPADE/SEAN norm that follows
+ * (architecture.py:98-113: conv_0 -> noise_middle -> norm_1): stats_part [dsee_stats_part_rows(T * C/4)][3][C].
+ * 256 % (C/4) == 0. */
+int dsee_wino43_output_stats(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
+                             int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
+                             uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
+                             uint64_t res_noise_offset, float* stats_part, hipStream_t st) {
+  DSEE_CHECK_ARG(M && y && stats_part && C % 4 == 0 && H % 4 == 0 && W % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
+  DSEE_CHECK_ARG(act != DSEE_ACT_MASK);
+  DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
+  DSEE_CHECK_ARG(!res_noise_w || (residual && residual_ld == C));
+  DSEE_CHECK_ARG((long)N * (H / 4) * (W / 4) * C * 4 < 0xFFFFFFF0L);
+  const long items = (long)N * (H / 4) * (W / 4) * (C / 4);
+  const int grid = (int)min((long)DSEE_STATS_ROWS_MAX, (items + 255) / 256);
+  wino43_output_kernel<true, float, true><<<grid, 256, 0, st>>>(M, bias, residual, residual_ld, y, N, H, W, C, act, slope,
+                                                                noise_w, noise_seed, noise_offset, res_noise_w,
+                                                                res_noise_seed, res_noise_offset, nullptr, dsee_rng_epoch(),
+                                                                stats_part);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -338,7 +338,7 @@ class SPADEResnetBlock(nn.Module):
         shp = (n, h0 << ups, w0 << ups, c)
         res_noise = None
         if noisy:
-            x = ops.UpNoise.apply(x, self.noise_in.weight, noise.normal_nhwc(shp, tag + ".noise_in"), ups)
+            x = ops.UpNoise.apply(x, self.noise_in.weight, noise.normal_nhwc(shp, tag + ".noise_in"), ups, training)
             # the shortcut x_s = noise_skip(x) (architecture.py:133-134) is not materialised: conv_1's output transform
             # adds x + w_skip * eps_skip (a replayed noise TENSOR, as in the parity tests, takes the explicit pass)
             res_noise = (self.noise_skip.weight, noise.normal_nhwc(shp, tag + ".noise_skip"))
@@ -349,7 +349,8 @@ class SPADEResnetBlock(nn.Module):
         h = self.norm_0(x, labels, style, training, sink)
         # noise_middle (architecture.py:111-112) rides in conv_0's output transform
         dx = ops.conv2d(h, self.conv_0.weight(training), self.conv_0.bias,
-                        noise=(self.noise_middle.weight, noise.normal_nhwc(shp, tag + ".noise_middle")) if noisy else None)
+                        noise=(self.noise_middle.weight, noise.normal_nhwc(shp, tag + ".noise_middle")) if noisy else None,
+                        stats=training)
         h = self.norm_1(dx, labels, style, training)
         return ops.conv2d(h, self.conv_1.weight(training), self.conv_1.bias, res=x, act=out_act, res_noise=res_noise,
                           res_sink=sink)

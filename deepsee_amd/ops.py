@@ -422,7 +422,7 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
 
 
 def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=None, act=L.ACT_NONE, res_ld=0, keep=None,
-               noise=None, res_noise=None):
+               noise=None, res_noise=None, stats=False):
     """y = conv3x3(x, w) (transpose_flip: data gradient of that conv) through 36 Winograd-domain GEMMs.
     `keep`: list that receives (V, amax_V) of the input when the whole batch went through in one pass.
     `noise` = (noise_w [r_s], PhiloxNormal of y's shape): y += noise_w * eps in the output transform;
@@ -439,6 +439,12 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
         nz = (None, 0, 0) if noise is None else (noise[0], noise[1].seed, noise[1].offset + n0 * h * wd * r_s // 4)
         rz = ((None, 0, 0) if res_noise is None else
               (res_noise[0], res_noise[1].seed, res_noise[1].offset + n0 * h * wd * r_s // 4))
+        if stats and PRODUCER_STATS and nb == n and ms is None and act != L.ACT_MASK and _stats_rows_ok(r_s):
+            rows = L.lib().dsee_stats_part_rows(C.c_long(nb * (h // 4) * (wd // 4) * (r_s // 4)))
+            part = new(rows, 3, r_s)
+            L.call("wino43_output_stats", m, bias, res, res_ld or r_s, y, nb, h, wd, r_s, act, LRELU_SLOPE, *nz, *rz, part)
+            y.dsee_stats_rows = (part, rows)
+            continue
         L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
                r_s, act, LRELU_SLOPE, *nz, *rz, ms)
     return y
@@ -573,7 +579,7 @@ class Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, res, stride, pad, ups, act, noise_w=None, noise_eps=None, res_noise_w=None,
-                res_noise_eps=None, res_sink=None, exact=False):
+                res_noise_eps=None, res_sink=None, exact=False, stats=False):
         """`exact`: keep a direct convolution on the fp32 MFMA (no operand-maximum passes over its activations)."""
         ctx.exact = bool(exact)
         co, ci, kh, kw = w.shape
@@ -598,7 +604,7 @@ class Conv2d(torch.autograd.Function):
             keep = [] if (KEEP_V and ctx.needs_input_grad[1] and _wgrad_mode(cin_s, cout_s) == 2) else None
             out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act, keep=keep,
                              noise=None if noise_w is None else (noise_w, noise_eps),
-                             res_noise=None if res_noise_w is None else (res_noise_w, res_noise_eps))
+                             res_noise=None if res_noise_w is None else (res_noise_w, res_noise_eps), stats=stats)
             vkeep = keep[0] if keep else None
         else:
             ctx.amax_cache = {}   # max |x| found here is reused by the weight gradient
@@ -685,7 +691,7 @@ class Conv2d(torch.autograd.Function):
         else:
             dnw = noise_wgrad(ctx.noise) if (ctx.noise is not None and ctx.needs_input_grad[8]) else None
             drnw = noise_wgrad(ctx.res_noise) if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None
-        return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None, None
+        return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None, None, None
 
 
 class GradSink:
@@ -762,11 +768,14 @@ def _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
             and noise is None and res_noise is None and x.shape[3] >= 128 and x.shape[3] % 32 == 0)
 
 
-def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, noise=None, res_noise=None, res_sink=None):
+def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, noise=None, res_noise=None, res_sink=None,
+           stats=False):
     """`noise` = (noise_w, eps): the NoiseInjection that follows the conv; `res_noise` = (noise_w, eps): the
     NoiseInjection on the residual (the shortcut x_s = noise_skip(x)).  PhiloxNormal draws on a Winograd layer ride in
     the output transform; anything else (a replayed tensor, a non-Winograd layer) runs as its own UpNoise pass.
-    `res_sink` (GradSink): the residual's gradient is handed to the norm backward instead of the autograd engine."""
+    `res_sink` (GradSink): the residual's gradient is handed to the norm backward instead of the autograd engine.
+    `stats`: the output feeds a training-mode BatchNorm -- a Winograd layer then writes the statistics rows in its output
+    transform (bn_stats finds them on the tensor)."""
     if _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
         co, ci = w.shape[0], w.shape[1]
         w27 = w.permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1)          # row tap*co_n + co (55 KB of parameter glue)
@@ -778,7 +787,7 @@ def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, no
     rn = (None, None) if res_noise is None else res_noise
     if noise is None or (_fusable_noise(x, w, stride, pad, ups, noise[1]) and act == L.ACT_NONE):
         nz = (None, None) if noise is None else noise
-        return Conv2d.apply(x, w, bias, res, stride, pad, ups, act, nz[0], nz[1], rn[0], rn[1], res_sink)
+        return Conv2d.apply(x, w, bias, res, stride, pad, ups, act, nz[0], nz[1], rn[0], rn[1], res_sink, False, bool(stats))
     y = Conv2d.apply(x, w, bias, res, stride, pad, ups, act, None, None, rn[0], rn[1], res_sink)
     return UpNoise.apply(y, noise[0], noise[1], 0)
 
@@ -958,14 +967,22 @@ class UpNoise(torch.autograd.Function):
     """y = nearest_up(x, 2^ups) + w[c] * eps   (eps/w may be None)."""
 
     @staticmethod
-    def forward(ctx, x, noise_w, eps, ups):
+    def forward(ctx, x, noise_w, eps, ups, stats=False):
+        """`stats`: y feeds a training-mode BatchNorm: its statistics rows are written in the same pass."""
         n, h0, w0, c = x.shape
         y = new(n, h0 << ups, w0 << ups, c)
         ctx.philox = eps if isinstance(eps, PhiloxNormal) else None
         if ctx.philox is not None:
             assert eps.shape == tuple(y.shape)
-            L.call("upsample_noise_rng_fwd", x, noise_w, y, n, h0 << ups, w0 << ups, c, ups, C.c_uint64(eps.seed),
-                   C.c_uint64(eps.offset))
+            if stats and PRODUCER_STATS and _stats_rows_ok(c):
+                rows = L.lib().dsee_stats_part_rows(C.c_long(y.numel() // 4))
+                part = new(rows, 3, c)
+                L.call("upsample_noise_rng_fwd_stats", x, noise_w, y, n, h0 << ups, w0 << ups, c, ups, C.c_uint64(eps.seed),
+                       C.c_uint64(eps.offset), part)
+                y.dsee_stats_rows = (part, rows)
+            else:
+                L.call("upsample_noise_rng_fwd", x, noise_w, y, n, h0 << ups, w0 << ups, c, ups, C.c_uint64(eps.seed),
+                       C.c_uint64(eps.offset))
             eps = None
         else:
             L.call("upsample_noise_fwd", x, eps, noise_w if eps is not None else None, y, n, h0 << ups, w0 << ups, c, ups)
@@ -994,7 +1011,7 @@ class UpNoise(torch.autograd.Function):
                    C.c_uint64(ctx.philox.offset))
         elif eps is not None and ctx.needs_input_grad[1]:
             dw = channel_dot(dy, eps, c).clone()
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 # ------------------------------------------------------------------------------------ SPADE/SEAN inputs
@@ -1181,6 +1198,12 @@ SYNC_BN = None   # set by SRModel / parallel.attach when opt.sync_bn
 
 # one statistics pass per tensor, shared by the BatchNorms that normalise it (False: one pass per norm layer)
 SHARE_STATS = True
+# BatchNorm statistics rows written by the kernel that produces the norm's input (False: a statistics pass over x)
+PRODUCER_STATS = True
+
+
+def _stats_rows_ok(c):
+    return SYNC_BN is None and c % 4 == 0 and c // 4 <= 256 and 256 % (c // 4) == 0
 
 
 def bn_stats(x, running_mean, running_var, training):
@@ -1194,6 +1217,11 @@ def bn_stats(x, running_mean, running_var, training):
     if cfg is None:
         # norm_0 and norm_s of a resblock normalise the same tensor: the partial (mean, M2) rows of the pass over x stay
         # attached to it, the second layer only folds them (its own running statistics)
+        rows = getattr(x, "dsee_stats_rows", None)
+        if rows is not None:       # written by x's producer (UpNoise / the Winograd output transform)
+            L.call("norm_stats_finalize_parts", rows[0], rows[1], c, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean,
+                   running_var)
+            return mean, invstd, None
         part = getattr(x, "dsee_stats_part", None)
         if part is None:
             part = torch.empty(L.lib().dsee_norm_workspace(n, h * w, c, 1) // 4, dtype=torch.float32, device="cuda")

@@ -98,6 +98,11 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
                        int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
                        uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
                        uint64_t res_noise_offset, const float* mscale, hipStream_t stream);
+/* The fp32 form with the BatchNorm statistics rows of y written in the same pass (see dsee_norm_stats_finalize_parts). */
+int dsee_wino43_output_stats(const float* M, const float* bias, const float* residual, int residual_ld, float* y, int N,
+                             int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
+                             uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
+                             uint64_t res_noise_offset, float* stats_part, hipStream_t stream);
 int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int transpose_flip, int split,
                         const float* amax_w, hipStream_t stream);
 /* ... of `layers` equally shaped weights in ONE launch (the generator's ten 512 -> 512 convolutions: their normalised
@@ -280,6 +285,15 @@ int dsee_norm_stats(const float* x, int N, int HW, int C, int groups, float eps,
 /* The same in two calls, for several BatchNorms over the SAME tensor (norm_0 and norm_s of a SPADE resblock both normalise
  * the block input, architecture.py:98,127): one pass over x into `workspace` (dsee_norm_workspace bytes, caller keeps it),
  * then one finalize per norm layer (own running statistics). */
+/* BatchNorm statistics from a producer's epilogue (sync_batchnorm/batchnorm.py:65-68 without a pass over x): the kernels
+ * that write a SPADE/SEAN norm's input -- dsee_upsample_noise_rng_fwd_stats (architecture.py:98,127 input of norm_0),
+ * dsee_wino43_output_stats (conv_0 + noise_middle -> norm_1) -- also write rows (count, mean, M2) x C, one per workgroup,
+ * stats_part [dsee_stats_part_rows(items)][3][C] with items = the producer's work items (output float4s resp. tile x channel
+ * quads); dsee_norm_stats_finalize_parts folds them in row order (Chan), writes mean / invstd and updates the running
+ * statistics exactly as dsee_norm_stats does. */
+int dsee_stats_part_rows(long items);
+int dsee_norm_stats_finalize_parts(const float* part, int rows, int C, float eps, float momentum, float* mean,
+                                   float* invstd, float* running_mean, float* running_var, hipStream_t stream);
 int dsee_norm_stats_partial(const float* x, int N, int HW, int C, int groups, float* workspace, hipStream_t stream);
 int dsee_norm_stats_finalize(const float* workspace, int N, int HW, int C, int groups, float eps, float momentum,
                              float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t stream);
@@ -364,6 +378,8 @@ int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise
  * gradient of the noise weights against the regenerated eps (normalization.py:303-304). */
 int dsee_upsample_noise_rng_fwd(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
                                 uint64_t seed, uint64_t offset, hipStream_t stream);
+int dsee_upsample_noise_rng_fwd_stats(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
+                                      uint64_t seed, uint64_t offset, float* stats_part, hipStream_t stream);
 int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* workspace, uint64_t seed, uint64_t offset,
                          hipStream_t stream);
 int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t stream);

@@ -459,6 +459,9 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
         torch.cuda.synchronize()
         return out, tm.optimizer_G.flat.detach().cpu().clone(), tm.optimizer_G.steps()
 
+    # (SyncBN computes its statistics in a pass of its own; the plain run does the same here so that the two runs differ
+    # by the collectives only -- beta1 = 0 Adam turns any rounding difference of step 1 into +-lr differences at step 2)
+    ops.PRODUCER_STATS = False
     plain = steps(TrainerManager(make_opt(seed=3, **over)))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -472,6 +475,7 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
         dp = steps(tm)
     finally:
         ops.SYNC_BN = None
+        ops.PRODUCER_STATS = True
         dist.destroy_process_group()
     for a, b in zip(plain[0], dp[0]):
         for k in a:
@@ -485,8 +489,8 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
 def test_hip_graphs_with_rccl_group_world1():
     """The data-parallel step as bench.py --gpus N runs it -- forward + backward + gradient gather replayed as a hipGraph,
     then the chunked RCCL all-reduce and the per-chunk Adam launches issued eagerly -- on a 1-rank RCCL group (every
-    collective is the identity): capture has to work while RCCL's watchdog thread is alive, and five iterations (eager,
-    capture, three replays) must track the same model stepped eagerly without a process group."""
+    collective is the identity): capture has to work while RCCL's watchdog thread is alive, and eight iterations (eager,
+    capture, replays) must track the same model stepped eagerly without a process group."""
     import socket
     import torch.distributed as dist
     from deepsee_amd import parallel
@@ -497,7 +501,7 @@ def test_hip_graphs_with_rccl_group_world1():
 
     def steps(tm):
         out = []
-        for _ in range(5):
+        for _ in range(8):
             tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
             tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
             out.append({k: float(v) for k, v in tm.get_latest_losses().items()})
@@ -517,12 +521,12 @@ def test_hip_graphs_with_rccl_group_world1():
         stats = dict(tm.graph_stats)
     finally:
         dist.destroy_process_group()
-    assert stats["captured"] >= 2 and stats["replayed"] >= 4, stats
+    assert stats["captured"] >= 2 and stats["replayed"] >= 2, stats   # (every encoder-branch variant: eager, capture, replays)
     for it, (a, b) in enumerate(zip(plain[0], dp[0])):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (it, k, a[k], b[k])
     for x, y in ((plain[1], dp[1]), (plain[2], dp[2])):
-        assert float((x - y).abs().max()) <= 2.5 * 5 * 4e-4           # beta1 = 0 Adam: <= lr per step and element
+        assert float((x - y).abs().max()) <= 2.5 * 8 * 4e-4           # beta1 = 0 Adam: <= lr per step and element
         assert float((x - y).abs().mean()) <= 5e-5
 
 
@@ -667,7 +671,7 @@ def test_half_mode_vs_oracle():
 
 SWITCHES = [("KEEP_V", False), ("ADJOINT_DGRAD", False), ("FUSE_DM", False), ("FUSE_NOISE", False), ("GEMM_AF32", False),
             ("FUSED_NORM", False), ("THIN_GEMM", False), ("GEMM_F16X2", False), ("GEMM_SPLIT", False),
-            ("WINOGRAD_WGRAD", False), ("WINOGRAD_MOD", False), ("CONV_F16X2_MIN_FLOP", 0.0), ("DOUT_SUMS", False), ("SHARE_STATS", False)]
+            ("WINOGRAD_WGRAD", False), ("WINOGRAD_MOD", False), ("CONV_F16X2_MIN_FLOP", 0.0), ("DOUT_SUMS", False), ("SHARE_STATS", False), ("PRODUCER_STATS", False)]
 
 
 def test_kernel_path_switches():
