@@ -47,6 +47,9 @@ struct Gemm3Args {
   long a_slab_bytes, b_slab_bytes;   // distance between consecutive 16-k slabs
   long a_z_bytes, b_z_bytes, c_z_elems;  // batch / split-K index offsets
   int nz;
+  // pre-split fp16x2 A (NT form) / Q (TN form) operands: the producer scaled them with dsee_pow2_scale(bound * *amax) where
+  // bound * max|x| >= max|operand| is known BEFORE the producer runs (dsee_wino43_input_f16x2: bound = 100)
+  float a_bound, b_bound;
 };
 
 // force a value the compiler cannot prove wave-uniform into SGPRs (buffer resources / M0 must be scalar; without this
@@ -368,15 +371,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
 // LDS-DMA as fp32 (64 B per row) into a 2-stage staging area; every wave converts the 32 rows it loaded itself (so only
 // its own vmcnt matters) into the bf16x3 LDS image one slab ahead of the MFMAs: lane = (row, k-half), 8 values ->
 // 3 x 8 bf16 -> the same 6r + c + (r>>4) slot layout the fragments are read from.  B (weights) stays pre-split.
-template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false>
+// APRE: the A operand arrives PRE-SPLIT from its producer (fp16x2 rows [K/16][M][2][16], dsee_wino43_input_f16x2) and
+// travels exactly like B -- LDS-DMA straight into a ring of three split images, no fp32 staging, no conversion pass.
+template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false, bool APRE = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   static_assert(BM / 16 == 2 * NW, "two fp32 A instructions (16 rows each) per wave");
+  static_assert(!APRE || (TERMS == 2 && NW == 8), "pre-split A: fp16x2, ping-pong form only");
   constexpr int SA = I::slots(BM), SB = I::slots(BN);
   constexpr int NB = (SB + 63) / 64;
   constexpr int NIB = (NB + NW - 1) / NW;                // B instructions per wave per slab (last maybe absent)
+  constexpr int NA = (SA + 63) / 64, NIA = (NA + NW - 1) / NW, AST = NA * 1024;   // APRE: A instructions / bytes per stage
   constexpr int F32_STAGE = BM * 64;                     // bytes of one fp32 A stage
   constexpr int IMG = (SA * 16 + 255) / 256 * 256;       // bytes of one split A image
   constexpr int BST = NB * 1024;                         // bytes of one B stage
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   // converted (with one in flight the kernel was bound by bytes-in-flight x latency at ~2.5 TB/s, not by HBM or the
   // matrix cores).  bf16x3 (6-byte images: no LDS left for a third stage) keeps NFS = 2.
   constexpr int NFS = TERMS == 2 ? 3 : 2;
-  constexpr int OFF_IMG = NFS * F32_STAGE, OFF_B = OFF_IMG + 2 * IMG;
+  constexpr int OFF_IMG = APRE ? 0 : NFS * F32_STAGE, OFF_B = APRE ? 3 * AST : OFF_IMG + 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   float sa = 1.f, oscale = 1.f;
   if constexpr (TERMS != 3) {
     const float ama = dsee_amax_read(a.amax_a), amb = dsee_amax_read(a.amax_b);
-    sa = pow2_scale(ama);
+    sa = pow2_scale(APRE ? a.a_bound * ama : ama);
     oscale = 1.f / (sa * pow2_scale(amb));
   }
   if constexpr (C16) {
@@ -415,11 +422,21 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
     oscale *= sm;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.cscale = 1.f / sm;
   }
-  const long arow = (long)a.K * 4;  // bytes per A row
+  const long arow = APRE ? (long)I::ROWB : (long)a.K * 4;  // bytes per A row (APRE: per row and slab)
   // A instruction jj (0,1) of this wave: rows 16*(wave + NW*jj) .. +15, lane -> (row l>>2, 16-byte chunk l&3)
-  unsigned voffa[2], voffb[NIB];
+  unsigned voffa[APRE ? NIA : 2], voffb[NIB];
+  if constexpr (APRE) {
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) voffa[jj] = (unsigned)((16 * (wave + NW * jj) + (lane >> 2)) * arow + (lane & 3) * 16);
+    for (int j = 0; j < NIA; ++j) {
+      const int s = 64 * (wave + NW * j) + lane;
+      voffa[j] = (wave + NW * j < NA && s < SA && s % I::PERIOD != I::PERIOD - 1) ? (unsigned)((s - s / I::PERIOD) * 16)
+                                                                                    : 0xFFFFFFF0u;
+    }
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) voffa[jj] = (unsigned)((16 * (wave + NW * jj) + (lane >> 2)) * arow + (lane & 3) * 16);
+  }
+  const bool has_last_a = wave + NW * (NIA - 1) < NA;  // wave-uniform (APRE)
 #pragma unroll
   for (int j = 0; j < NIB; ++j) {
     const int s = 64 * (wave + NW * j) + lane;
@@ -452,11 +469,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
     bvalid = __builtin_amdgcn_readfirstlane(live ? min(BN, a.N - bn * BN) * I::ROWB : 0);
   };
   auto issue_a = [&](int fstage) {
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lka * 64), 0, avalid, 0x00020000);
+    if constexpr (APRE) {
+      __amdgpu_buffer_rsrc_t ra =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lka * a.a_slab_bytes), 0, avalid, 0x00020000);
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      auto* dst = (__attribute__((address_space(3))) void*)(smem + fstage * F32_STAGE + (wave + NW * jj) * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
+      for (int j = 0; j < NIA; ++j)
+        if (j + 1 < NIA || has_last_a) {
+          auto* dst = (__attribute__((address_space(3))) void*)(smem + OFF_IMG + fstage * AST + (wave + NW * j) * 1024);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[j], 0, 0, 0);
+        }
+    } else {
+      __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lka * 64), 0, avalid, 0x00020000);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + fstage * F32_STAGE + (wave + NW * jj) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
+      }
     }
     if (++lka == nk) {
       lka = 0;
@@ -524,10 +552,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   // which includes A(k+1) -- has landed once at most the younger [A(k+2),] B(k+2), A(k+NFS) remain outstanding:
   // 2 (NFS - 1) + (this wave's B instructions per slab).
   auto wait_own = [&]() {
-    if (has_last)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NFS - 1) + NIB) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NFS - 1) + NIB - 1) : "memory");
+    if constexpr (APRE) {
+      // both operands are requested two slabs ahead: only this wave's A and B instructions of the youngest slab may remain
+      if (has_last && has_last_a)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA + NIB) : "memory");
+      else if (has_last || has_last_a)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA + NIB - 1) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA + NIB - 2) : "memory");
+    } else {
+      if (has_last)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NFS - 1) + NIB) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NFS - 1) + NIB - 1) : "memory");
+    }
   };
 
   f32x16 acc[MT][NT];
@@ -549,14 +587,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   issue_a(0);
   issue_b(1);   // slab 1
   issue_a(1);
-  if constexpr (NFS == 3) issue_a(2);   // slab 2 (A only: one further ahead)
-  if constexpr (NW == 8 && NFS == 3)
+  if constexpr (NFS == 3 && !APRE) issue_a(2);   // slab 2 (A only: one further ahead)
+  if constexpr (APRE)
+    wait_own();   // slab 0 landed (this wave's part; the barrier below publishes it)
+  else if constexpr (NW == 8 && NFS == 3)
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // slabs 0 and 1 landed: the ping-pong loop reads slab 1's fp32 rows
                                                         // at the head of its first interval (only A(2) may be in flight)
   else
     wait_own();   // slab 0 landed (B(1), A(1) may still be in flight)
   asm volatile("" ::: "memory");
-  convert(0, 0);
+  if constexpr (!APRE) convert(0, 0);
   // slab parity (image), fp32 stage of the NEXT slab to convert / of the slab to request, B stage computed / to fill
   int par = 0, fcv = 1, fis = 0, bcur = 0, bnxt = 2, ck = 0;
   long ct = blockIdx.x;
@@ -608,11 +648,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
     for (;;) {
       // ---- L interval: the conversion's fp32 rows (landed a slab ago) are read first, the fragment reads follow behind
       //      them, then the DMA requests, and the conversion arithmetic runs while all those LDS reads return
-      const unsigned char* sa_ = smem + OFF_IMG + par * IMG;
+      const unsigned char* sa_ = smem + OFF_IMG + (APRE ? bcur * AST : par * IMG);
       const unsigned char* sb = smem + OFF_B + bcur * BST;
       u32x4 af[MT][TERMS], bf[NT][TERMS];
       f32x4 cv0, cv1;
-      constexpr bool EARLY = NFS == 3;   // A(k+1) was requested two slabs ago: only B(k+1), A(k+2) are younger
+      constexpr bool EARLY = NFS == 3 && !APRE;   // A(k+1) was requested two slabs ago: only B(k+1), A(k+2) are younger
       if constexpr (EARLY) {
         if (has_last)
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NIB) : "memory");
@@ -641,14 +681,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 #endif
       if constexpr (!(DSEE_GEMM_ABL & 8)) {
         issue_b(bnxt);   // slab k+2
-        issue_a(fis);    // slab k+3, into the fp32 stage this wave converted in its previous L interval
+        issue_a(APRE ? bnxt : fis);    // slab k+3, into the fp32 stage this wave converted in its previous L interval
+                                       // (APRE: slab k+2, into the image stage last read a slab ago)
       }
       __builtin_amdgcn_sched_barrier(0);
       STAMP(tIs)
       wait_own();   // B(k+1) (and, two-stage form, A(k+1)) landed before the barrier that publishes them
       asm volatile("" ::: "memory");
-      if constexpr (!EARLY && !(DSEE_GEMM_ABL & 4)) cv_load(fcv, cv0, cv1);
-      if constexpr (!(DSEE_GEMM_ABL & 4)) cv_store(cv0, cv1, par ^ 1);
+      if constexpr (!APRE) {
+        if constexpr (!EARLY && !(DSEE_GEMM_ABL & 4)) cv_load(fcv, cv0, cv1);
+        if constexpr (!(DSEE_GEMM_ABL & 4)) cv_store(cv0, cv1, par ^ 1);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       STAMP(tCv)
       __builtin_amdgcn_s_barrier();
@@ -992,22 +1035,23 @@ int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false>
+template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false, bool APRE = false>
 int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  constexpr int NB = (I::slots(BN) + 63) / 64;
+  constexpr int NB = (I::slots(BN) + 63) / 64, NA = (I::slots(BM) + 63) / 64;
   constexpr int IMG = (I::slots(BM) * 16 + 255) / 256 * 256;
-  const size_t lds = (size_t)(TERMS == 2 ? 3 : 2) * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
+  const size_t lds = APRE ? (size_t)3 * (NA + NB) * 1024
+                          : (size_t)(TERMS == 2 ? 3 : 2) * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS, C16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS, C16, APRE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN);
   const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);
-  gemm3a_kernel<WM, WN, MT, NT, TERMS, C16><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
+  gemm3a_kernel<WM, WN, MT, NT, TERMS, C16, APRE><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1143,6 +1187,23 @@ int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N
     return launch_gemm3a<2, 4, 4, 2, 2>(a, st);
   }
   return launch_gemm3a<2, 2, 2, 2, 2>(a, st);
+}
+
+/* The same GEMM with the A operand PRE-SPLIT by its producer: A2 [K/16][M][2][16] fp16 = dsee_wino43_input_f16x2's output,
+ * scaled by dsee_pow2_scale(a_bound * *amax_a).  No fp32 staging and no conversion pass inside the kernel (the in-kernel
+ * split of dsee_gemm_f16x2_af32 costs 0.33 of its 1.95 ms at 512 -> 512 @256^2, profiles/r02_gemm_ablation.md).
+ * 256 x 256 tiles only: rows_per_group % 256 == 0 and N % 256 == 0. */
+int dsee_gemm_f16x2_pre(const void* A2, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                        const float* amax_a, float a_bound, const float* amax_b, hipStream_t st) {
+  DSEE_CHECK_ARG(A2 && B2 && C && amax_a && amax_b && a_bound > 0.f && M > 0 && N > 0 && K > 0 && K % 16 == 0);
+  DSEE_CHECK_ARG(rows_per_group % 256 == 0 && M % rows_per_group == 0 && N % 256 == 0 && b_rows >= N);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)A2; a.B = (const unsigned char*)B2; a.C = C;
+  a.amax_a = amax_a; a.amax_b = amax_b; a.a_bound = a_bound;
+  a.M = M; a.N = N; a.K = K; a.ldc = N; a.rows_per_group = rows_per_group;
+  a.a_slab_bytes = M * 64;
+  a.b_group_bytes = (long)b_rows * K * 4; a.b_slab_bytes = (long)b_rows * 64; a.nz = 1;
+  return launch_gemm3a<2, 4, 4, 2, 2, false, true>(a, st);
 }
 
 /* dsee_gemm_bf16x3_tn with both operands left in fp32: P [groups*T][rows_p], Q [groups*T][rows_q] fp32 row-major (the

@@ -375,6 +375,17 @@ def _gemm_name(split):
     return {1: "winograd_gemm_bf16x3", 2: "winograd_gemm_f16x2", 3: "winograd_gemm_f16_1term"}[split]
 
 
+# A operand of a forward Winograd GEMM written pre-split by the input transform (False: fp32 V, split inside the GEMM)
+PRESPLIT_A = True
+FUSED_V_BOUND = 100.0       # |B^T d B| <= 100 max|d| for F(4x4,3x3): scale of a pre-split V from max |input|
+
+
+def _presplit_ok(xc, t, t_g, r_s):
+    """dsee_gemm_f16x2_pre takes 256 x 256 tiles only; below 512 of them the 128 x 128 kernel fills the chip better."""
+    return (PRESPLIT_A and getattr(xc, "dsee_amax", None) is not None and t_g % 256 == 0 and r_s % 256 == 0
+            and (36 * t // 256) * (r_s // 256) >= 512)
+
+
 def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=None, u_amax=None):
     """(M [36][t][r_s], mscale) = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs.
     mscale: None (M is fp32) or the device scalar that rescales the fp16 M of the half-precision mode.
@@ -391,6 +402,14 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
             L.call("gemm_f16_af32", v, u, m, 36 * t, r_s, k_s, t_g, rows, 0, va, u_amax, 1, ms)
         if keep is not None:
             keep.append((v, va))
+    elif split == 2 and keep is None and _presplit_ok(xc, t, t_g, r_s):
+        # the input's maximum is known (written by the kernel that produced it): the transform writes V already split, with
+        # the scale fixed by the bound |B^T d B| <= 100 max|d|, and the GEMM streams it without staging or conversion
+        ax = xc.dsee_amax
+        v2 = _i16(36 * t * k_s * 2)
+        L.call("wino43_input_f16x2", xc, v2, nb, h, wd, k_s, ax, FUSED_V_BOUND)
+        with _timed(_gemm_name(2), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 2)):
+            L.call("gemm_f16x2_pre", v2, u, m, 36 * t, r_s, k_s, t_g, rows, ax, FUSED_V_BOUND, u_amax)
     elif split == 2:
         v, va = new(36, t, k_s), amax_slot()
         L.call("wino43_input", xc, v, nb, h, wd, k_s, va)
@@ -435,7 +454,10 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     y = new(n, h, wd, r_s)
     nb = _wino_chunk(n, h, wd, max(r_s, k_s))
     for n0 in range(0, n, nb):
-        m, ms = _wino_vgemm(x[n0:n0 + nb], nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None, ua)
+        xc = x if nb == n else x[n0:n0 + nb]
+        if nb != n and getattr(x, "dsee_amax", None) is not None:
+            xc.dsee_amax = x.dsee_amax          # (the maximum of the whole batch bounds every chunk)
+        m, ms = _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None, ua)
         nz = (None, 0, 0) if noise is None else (noise[0], noise[1].seed, noise[1].offset + n0 * h * wd * r_s // 4)
         rz = ((None, 0, 0) if res_noise is None else
               (res_noise[0], res_noise[1].seed, res_noise[1].offset + n0 * h * wd * r_s // 4))
@@ -1322,7 +1344,6 @@ class SpadeNormAct(torch.autograd.Function):
 
 # The fused SPADE / SEAN forward (dsee_spade_fused_fwd): fp16x2 operands, K = 128 | 160, whole 64-tile groups per image.
 FUSED_NORM = True
-FUSED_V_BOUND = 100.0    # |B^T d B| <= 100 max|d|: the V scale is known before the transform runs
 
 
 def _fused_norm_ok(n, h, w, c, rows, ld):
@@ -1410,8 +1431,11 @@ class SeanNormTable(torch.autograd.Function):
                 PROFILE_OPERAND_GB += (t // 64) * (rows // 64) * 36 * 2 * 64 * ld * 4.0 / 1e9
             with _timed("spade_fused_fwd", 2.0 * 36 * t * ld * rows,
                         4.0 * 36 * t * ld + 4.0 * n * h * w * c * (3 if need_scale else 2)):
+                hm = amax_slot()     # max |h|: the convolution that consumes h writes its V pre-split with this bound
                 L.call("spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
-                       scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE)
+                       scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE,
+                       hm)
+                out.dsee_amax = hm
             keep = None
             if KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
                 # the weight / table gradient reads the fp32 V as its Q operand

@@ -139,6 +139,12 @@ int dsee_gemm_f16_tn_f32(const float* P, const float* Q, float* C, int groups, l
                          int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
 int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                          int tile, const float* amax_a, const float* amax_b, hipStream_t stream);
+/* ... and with the A operand pre-split by its producer (round 3): A2 [K/16][M][2][16] fp16 written by
+ * dsee_wino43_input_f16x2 with the scale dsee_pow2_scale(a_bound * *amax_a) fixed BEFORE the transform runs (a_bound >= 100
+ * bounds |B^T d B| / max|d|), so the GEMM streams both operands global -> LDS without staging or conversion.  256 x 256
+ * tiles only (rows_per_group % 256 == 0, N % 256 == 0).  Layers: architecture.py:98,122 (forward convolutions). */
+int dsee_gemm_f16x2_pre(const void* A2, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                        const float* amax_a, float a_bound, const float* amax_b, hipStream_t stream);
 int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                            int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
 /* Evaluation metrics on the device: per image PSNR, SSIM and RMSE of `fake` against `real`, both fp32 NHWC
@@ -178,13 +184,15 @@ int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, in
  *        scaled by a power of two known before the transform runs (|B^T d B| <= 100 max|d|; v_bound >= 100)
  *   U2 = dsee_wino43_weights[_table](..., split = 2, amax_u)   [36*groups][K/16][rows][2][16] fp16
  *   h [, scale] = dsee_spade_fused_fwd(...)   K = 128 (SPADE / capped) or 160 (SEAN: 128 + 32 one-hot), rows = 2 C,
- *        C % 32 == 0, (H/4)*(W/4) % 64 == 0, groups = N (per-image style tables) or 1; out_scale may be NULL. */
+ *        C % 32 == 0, (H/4)*(W/4) % 64 == 0, groups = N (per-image style tables) or 1; out_scale may be NULL.
+ *        amax_h (optional, 64-line form, zeroed by the caller): receives max |h| -- the bound the convolution that consumes h
+ *        needs BEFORE its input transform runs (dsee_wino43_input_f16x2 + dsee_gemm_f16x2_pre). */
 int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C, const float* amax_x, float bound,
                             hipStream_t stream);
 int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
                          const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                          float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                         float slope, hipStream_t stream);
+                         float slope, float* amax_h, hipStream_t stream);
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
                             float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,

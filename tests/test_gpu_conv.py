@@ -332,6 +332,36 @@ def test_gemm_f16x2_is_fp32_accurate(groups, tg, n, k, tile, spread):
     assert float(slot.max()) == am_a
 
 
+@pytest.mark.parametrize("groups,tg,n,k,bound", [(3, 256, 256, 160, 1.0), (2, 512, 512, 512, 100.0), (36, 256, 256, 32, 8.0),
+                                                 (1, 8192, 512, 128, 100.0)])
+def test_gemm_f16x2_pre_split_a(groups, tg, n, k, bound):
+    """dsee_gemm_f16x2_pre: the NT GEMM with BOTH operands pre-split (A rows in the layout dsee_wino43_input_f16x2 writes,
+    scaled with a bound known before the producer ran -- `bound` x the true maximum, i.e. log2(bound) bits of headroom
+    given away) against float64: fp32-level accuracy (the two-term split still carries 22 - log2(bound) bits), every launch
+    on NaN-poisoned LDS and bit-identical."""
+    from deepsee_amd import lib as L
+    g = torch.Generator().manual_seed(groups * 100 + k)
+    a = torch.randn(groups * tg, k, generator=g)
+    b = torch.randn(groups, n, k, generator=g)
+    ref = torch.einsum("gtk,gnk->gtn", a.view(groups, tg, k).double(), b.double()).reshape(groups * tg, n)
+    am_a, am_b = float(a.abs().max()), float(b.abs().max())
+    a2 = _split2_rows(a, _pow2_scale(bound * am_a)).cuda()
+    b2 = torch.stack([_split2_rows(b[i], _pow2_scale(am_b)) for i in range(groups)]).cuda()
+    sink = torch.zeros(1, device="cuda")
+    first = None
+    for it in range(3):
+        L.call("selftest_lds_poison", sink)
+        c = torch.full((groups * tg, n), float("nan"), device="cuda")
+        L.call("gemm_f16x2_pre", a2, b2, c, groups * tg, n, k, tg, n, _amax(am_a), float(bound), _amax(am_b))
+        torch.cuda.synchronize()
+        assert torch.isfinite(c).all()
+        first = c.clone() if first is None else first
+        assert torch.equal(c, first)
+    err = ((first.cpu().double() - ref).norm() / ref.norm()).item()
+    print("pre-split A, bound %g: vs f64 %.2e" % (bound, err))
+    assert err < (5e-7 if bound <= 8 else 4e-6)
+
+
 def test_gemm_f16x2_tn_long_chain_accuracy():
     """The 256x256 TN tile keeps ONE fp32 accumulator chain per split (no second level: 128 accumulator registers are
     all a wave has): at the step's longest chain, 4096 tiles per split (512x512 layer at 256^2, bs = 8, split-K 8), on
@@ -525,9 +555,11 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale):
     for it in range(4):
         L.call("selftest_lds_poison", sink)
         out.fill_(float("nan"))
+        hm = ops.amax_slot()
         L.call("spade_fused_fwd", v2, u, ac, 100.0, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), out, sc, n, h, h, c, rows, K,
-               n if per_image else 1, add_one, 0.2)
+               n if per_image else 1, add_one, 0.2, hm)
         torch.cuda.synchronize()
+        assert float(hm.max()) == float(out.abs().max())      # the maximum the consumer's operand scale is built from
         assert torch.isfinite(out).all(), "NaN from a poisoned LDS stage (launch %d)" % it
         if first is None:
             first = out.clone()
@@ -606,7 +638,7 @@ def test_small_channel_keeps_its_precision_in_the_fused_spade_kernel():
     u, ua = ops._wino_u(w2a.cuda(), rows, ca, False, rows, K, 2)
     out = torch.empty_like(xd)
     L.call("spade_fused_fwd", v2, u, ac, ops.FUSED_V_BOUND, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), out, None, n, h, h,
-           c, rows, K, 1, 1.0, 0.2)
+           c, rows, K, 1, 1.0, 0.2, None)
     torch.cuda.synchronize()
     got = out.cpu().double().permute(0, 3, 1, 2)
     e5, e_all = rel(got[:, 5], ref[:, 5]), rel(got, ref)
