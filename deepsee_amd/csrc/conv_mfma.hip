@@ -1530,7 +1530,10 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
     const int sper = wino_sper(T, Cin_s, Cout_s), Kpad = dsee_conv_kpad(1, 1, Cin_s);
     // split == 2: V / dM are the plain fp32 transforms, transposed + split inside the GEMM
     // split == 3: the same with two-term fp16 splits (3 MFMA products), operand scales from max |dM|, max |V|
-    int rc = split == 4   ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
+    // split == 5: V is the pre-split V2 of the forward pass (dsee_wino43_input_f16x2, bound DSEE_WINO_V_BOUND), amax_v = max |x|
+    int rc = split == 5   ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v,
+                                                    DSEE_WINO_V_BOUND, st)
+             : split == 4 ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
              : split == 3 ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
              : split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st)
                           : dsee_gemm_bf16x3_tn(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, st);
@@ -1577,7 +1580,9 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
   if (split) {
     DSEE_CHECK_ARG(rows % 128 == 0);
     const int sper = wino_sper(T / N, ld, rows, N), Kpad = dsee_conv_kpad(1, 1, ld);
-    int rc = split == 4   ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
+    int rc = split == 5   ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v,
+                                                    DSEE_WINO_V_BOUND, st)
+             : split == 4 ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
              : split == 3 ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
              : split == 2 ? dsee_gemm_bf16x3_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st)
                           : dsee_gemm_bf16x3_tn(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, st);

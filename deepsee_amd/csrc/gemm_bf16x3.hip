@@ -794,20 +794,30 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 // pass already computed) left in fp32 in HBM.  A slab is 16 tiles; every wave DMAs, for all 16 of them, the 32 P
 // columns / RB Q columns it owns (whole 128-byte / RB*4-byte pieces) and transposes + splits them itself into the
 // bf16x3 images (rows = channels, 16 t contiguous), again one slab ahead of the MFMAs and with no barrier of its own.
-template <int WM, int WN, int MT, int NT, int FL, int TERMS>
+//
+// QPRE: Q arrives PRE-SPLIT in the layout dsee_wino43_input_f16x2 writes -- V2 [channel slab of 16][all 36 T tile rows][2 terms]
+// [16 channels] fp16 -- i.e. tile-major, the transposed order of what the MFMA needs.  One LDS-DMA instruction moves the 16
+// tiles of a slab for one channel slab (1 KB contiguous), and the fragments -- 8 consecutive TILES of one channel per lane --
+// come straight out of the landed bytes through ds_read_b64_tr_b16 (the LDS transpose read: within a 16-lane group, lanes
+// 4e..4e+3 address tile row e, lane i receives channel i of the 4 x 16 block): no fp32 staging, no conversion, no image for Q.
+// Three raw stages (a slab is read during the iteration that requests the slab two ahead).
+template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false>
 __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   static_assert(BM == 32 * NW, "every wave owns 32 rows of the P tile");
+  static_assert(!QPRE || (TERMS == 2 && BN % 32 == 0), "pre-split Q: fp16x2");
   constexpr int RB = BN / NW;                       // Q rows (channels) owned by a wave
   static_assert(BN % NW == 0 && RB % 4 == 0 && 2 * RB <= 64, "Q rows per wave");
   constexpr int QCH = RB / 4;                       // 16-byte chunks per tile row of a wave's Q piece
-  constexpr int QI = (16 * QCH + 63) / 64;          // Q DMA instructions per wave per slab
+  constexpr int QS = BN / 16;                       // QPRE: channel slabs of the tile = DMA instructions per slab and block
+  constexpr int QI = QPRE ? (QS + NW - 1) / NW : (16 * QCH + 63) / 64;   // Q DMA instructions per wave per slab
   constexpr int SA = I::slots(BM), SB = I::slots(BN);
-  constexpr int IMGA = (SA * 16 + 255) / 256 * 256, IMGB = (SB * 16 + 255) / 256 * 256;
-  constexpr int FA = NW * 2048, FB = NW * QI * 1024;  // bytes of one fp32 stage (P, Q)
-  constexpr int OFF_FB = 2 * FA, OFF_IA = OFF_FB + 2 * FB, OFF_IB = OFF_IA + 2 * IMGA;
+  constexpr int IMGA = (SA * 16 + 255) / 256 * 256, IMGB = QPRE ? 0 : (SB * 16 + 255) / 256 * 256;
+  // bytes of one fp32 stage of P, of one Q stage (QPRE: raw split rows, three stages; else fp32, two stages)
+  constexpr int FA = NW * 2048, FB = QPRE ? QS * 1024 : NW * QI * 1024;
+  constexpr int OFF_FB = 2 * FA, OFF_IA = OFF_FB + (QPRE ? 3 : 2) * FB, OFF_IB = OFF_IA + 2 * IMGA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -826,7 +836,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   float sp = 1.f, sq = 1.f, oscale = 1.f;   // fp16x2: operand scales (exact powers of two), undone in the epilogue
   if constexpr (TERMS != 3) {
     sp = pow2_scale(dsee_amax_read(a.amax_a));
-    sq = pow2_scale(dsee_amax_read(a.amax_b));
+    sq = pow2_scale(QPRE ? a.b_bound * dsee_amax_read(a.amax_b) : dsee_amax_read(a.amax_b));
     oscale = 1.f / (sp * sq);
   }
   const long lda = (long)a.M * 4, ldb = (long)a.N * 4;  // bytes per tile row of P / Q
@@ -834,11 +844,14 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   unsigned voffa[2], voffb[QI];
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) voffa[jj] = (unsigned)((8 * jj + (lane >> 3)) * lda + wave * 128 + (lane & 7) * 16);
+  if constexpr (!QPRE) {
 #pragma unroll
-  for (int j = 0; j < QI; ++j) {
-    const int s = 64 * j + lane;  // (tile s / QCH, chunk s % QCH)
-    voffb[j] = s < 16 * QCH ? (unsigned)((s / QCH) * ldb + wave * RB * 4 + (s % QCH) * 16) : 0xFFFFFFF0u;
+    for (int j = 0; j < QI; ++j) {
+      const int s = 64 * j + lane;  // (tile s / QCH, chunk s % QCH)
+      voffb[j] = s < 16 * QCH ? (unsigned)((s / QCH) * ldb + wave * RB * 4 + (s % QCH) * 16) : 0xFFFFFFF0u;
+    }
   }
+  const bool has_last_q = wave + NW * (QI - 1) < QS;   // QPRE, wave-uniform: this wave issues its last Q instruction
   const int nk = a.K / 16;
 
   long lt = blockIdx.x;
@@ -850,10 +863,20 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     const bool live = lt < ntile;
     decode(live ? lt : (long)blockIdx.x, z, bm, bn);
     pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 4);
-    pb = uniform_ptr(a.B + z * a.b_z_bytes + (long)bn * BN * 4);
     live_bytes_a = __builtin_amdgcn_readfirstlane(live ? (int)min(16 * lda, 0x7FFFFFFFL) : 0);
-    live_bytes_b = __builtin_amdgcn_readfirstlane(live ? (int)min(16 * ldb, 0x7FFFFFFFL) : 0);
+    if constexpr (QPRE) {
+      // instruction j of this wave: channel slab bn * QS + wave + NW * j, the slab's 16 tile rows (64 bytes each)
+      pb = uniform_ptr(a.B + z * a.b_z_bytes);
+#pragma unroll
+      for (int j = 0; j < QI; ++j)
+        voffb[j] = (unsigned)((unsigned long)(bn * QS + wave + NW * j) * (unsigned long)a.b_group_bytes) + lane * 16;
+      live_bytes_b = __builtin_amdgcn_readfirstlane(live ? (int)0xFFFFFFF0u : 0);
+    } else {
+      pb = uniform_ptr(a.B + z * a.b_z_bytes + (long)bn * BN * 4);
+      live_bytes_b = __builtin_amdgcn_readfirstlane(live ? (int)min(16 * ldb, 0x7FFFFFFFL) : 0);
+    }
   };
+  int qnxt = 0;   // QPRE: raw Q stage the next request fills (0, 1, 2, 0, ...)
   auto issue = [&](int fs) {
     __amdgpu_buffer_rsrc_t ra =
         __builtin_amdgcn_make_buffer_rsrc((void*)(pa + lk * a.a_slab_bytes), 0, live_bytes_a, 0x00020000);
@@ -864,10 +887,20 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
       auto* dst = (__attribute__((address_space(3))) void*)(smem + fs * FA + wave * 2048 + jj * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
     }
+    if constexpr (QPRE) {
 #pragma unroll
-    for (int j = 0; j < QI; ++j) {
-      auto* dst = (__attribute__((address_space(3))) void*)(smem + OFF_FB + fs * FB + (wave * QI + j) * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, voffb[j], 0, 0, 0);
+      for (int j = 0; j < QI; ++j)
+        if (j + 1 < QI || has_last_q) {
+          auto* dst = (__attribute__((address_space(3))) void*)(smem + OFF_FB + qnxt * FB + (wave + NW * j) * 1024);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, voffb[j], 0, 0, 0);
+        }
+      qnxt = qnxt == 2 ? 0 : qnxt + 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < QI; ++j) {
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + OFF_FB + fs * FB + (wave * QI + j) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, voffb[j], 0, 0, 0);
+      }
     }
     if (++lk == nk) {
       lk = 0;
@@ -899,7 +932,9 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   auto convert = [&](int fs, int im) {
     conv_item(smem + fs * FA + wave * 2048, 128, lane & 31, lane >> 5, smem + OFF_IA + im * IMGA, 32 * wave + (lane & 31),
               sp);
-    if constexpr (RB == 32) {
+    if constexpr (QPRE) {
+      // nothing to do for Q
+    } else if constexpr (RB == 32) {
       conv_item(smem + OFF_FB + fs * FB + wave * QI * 1024, RB * 4, lane & 31, lane >> 5, smem + OFF_IB + im * IMGB,
                 RB * wave + (lane & 31), sq);
     } else {
@@ -924,19 +959,29 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   const unsigned fb = (unsigned)((I::CH * rb0 + I::pad(rb0) + (lane >> 5)) * 16);
   constexpr int TSTEP = I::TSTEP;
 
+  // everything but this wave's instructions of the youngest requested slab has landed
+  auto wait_slab = [&]() {
+    if (!QPRE || has_last_q)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI - 1) : "memory");
+  };
+  // QPRE: this lane's part of a transpose read -- tile row 8 * (lane >> 5) + ((lane & 15) >> 2) (+ 4 for the second read) of
+  // the slab, channel slab (lane >> 4) & 1 of the 32-column MFMA tile, channels 4 * (lane & 3) .. + 3 of it
+  const unsigned qfrag = (unsigned)(((lane >> 4) & 1) * 1024 + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (lane & 3) * 8);
   load_base();
   issue(0);
   issue(1);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI) : "memory");
+  wait_slab();
   convert(0, 0);
-  int par = 0, ck = 0;
+  int par = 0, ck = 0, qcur = 0;
   long ct = blockIdx.x;
   for (;;) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const unsigned char* sa_ = smem + OFF_IA + par * IMGA;
-    const unsigned char* sb = smem + OFF_IB + par * IMGB;
+    const unsigned char* sb = QPRE ? smem + OFF_FB + qcur * FB : smem + OFF_IB + par * IMGB;
     u32x4 af[MT][TERMS];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -945,8 +990,23 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       u32x4 bf[TERMS];
+      if constexpr (QPRE) {
+        typedef short v4i16 __attribute__((ext_vector_type(4)));
+        const unsigned char* q = sb + (wn * NT + j) * 2048 + qfrag;
 #pragma unroll
-      for (int p = 0; p < TERMS; ++p) bf[p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
+        for (int p = 0; p < TERMS; ++p) {
+          const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q + p * 32));
+          const v4i16 hi =
+              __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q + p * 32 + 256));
+          bf[p] = (u32x4){((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                          ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                          ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                          ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16)};
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) bf[p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
+      }
       if (j == 0) {
         __builtin_amdgcn_sched_barrier(0);
         issue(par);  // fp32 stage `par` was converted one iteration ago by this wave
@@ -956,9 +1016,10 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
       for (int i = 0; i < MT; ++i) mfma_terms<TERMS>(af[i], bf, acc[i][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI) : "memory");
+    wait_slab();
     convert(par ^ 1, par ^ 1);
     par ^= 1;
+    qcur = qcur == 2 ? 0 : qcur + 1;
     ++ck;
     if constexpr (FL > 0) {
       if ((ck & (FL - 1)) == 0 || ck == nk) {
@@ -1056,23 +1117,24 @@ int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int FL, int TERMS>
+template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false>
 int launch_gemm3t(Gemm3Args a, int nz, hipStream_t st) {
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   constexpr int QI = (16 * (BN / NW / 4) + 63) / 64;
   constexpr int IMGA = (I::slots(BM) * 16 + 255) / 256 * 256, IMGB = (I::slots(BN) * 16 + 255) / 256 * 256;
-  const size_t lds = (size_t)2 * NW * 2048 + (size_t)2 * NW * QI * 1024 + 2 * IMGA + 2 * IMGB;
+  const size_t lds = QPRE ? (size_t)2 * NW * 2048 + (size_t)3 * (BN / 16) * 1024 + 2 * IMGA
+                          : (size_t)2 * NW * 2048 + (size_t)2 * NW * QI * 1024 + 2 * IMGA + 2 * IMGB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL, TERMS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   a.nz = nz;
   const long ntile = (a.M / BM) * (a.N / BN) * nz;
   const long slots = gemm3_num_cus();
-  gemm3t_kernel<WM, WN, MT, NT, FL, TERMS><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
+  gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1288,6 +1350,28 @@ int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups,
   // accumulator level: one fp32 chain per split (7e-7 of the result at 4096 tiles per split, a library sgemm: 1.2e-6).
   if (rows_q % 256 == 0 && !(DSEE_GEMM_ABL & 128)) return launch_gemm3t<2, 4, 4, 2, 0, 2>(a, groups * splits, st);
   return launch_gemm3t<4, 2, 2, 2, 16, 2>(a, groups * splits, st);
+}
+
+/* dsee_gemm_f16x2_tn_f32 with the Q operand PRE-SPLIT: Q2 = dsee_wino43_input_f16x2's output [rows_q/16][groups*T][2][16]
+ * fp16 (tile rows of all groups consecutive), scaled by dsee_pow2_scale(q_bound * *amax_x) -- the V a forward GEMM
+ * (dsee_gemm_f16x2_pre, dsee_spade_fused_fwd) already consumed serves the weight gradient, no fp32 copy of V exists. */
+int dsee_gemm_f16x2_tn_qpre(const float* P, const void* Q2, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                            int splits, const float* amax_p, const float* amax_x, float q_bound, hipStream_t st) {
+  DSEE_CHECK_ARG(P && Q2 && C && amax_p && amax_x && q_bound > 0.f && groups > 0 && T % 16 == 0 && rows_p % 256 == 0);
+  DSEE_CHECK_ARG(splits > 0 && (T / 16) % splits == 0 && ldc >= rows_q && (rows_q == 160 || rows_q % 128 == 0));
+  DSEE_CHECK_ARG((long)rows_p * 64 < 0x7FFFFFFFL && (long)(rows_q / 16) * groups * T * 64 < 0xFFFFFFF0L);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)P; a.B = (const unsigned char*)Q2; a.C = C;
+  a.amax_a = amax_p; a.amax_b = amax_x; a.b_bound = q_bound;
+  const long nk = T / 16 / splits;
+  a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p;
+  a.a_slab_bytes = (long)16 * rows_p * 4; a.a_z_bytes = nk * a.a_slab_bytes; a.c_z_elems = (long)rows_p * ldc;
+  a.b_slab_bytes = 16 * 64;                       // 16 tile rows of one channel slab
+  a.b_z_bytes = nk * a.b_slab_bytes;              // z = group * splits + split: (group * T + split * nk * 16) tile rows
+  a.b_group_bytes = (long)groups * T * 64;        // distance between channel slabs
+  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 2, true>(a, groups * splits, st);
+  if (rows_q % 256 == 0) return launch_gemm3t<2, 4, 4, 2, 0, 2, true>(a, groups * splits, st);
+  return launch_gemm3t<4, 2, 2, 2, 16, 2, true>(a, groups * splits, st);
 }
 
 }  // extern "C"

@@ -380,10 +380,11 @@ PRESPLIT_A = True
 FUSED_V_BOUND = 100.0       # |B^T d B| <= 100 max|d| for F(4x4,3x3): scale of a pre-split V from max |input|
 
 
-def _presplit_ok(xc, t, t_g, r_s):
-    """dsee_gemm_f16x2_pre takes 256 x 256 tiles only; below 512 of them the 128 x 128 kernel fills the chip better."""
+def _presplit_ok(xc, t, t_g, r_s, k_s=0, keep=False):
+    """dsee_gemm_f16x2_pre takes 256 x 256 tiles only; below 512 of them the 128 x 128 kernel fills the chip better.
+    `keep`: the weight gradient will read the same V2 (dsee_gemm_f16x2_tn_qpre: 160 or a multiple of 128 columns)."""
     return (PRESPLIT_A and getattr(xc, "dsee_amax", None) is not None and t_g % 256 == 0 and r_s % 256 == 0
-            and (36 * t // 256) * (r_s // 256) >= 512)
+            and (36 * t // 256) * (r_s // 256) >= 512 and (not keep or k_s == 160 or k_s % 128 == 0))
 
 
 def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=None, u_amax=None):
@@ -402,7 +403,7 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
             L.call("gemm_f16_af32", v, u, m, 36 * t, r_s, k_s, t_g, rows, 0, va, u_amax, 1, ms)
         if keep is not None:
             keep.append((v, va))
-    elif split == 2 and keep is None and _presplit_ok(xc, t, t_g, r_s):
+    elif split == 2 and _presplit_ok(xc, t, t_g, r_s, k_s, keep is not None):
         # the input's maximum is known (written by the kernel that produced it): the transform writes V already split, with
         # the scale fixed by the bound |B^T d B| <= 100 max|d|, and the GEMM streams it without staging or conversion
         ax = xc.dsee_amax
@@ -410,6 +411,8 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
         L.call("wino43_input_f16x2", xc, v2, nb, h, wd, k_s, ax, FUSED_V_BOUND)
         with _timed(_gemm_name(2), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 2)):
             L.call("gemm_f16x2_pre", v2, u, m, 36 * t, r_s, k_s, t_g, rows, ax, FUSED_V_BOUND, u_amax)
+        if keep is not None:
+            keep.append((v2, ax, True))      # (pre-split V, max |x|, marker): the weight gradient's Q operand as it is
     elif split == 2:
         v, va = new(36, t, k_s), amax_slot()
         L.call("wino43_input", xc, v, nb, h, wd, k_s, va)
@@ -514,7 +517,9 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
         L.call("wino43_dout_split_t", gc, dm, nb, h, wd, cout_s)
         return (v, None), (dm, None)
     need = GEMM_SPLIT and (GEMM_F16X2 or HALF)   # maxima for the fp16 operand scales
-    if v is None or (need and v[1] is None):
+    if v is not None and len(v) == 3:
+        pass                                     # the forward's pre-split V2 (dsee_wino43_wgrad split = 5)
+    elif v is None or (need and v[1] is None):
         v = (new(36, t, cin_s), amax_slot() if need else None)
         L.call("wino43_input", xc, v[0], nb, h, wd, cin_s, v[1])
     if dm is None:
@@ -585,7 +590,8 @@ def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None
                                      v_fwd if (mode == 2 and nb == n) else None, sums=sums)
         dw = new(co, ci, 3, 3)
         with _timed(_wgrad_name(mode), 2.0 * 36 * t * cin_s * cout_s):
-            L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci, _wgrad_split(mode), v[1], dm[1])
+            L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci,
+                   5 if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
         total = dw if total is None else total.add_(dw)
         if with_dx:
             dxc = _wino_dgrad_from_dm(dm, u_t, nb, h, wd, cout_s, cin_s, rows_t)
@@ -638,14 +644,15 @@ class Conv2d(torch.autograd.Function):
         ctx.noise = noise_eps if noise_w is not None else None
         ctx.res_noise = res_noise_eps if res_noise_w is not None else None
         ctx.res_sink = res_sink
-        ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None, *(vkeep if vkeep else (None, None)))
+        ctx.v_pre = bool(vkeep) and len(vkeep) == 3
+        ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None, *(vkeep[:2] if vkeep else (None, None)))
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, w, out, vk, vk_amax = ctx.saved_tensors
         w.dsee_amax, w.dsee_u = ctx.w_amax, ctx.w_u
-        vkeep = (vk, vk_amax) if vk is not None else None
+        vkeep = ((vk, vk_amax, True) if ctx.v_pre else (vk, vk_amax)) if vk is not None else None
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
@@ -1438,10 +1445,13 @@ class SeanNormTable(torch.autograd.Function):
                 out.dsee_amax = hm
             keep = None
             if KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
-                # the weight / table gradient reads the fp32 V as its Q operand
-                vq = (new(36, t, ld), amax_slot())
-                L.call("wino43_input", cat, vq[0], n, h, w, ld, vq[1])
-                keep = [vq]
+                if PRESPLIT_A:
+                    keep = [(v2, ac, True)]     # the weight / table gradient reads the split V the kernel above consumed
+                else:
+                    # ... or an fp32 V of its own as its Q operand
+                    vq = (new(36, t, ld), amax_slot())
+                    L.call("wino43_input", cat, vq[0], n, h, w, ld, vq[1])
+                    keep = [vq]
         elif nb:
             tpi = (h // 4) * (w // 4)
             kp = L.kpad(1, 1, ld)
@@ -1472,8 +1482,9 @@ class SeanNormTable(torch.autograd.Function):
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
         ctx.cat_ups = cat_ups
         vcat = keep[0] if (nb and keep) else (None, None)
+        ctx.v_pre = len(vcat) == 3
         ctx.w_amax = getattr(w2a, "dsee_amax", None) if has_a else None
-        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, *vcat, actv_low)
+        ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, *vcat[:2], actv_low)
         return out
 
     @staticmethod
@@ -1481,7 +1492,7 @@ class SeanNormTable(torch.autograd.Function):
         x, cat, w2a, out, scale, mean, invstd, vc, vc_amax, actv_low = ctx.saved_tensors
         if w2a is not None:
             w2a.dsee_amax = ctx.w_amax     # (an upper bound: the slot also holds max |style table|)
-        vcat = (vc, vc_amax) if vc is not None else None
+        vcat = ((vc, vc_amax, True) if ctx.v_pre else (vc, vc_amax)) if vc is not None else None
         geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
         n, h, w, c = x.shape
         ld = cat.shape[3]
@@ -1520,10 +1531,10 @@ class SeanNormTable(torch.autograd.Function):
                 with _timed(_wgrad_name(mode), 2.0 * 36 * nb * tpi * ld * rows):
                     if ctx.has_t:
                         L.call("wino43_wgrad_table", v[0], dm[0], wsw, nbytes, dwc, dtable[n0:n0 + nb], nb * tpi, nb, ca,
-                               rows, lab.nc, _wgrad_split(mode), v[1], dm[1])
+                               rows, lab.nc, 5 if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
                     else:
                         L.call("wino43_wgrad", v[0], dm[0], wsw, nbytes, dwc, nb * tpi, ld, rows, rows, NHIDDEN,
-                               _wgrad_split(mode), v[1], dm[1])
+                               5 if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
                 if dwc is not None:
                     dw2a = dwc if dw2a is None else dw2a.add_(dwc)
                 if fused_d:

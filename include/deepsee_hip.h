@@ -140,13 +140,19 @@ int dsee_gemm_f16_tn_f32(const float* P, const float* Q, float* C, int groups, l
 int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                          int tile, const float* amax_a, const float* amax_b, hipStream_t stream);
 /* ... and with the A operand pre-split by its producer (round 3): A2 [K/16][M][2][16] fp16 written by
- * dsee_wino43_input_f16x2 with the scale dsee_pow2_scale(a_bound * *amax_a) fixed BEFORE the transform runs (a_bound >= 100
+ * dsee_wino43_input_f16x2 with the power-of-two scale of a_bound x *amax_a fixed BEFORE the transform runs (a_bound >= 100
  * bounds |B^T d B| / max|d|), so the GEMM streams both operands global -> LDS without staging or conversion.  256 x 256
  * tiles only (rows_per_group % 256 == 0, N % 256 == 0).  Layers: architecture.py:98,122 (forward convolutions). */
 int dsee_gemm_f16x2_pre(const void* A2, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                         const float* amax_a, float a_bound, const float* amax_b, hipStream_t stream);
 int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                            int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
+/* ... and with Q pre-split (round 3): Q2 = the V2 [rows_q/16][groups*T][2][16] fp16 dsee_wino43_input_f16x2 wrote for the
+ * forward pass (power-of-two scale of q_bound x *amax_x); the kernel reads its fragments -- 8 consecutive tiles of a channel --
+ * with ds_read_b64_tr_b16 from the landed rows, so the forward's split V is the weight gradient's operand and no fp32 V is kept.
+ * rows_p % 256 == 0, rows_q == 160 or rows_q % 128 == 0.  Weight gradients of architecture.py:98,122, normalization.py:107-120. */
+int dsee_gemm_f16x2_tn_qpre(const float* P, const void* Q2, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                            int splits, const float* amax_p, const float* amax_x, float q_bound, hipStream_t stream);
 /* Evaluation metrics on the device: per image PSNR, SSIM and RMSE of `fake` against `real`, both fp32 NHWC
  * [N][H][W][Cs] in [-1, 1] (channels 0..2 used).  Replaces MetricsEvaluator.collect_samples' per-sample CPU loop
  * (evaluator/evaluation.py:88-137: util/util.py:72-103 tensor2im quantisation, evaluator/calculate_PSNR_SSIM.py:71-79
@@ -187,6 +193,7 @@ int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, in
  *        C % 32 == 0, (H/4)*(W/4) % 64 == 0, groups = N (per-image style tables) or 1; out_scale may be NULL.
  *        amax_h (optional, 64-line form, zeroed by the caller): receives max |h| -- the bound the convolution that consumes h
  *        needs BEFORE its input transform runs (dsee_wino43_input_f16x2 + dsee_gemm_f16x2_pre). */
+#define DSEE_WINO_V_BOUND 100.0f   /* |B^T d B| <= 100 max|d| for the F(4x4,3x3) input transform */
 int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C, const float* amax_x, float bound,
                             hipStream_t stream);
 int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
@@ -216,7 +223,9 @@ size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
                       long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, const float* amax_v,
                       const float* amax_dm, hipStream_t stream);
-/* split = 3: as split = 2 with two-term fp16 splits (dsee_gemm_f16x2_tn_f32; amax_v / amax_dm = max |V|, max |dM|).
+/* split = 5: V is the PRE-SPLIT fp16x2 transform dsee_wino43_input_f16x2 wrote for the forward pass with bound
+ * DSEE_WINO_V_BOUND (cast to const float*), amax_v = max |x| of the layer input (dsee_gemm_f16x2_tn_qpre).
+ * split = 3: as split = 2 with two-term fp16 splits (dsee_gemm_f16x2_tn_f32; amax_v / amax_dm = max |V|, max |dM|).
  * split = 2: V / dM are the plain fp32 transforms (dsee_wino43_input / dsee_wino43_dout), transposed and split inside
  * dsee_gemm_bf16x3_tn_f32 (Cout_stored % 256 == 0, Cin_stored == 160 or % 128 == 0).
  * split = 1: V / dM are the transposed bf16x3 operands [36][T/16][C][3][16 tiles] written by the two producers below

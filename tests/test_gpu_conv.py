@@ -409,6 +409,36 @@ def test_gemm_f16x2_tn_matches_float64(groups, t, rp, rq, splits):
     assert e2 < 5e-7 and e2 <= 2 * max(e32, e3), (e2, e3, e32)
 
 
+@pytest.mark.parametrize("groups,t,rp,rq,splits,bound", [(2, 1024, 256, 256, 2, 1.0), (3, 512, 256, 160, 1, 100.0),
+                                                         (36, 256, 512, 512, 1, 100.0), (8, 2048, 1024, 160, 4, 8.0)])
+def test_gemm_f16x2_tn_pre_split_q(groups, t, rp, rq, splits, bound):
+    """dsee_gemm_f16x2_tn_qpre: the weight-gradient TN GEMM whose Q operand is the PRE-SPLIT V of the forward pass
+    (dsee_wino43_input_f16x2's layout [rq/16][groups*t][2][16] fp16, tile-major) -- the MFMA fragments (8 consecutive tiles
+    of one channel) come out of ds_read_b64_tr_b16 on the landed bytes.  Against float64, on NaN-poisoned LDS, bit-identical
+    from launch to launch, and against the fp32-Q form on the same data."""
+    from deepsee_amd import lib as L
+    g = torch.Generator().manual_seed(t + rq)
+    p = torch.randn(groups * t, rp, generator=g) * 3.0
+    q = torch.randn(groups * t, rq, generator=g) * 0.02
+    am_p, am_q = float(p.abs().max()), float(q.abs().max())
+    q2 = _split2_rows(q, _pow2_scale(bound * am_q)).cuda()
+    ts = t // splits
+    ref = torch.einsum("ztp,ztq->zpq", p.view(groups * splits, ts, rp).double(), q.view(groups * splits, ts, rq).double())
+    sink = torch.zeros(1, device="cuda")
+    first = None
+    for it in range(3):
+        L.call("selftest_lds_poison", sink)
+        c = torch.full((groups * splits, rp, rq), float("nan"), device="cuda")
+        L.call("gemm_f16x2_tn_qpre", p.cuda(), q2, c, groups, t, rp, rq, rq, splits, _amax(am_p), _amax(am_q), float(bound))
+        torch.cuda.synchronize()
+        assert torch.isfinite(c).all()
+        first = c.clone() if first is None else first
+        assert torch.equal(c, first)
+    err = ((first.cpu().double() - ref).norm() / ref.norm()).item()
+    print("TN with pre-split Q, bound %g: vs f64 %.2e" % (bound, err))
+    assert err < (5e-7 if bound <= 8 else 4e-6)
+
+
 def test_f16x2_special_values():
     """Edges of the operand split: zero operands (scale 1, result exactly 0), values 2^20 below the operand maximum
     (h1 subnormal: absolute error <= 2^-39 of the maximum), huge / tiny magnitudes (the power-of-two scale keeps fp16 in
