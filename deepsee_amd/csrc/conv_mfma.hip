@@ -1531,7 +1531,10 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
     // split == 2: V / dM are the plain fp32 transforms, transposed + split inside the GEMM
     // split == 3: the same with two-term fp16 splits (3 MFMA products), operand scales from max |dM|, max |V|
     // split == 5: V is the pre-split V2 of the forward pass (dsee_wino43_input_f16x2, bound DSEE_WINO_V_BOUND), amax_v = max |x|
-    int rc = split == 5   ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v,
+    // split == 6: dM is pre-split as well (dsee_wino43_dout_f16x2, bound DSEE_WINO_DM_BOUND), amax_dm = max |dY|
+    int rc = split == 6   ? dsee_gemm_f16x2_tn_pqpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm,
+                                                     DSEE_WINO_DM_BOUND, amax_v, DSEE_WINO_V_BOUND, st)
+             : split == 5 ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v,
                                                     DSEE_WINO_V_BOUND, st)
              : split == 4 ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)
              : split == 3 ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v, st)

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void up_noise_fwd_kernel(const float* __restri
 
 // dx[n,h0,w0,c] = sum over the 2^ups x 2^ups block of dy  (+ add)
 __global__ __launch_bounds__(256) void sumpool_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H,
-                                                      int W, int C, int ups) {
+                                                      int W, int C, int ups, float* __restrict__ amax = nullptr) {
+  float vmax = 0.f;
   const int h0 = H >> ups, w0 = W >> ups, C4 = C / 4, f = 1 << ups;
   const long total4 = (long)N * h0 * w0 * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -47,7 +48,9 @@ __global__ __launch_bounds__(256) void sumpool_kernel(const float* __restrict__ 
       for (int b = 0; b < f; ++b)
         v += *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + h * f + a) * W + w * f + b) * C + q * 4);
     *reinterpret_cast<f32x4*>(dx + i * 4) = v;
+    vmax = fmaxf(vmax, dsee_absmax4(v));
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);
 }
 
 // part[blk][C] = sum_pixels a*b  (b optional -> column sums), fixed order
@@ -488,6 +491,14 @@ int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise
 int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dx && C % 4 == 0 && ups >= 1);
   sumpool_kernel<<<egrid((long)N * (H >> ups) * (W >> ups) * C / 4), 256, 0, st>>>(dy, dx, N, H, W, C, ups);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* dsee_sumpool that also writes max |dx| (64-line form): dx is the output gradient of the previous block's conv_1 */
+int dsee_sumpool_amax(const float* dy, float* dx, int N, int H, int W, int C, int ups, float* amax_dx, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dx && amax_dx && C % 4 == 0 && ups >= 1);
+  sumpool_kernel<<<egrid((long)N * (H >> ups) * (W >> ups) * C / 4), 256, 0, st>>>(dy, dx, N, H, W, C, ups, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -43,7 +43,7 @@ struct Gemm3Args {
   int N, K;    // valid columns (= rows of B), reduction length per z (multiple of 16)
   int ldc;     // row stride of C
   long rows_per_group;               // grouped mode: rows m / rows_per_group select the B matrix
-  long b_group_bytes;
+  long b_group_bytes, a_group_bytes;   // (TN forms with pre-split operands: distance between 16-channel slabs)
   long a_slab_bytes, b_slab_bytes;   // distance between consecutive 16-k slabs
   long a_z_bytes, b_z_bytes, c_z_elems;  // batch / split-K index offsets
   int nz;
@@ -801,23 +801,27 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 // come straight out of the landed bytes through ds_read_b64_tr_b16 (the LDS transpose read: within a 16-lane group, lanes
 // 4e..4e+3 address tile row e, lane i receives channel i of the 4 x 16 block): no fp32 staging, no conversion, no image for Q.
 // Three raw stages (a slab is read during the iteration that requests the slab two ahead).
-template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false>
+// PPRE (with QPRE): P = dM2 pre-split by dsee_wino43_dout_f16x2 in the same image -- both operands then go global -> LDS ->
+// transpose read -> MFMA, the kernel converts nothing.
+template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false, bool PPRE = false>
 __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   static_assert(BM == 32 * NW, "every wave owns 32 rows of the P tile");
   static_assert(!QPRE || (TERMS == 2 && BN % 32 == 0), "pre-split Q: fp16x2");
+  static_assert(!PPRE || QPRE, "pre-split P comes with pre-split Q");
   constexpr int RB = BN / NW;                       // Q rows (channels) owned by a wave
   static_assert(BN % NW == 0 && RB % 4 == 0 && 2 * RB <= 64, "Q rows per wave");
   constexpr int QCH = RB / 4;                       // 16-byte chunks per tile row of a wave's Q piece
   constexpr int QS = BN / 16;                       // QPRE: channel slabs of the tile = DMA instructions per slab and block
   constexpr int QI = QPRE ? (QS + NW - 1) / NW : (16 * QCH + 63) / 64;   // Q DMA instructions per wave per slab
   constexpr int SA = I::slots(BM), SB = I::slots(BN);
-  constexpr int IMGA = (SA * 16 + 255) / 256 * 256, IMGB = QPRE ? 0 : (SB * 16 + 255) / 256 * 256;
-  // bytes of one fp32 stage of P, of one Q stage (QPRE: raw split rows, three stages; else fp32, two stages)
-  constexpr int FA = NW * 2048, FB = QPRE ? QS * 1024 : NW * QI * 1024;
-  constexpr int OFF_FB = 2 * FA, OFF_IA = OFF_FB + (QPRE ? 3 : 2) * FB, OFF_IB = OFF_IA + 2 * IMGA;
+  constexpr int IMGA = PPRE ? 0 : (SA * 16 + 255) / 256 * 256, IMGB = QPRE ? 0 : (SB * 16 + 255) / 256 * 256;
+  // bytes of one stage of P (fp32: two stages; PPRE: raw split rows of BM/16 channel slabs, three stages), of one Q stage
+  // (QPRE: raw split rows, three stages; else fp32, two stages)
+  constexpr int FA = PPRE ? (BM / 16) * 1024 : NW * 2048, FB = QPRE ? QS * 1024 : NW * QI * 1024;
+  constexpr int OFF_FB = (PPRE ? 3 : 2) * FA, OFF_IA = OFF_FB + (QPRE ? 3 : 2) * FB, OFF_IB = OFF_IA + 2 * IMGA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -835,15 +839,17 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   };
   float sp = 1.f, sq = 1.f, oscale = 1.f;   // fp16x2: operand scales (exact powers of two), undone in the epilogue
   if constexpr (TERMS != 3) {
-    sp = pow2_scale(dsee_amax_read(a.amax_a));
+    sp = pow2_scale(PPRE ? a.a_bound * dsee_amax_read(a.amax_a) : dsee_amax_read(a.amax_a));
     sq = pow2_scale(QPRE ? a.b_bound * dsee_amax_read(a.amax_b) : dsee_amax_read(a.amax_b));
     oscale = 1.f / (sp * sq);
   }
   const long lda = (long)a.M * 4, ldb = (long)a.N * 4;  // bytes per tile row of P / Q
   // P instruction jj: tiles 8jj .. 8jj+7 of the slab, lane -> (tile l>>3, 16-byte chunk l&7 of the wave's 128 bytes)
   unsigned voffa[2], voffb[QI];
+  if constexpr (!PPRE) {
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) voffa[jj] = (unsigned)((8 * jj + (lane >> 3)) * lda + wave * 128 + (lane & 7) * 16);
+    for (int jj = 0; jj < 2; ++jj) voffa[jj] = (unsigned)((8 * jj + (lane >> 3)) * lda + wave * 128 + (lane & 7) * 16);
+  }
   if constexpr (!QPRE) {
 #pragma unroll
     for (int j = 0; j < QI; ++j) {
@@ -862,8 +868,17 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     int bn;
     const bool live = lt < ntile;
     decode(live ? lt : (long)blockIdx.x, z, bm, bn);
-    pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 4);
-    live_bytes_a = __builtin_amdgcn_readfirstlane(live ? (int)min(16 * lda, 0x7FFFFFFFL) : 0);
+    if constexpr (PPRE) {
+      // instruction jj of this wave: channel slab bm * (BM/16) + wave + NW * jj of dM2, the slab's 16 tile rows
+      pa = uniform_ptr(a.A + z * a.a_z_bytes);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        voffa[jj] = (unsigned)((unsigned long)(bm * (BM / 16) + wave + NW * jj) * (unsigned long)a.a_group_bytes) + lane * 16;
+      live_bytes_a = __builtin_amdgcn_readfirstlane(live ? (int)0xFFFFFFF0u : 0);
+    } else {
+      pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 4);
+      live_bytes_a = __builtin_amdgcn_readfirstlane(live ? (int)min(16 * lda, 0x7FFFFFFFL) : 0);
+    }
     if constexpr (QPRE) {
       // instruction j of this wave: channel slab bn * QS + wave + NW * j, the slab's 16 tile rows (64 bytes each)
       pb = uniform_ptr(a.B + z * a.b_z_bytes);
@@ -884,7 +899,8 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
         __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * a.b_slab_bytes), 0, live_bytes_b, 0x00020000);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      auto* dst = (__attribute__((address_space(3))) void*)(smem + fs * FA + wave * 2048 + jj * 1024);
+      auto* dst = PPRE ? (__attribute__((address_space(3))) void*)(smem + qnxt * FA + (wave + NW * jj) * 1024)
+                       : (__attribute__((address_space(3))) void*)(smem + fs * FA + wave * 2048 + jj * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
     }
     if constexpr (QPRE) {
@@ -930,8 +946,9 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   // ds_read_b32 group read 32 different banks (channel = lane >> 1 put the two halves of a channel on one bank: 36 % of
   // this kernel's LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).
   auto convert = [&](int fs, int im) {
-    conv_item(smem + fs * FA + wave * 2048, 128, lane & 31, lane >> 5, smem + OFF_IA + im * IMGA, 32 * wave + (lane & 31),
-              sp);
+    if constexpr (!PPRE)
+      conv_item(smem + fs * FA + wave * 2048, 128, lane & 31, lane >> 5, smem + OFF_IA + im * IMGA, 32 * wave + (lane & 31),
+                sp);
     if constexpr (QPRE) {
       // nothing to do for Q
     } else if constexpr (RB == 32) {
@@ -980,29 +997,33 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const unsigned char* sa_ = smem + OFF_IA + par * IMGA;
+    const unsigned char* sa_ = PPRE ? smem + qcur * FA : smem + OFF_IA + par * IMGA;
     const unsigned char* sb = QPRE ? smem + OFF_FB + qcur * FB : smem + OFF_IB + par * IMGB;
+    typedef short v4i16 __attribute__((ext_vector_type(4)));
+    // 8 consecutive tiles of one channel (two 4 x 16 transpose reads, 256 bytes = 4 tile rows apart) as an MFMA k-fragment
+    auto tr_frag = [&](const unsigned char* q) {
+      const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q));
+      const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q + 256));
+      return (u32x4){((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                     ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                     ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                     ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16)};
+    };
     u32x4 af[MT][TERMS];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < TERMS; ++p) af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
+      for (int p = 0; p < TERMS; ++p) {
+        if constexpr (PPRE) af[i][p] = tr_frag(sa_ + (wm * MT + i) * 2048 + qfrag + p * 32);
+        else af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
+      }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       u32x4 bf[TERMS];
       if constexpr (QPRE) {
-        typedef short v4i16 __attribute__((ext_vector_type(4)));
         const unsigned char* q = sb + (wn * NT + j) * 2048 + qfrag;
 #pragma unroll
-        for (int p = 0; p < TERMS; ++p) {
-          const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q + p * 32));
-          const v4i16 hi =
-              __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q + p * 32 + 256));
-          bf[p] = (u32x4){((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
-                          ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
-                          ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
-                          ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16)};
-        }
+        for (int p = 0; p < TERMS; ++p) bf[p] = tr_frag(q + p * 32);
       } else {
 #pragma unroll
         for (int p = 0; p < TERMS; ++p) bf[p] = *reinterpret_cast<const u32x4*>(sb + fb + j * TSTEP + p * 32);
@@ -1117,24 +1138,25 @@ int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false>
+template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false, bool PPRE = false>
 int launch_gemm3t(Gemm3Args a, int nz, hipStream_t st) {
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   constexpr int QI = (16 * (BN / NW / 4) + 63) / 64;
   constexpr int IMGA = (I::slots(BM) * 16 + 255) / 256 * 256, IMGB = (I::slots(BN) * 16 + 255) / 256 * 256;
-  const size_t lds = QPRE ? (size_t)2 * NW * 2048 + (size_t)3 * (BN / 16) * 1024 + 2 * IMGA
+  const size_t lds = PPRE ? (size_t)3 * (BM / 16 + BN / 16) * 1024
+                     : QPRE ? (size_t)2 * NW * 2048 + (size_t)3 * (BN / 16) * 1024 + 2 * IMGA
                           : (size_t)2 * NW * 2048 + (size_t)2 * NW * QI * 1024 + 2 * IMGA + 2 * IMGB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE, PPRE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   a.nz = nz;
   const long ntile = (a.M / BM) * (a.N / BN) * nz;
   const long slots = gemm3_num_cus();
-  gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
+  gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE, PPRE><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1372,6 +1394,29 @@ int dsee_gemm_f16x2_tn_qpre(const float* P, const void* Q2, float* C, int groups
   if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 2, true>(a, groups * splits, st);
   if (rows_q % 256 == 0) return launch_gemm3t<2, 4, 4, 2, 0, 2, true>(a, groups * splits, st);
   return launch_gemm3t<4, 2, 2, 2, 16, 2, true>(a, groups * splits, st);
+}
+
+/* ... and with BOTH operands pre-split: P2 = dsee_wino43_dout_f16x2's dM2 [rows_p/16][groups*T][2][16] (scale of p_bound x
+ * *amax_dy), Q2 as above.  No conversion of any kind in the kernel. */
+int dsee_gemm_f16x2_tn_pqpre(const void* P2, const void* Q2, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                             int splits, const float* amax_dy, float p_bound, const float* amax_x, float q_bound,
+                             hipStream_t st) {
+  DSEE_CHECK_ARG(P2 && Q2 && C && amax_dy && amax_x && p_bound > 0.f && q_bound > 0.f && groups > 0 && T % 16 == 0);
+  DSEE_CHECK_ARG(rows_p % 256 == 0 && splits > 0 && (T / 16) % splits == 0 && ldc >= rows_q);
+  DSEE_CHECK_ARG(rows_q == 160 || rows_q % 128 == 0);
+  DSEE_CHECK_ARG((long)(rows_p / 16) * groups * T * 64 < 0xFFFFFFF0L && (long)(rows_q / 16) * groups * T * 64 < 0xFFFFFFF0L);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)P2; a.B = (const unsigned char*)Q2; a.C = C;
+  a.amax_a = amax_dy; a.amax_b = amax_x; a.a_bound = p_bound; a.b_bound = q_bound;
+  const long nk = T / 16 / splits;
+  a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p;
+  a.c_z_elems = (long)rows_p * ldc;
+  a.a_slab_bytes = a.b_slab_bytes = 16 * 64;
+  a.a_z_bytes = a.b_z_bytes = nk * 1024;
+  a.a_group_bytes = a.b_group_bytes = (long)groups * T * 64;
+  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 2, true, true>(a, groups * splits, st);
+  if (rows_q % 256 == 0) return launch_gemm3t<2, 4, 4, 2, 0, 2, true, true>(a, groups * splits, st);
+  return launch_gemm3t<4, 2, 2, 2, 16, 2, true, true>(a, groups * splits, st);
 }
 
 }  // extern "C"

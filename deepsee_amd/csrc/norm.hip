@@ -457,7 +457,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ sums,
                                                              const float* __restrict__ add, float* __restrict__ dx,
                                                              long total4, int C, long group_elems, int groups,
-                                                             float inv_count, int act, float slope) {
+                                                             float inv_count, int act, float slope,
+                                                             float* __restrict__ amax = nullptr) {
+  float vmax = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 4;
     const int c = (int)(e % C);
@@ -477,7 +479,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     f32x4 r = is * (d - s0 * inv_count - xh * (s1 * inv_count));
     if (add) r += *reinterpret_cast<const f32x4*>(add + e);
     *reinterpret_cast<f32x4*>(dx + e) = r;
+    vmax = fmaxf(vmax, dsee_absmax4(r));
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);   // (block-uniform) max |dx|: operand bound of the consumer's A dY A^T
 }
 
 int grid_for(long total4) { return (int)min(8192L, (total4 + 255) / 256); }
@@ -658,6 +662,19 @@ int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, con
   const long total4 = (long)N * HW * C / 4;
   norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
                                                              (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* the same, also writing max |dx| (64-line form, zeroed by the caller): dx is the output gradient of the convolution in front
+ * of this norm, whose A dY A^T transform is then written pre-split with the scale known in advance (dsee_wino43_dout_f16x2) */
+int dsee_modulate_bwd_apply_amax(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                                 const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
+                                 float inv_count, float slope, float* amax_dx, hipStream_t st) {
+  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && sums && dx && amax_dx && C % 4 == 0 && inv_count > 0.f);
+  const long total4 = (long)N * HW * C / 4;
+  norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
+                                                             (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -383,6 +383,127 @@ __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
 }
 
 // dM[xi][t][c] = (A dY A^T)[xi] per 4x4 tile of the output gradient (adjoint of the output transform)
+// dM = A dY A^T written as the pre-split fp16x2 operand (same image as wino43_input_f16x2_kernel: dM2 [C/16][36*T][2][16] fp16,
+// scaled by dsee_pow2_scale(bound * max|dY|); |A dY A^T| <= 225 max|dY| -- the absolute row sums of A are 1,4,4,15,15,1 -- so
+// the scale is fixed by the maximum the producer of dY wrote).  Both consumers take it as it is: the adjoint data-gradient
+// GEMM as its A operand (dsee_gemm_f16x2_pre), the weight-gradient TN GEMM as its P operand through LDS transpose reads.
+// SUMS: bias / noise-weight gradients as in wino43_dout_kernel; a wave keeps its 16-channel slab for the whole loop
+// (gridDim.x * 4 is a multiple of C/16), reduces over its 16 tile lanes and writes part[global wave][3][16].
+struct DoutSums;
+template <bool SUMS>
+__global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __restrict__ dy, unsigned char* __restrict__ dM2,
+                                                                int N, int H, int W, int C, const float* __restrict__ amax,
+                                                                float bound, float* __restrict__ part, int want_bias,
+                                                                int want_n0, int want_n1, uint64_t seed0, uint64_t off0,
+                                                                uint64_t seed1, uint64_t off1,
+                                                                const uint64_t* __restrict__ epoch) {
+  const float sc = dsee_pow2_scale(bound * dsee_amax_read(amax));
+  if constexpr (SUMS) {
+    if (epoch) {
+      off0 += *epoch;
+      off1 += *epoch;
+    }
+  }
+  const int nkb = C >> 4, C4 = C / 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = (T >> 4) * nkb * 64;
+  const size_t slab = (size_t)36 * T * 64;
+  f32x4 sb = {0.f, 0.f, 0.f, 0.f}, s0 = sb, s1 = sb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long w = i >> 6;
+    const int l = (int)(i & 63);
+    const int kb = (int)(w % nkb);
+    const long t = (w / nkb) * 16 + (l >> 2);
+    const int q = kb * 4 + (l & 3);
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    f32x4 tmp[6][4];  // tmp[row][col] = (A dY)[row][col]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 col[4], o[6];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const size_t px = ((size_t)n * H + ty * 4 + k) * W + tx * 4 + j;
+        col[k] = *reinterpret_cast<const f32x4*>(dy + px * C + q * 4);
+        if constexpr (SUMS) {
+          sb += col[k];
+          if (want_n0) s0 += col[k] * philox_normal4(seed0, off0 + (uint64_t)(px * C4 + q));
+          if (want_n1) s1 += col[k] * philox_normal4(seed1, off1 + (uint64_t)(px * C4 + q));
+        }
+      }
+      a6(col, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
+    }
+    const bool odd = (l & 1) != 0;
+    unsigned char* rowp = dM2 + (size_t)kb * slab + (size_t)t * 64 + (odd ? 32 + ((l & 3) - 1) * 8 : (l & 3) * 8);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      f32x4 o[6];
+      a6(tmp[k], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        _Float16 h0[4], h1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = o[j][e] * sc;
+          h0[e] = (_Float16)v;
+          h1[e] = (_Float16)(v - (float)h0[e]);
+        }
+        auto pk = [](_Float16 a, _Float16 b) {
+          return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+        };
+        const unsigned p0a = pk(h0[0], h0[1]), p0b = pk(h0[2], h0[3]), p1a = pk(h1[0], h1[1]), p1b = pk(h1[2], h1[3]);
+        const unsigned sa = odd ? p0a : p1a, sbb = odd ? p0b : p1b;
+        const unsigned ra = (unsigned)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        const unsigned rb = (unsigned)__builtin_amdgcn_mov_dpp((int)sbb, 0xB1, 0xF, 0xF, true);
+        const u32x4 wv = odd ? (u32x4){ra, rb, p1a, p1b} : (u32x4){p0a, p0b, ra, rb};
+        *reinterpret_cast<u32x4*>(rowp + (size_t)(k * 6 + j) * T * 64) = wv;
+      }
+    }
+  }
+  if constexpr (SUMS) {
+    // fold the 16 tile lanes of the wave (lane bits 2..5); lanes 0..3 then hold the sums of channel quads 0..3 of the slab
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sb[e] += __shfl_xor(sb[e], o, 64);
+        s0[e] += __shfl_xor(s0[e], o, 64);
+        s1[e] += __shfl_xor(s1[e], o, 64);
+      }
+    const int l = threadIdx.x & 63;
+    if (l < 4) {
+      const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+      float* o = part + (size_t)gw * 48 + l * 4;
+      if (want_bias) *reinterpret_cast<f32x4*>(o) = sb;
+      if (want_n0) *reinterpret_cast<f32x4*>(o + 16) = s0;
+      if (want_n1) *reinterpret_cast<f32x4*>(o + 32) = s1;
+    }
+  }
+}
+
+// out_w[c] = sum over the waves that own channel slab c / 16 (global wave index = slab mod C/16) of part[wave][w][c % 16]
+__global__ __launch_bounds__(256) void dout_f16x2_sums_finalize_kernel(const float* __restrict__ part, int waves, int C,
+                                                                       float* __restrict__ o0, float* __restrict__ o1,
+                                                                       float* __restrict__ o2) {
+  __shared__ float sv[32][8];
+  const int w = blockIdx.y;
+  float* out = w == 0 ? o0 : (w == 1 ? o1 : o2);
+  if (!out) return;   // (block-uniform)
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl, nkb = C >> 4;
+  float v = 0.f;
+  if (c < C)
+    for (int g = (c >> 4) + lane * nkb; g < waves; g += 32 * nkb) v += part[(size_t)g * 48 + w * 16 + (c & 15)];
+  sv[lane][cl] = v;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    for (int l = 1; l < 32; ++l) v += sv[l][cl];
+    out[c] = v;
+  }
+}
+
 // SUMS: the passes over dY that accompany this one ride along -- the bias gradient sum_px dY and the gradients of up to two
 // NoiseInjection weights sum_px dY * eps (eps regenerated from its Philox stream, as wino43_output<true> drew it) are
 // accumulated per thread (gridDim.x * 256 is a multiple of C/4: a thread keeps its channel quad for the whole loop), folded
@@ -1003,6 +1124,42 @@ int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C
   wino43_dout_kernel<OUT_F32, true><<<grid, 256, 0, st>>>(dy, dM, N, H, W, C, amax, sm);
   DSEE_LAUNCH_CHECK();
   dout_sums_finalize_kernel<<<dim3(dsee_cdiv(C, 8), 3), 256, 0, st>>>(workspace, grid, C, dbias, dnoise0, dnoise1);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+size_t dsee_wino43_dout_f16x2_workspace(void) { return (size_t)DOUT_SUMS_GRID * 4 * 48 * sizeof(float); }
+
+/* dM = A dY A^T as the pre-split fp16x2 operand dM2 [C/16][36*T][2][16] (scale dsee_pow2_scale(bound * *amax_dy), bound >=
+ * 225, amax_dy >= max |dY| written by dY's producer) + optionally the channel sums of dsee_wino43_dout_sums.
+ * workspace (dsee_wino43_dout_f16x2_workspace bytes) only when a sum is requested.  C % 16 == 0, T % 16 == 0,
+ * 2048 % (C/16) == 0. */
+int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
+                           float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
+                           float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dM2 && amax_dy && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 225.f);
+  const long T = (long)N * (H / 4) * (W / 4);
+  DSEE_CHECK_ARG(T % 16 == 0);
+  const bool sums = dbias || dnoise0 || dnoise1;
+  const long blocks = (T / 16) * (C / 16) / 4 + 1;
+  if (!sums) {
+    wino43_dout_f16x2_kernel<false><<<(int)min(16384L, blocks), 256, 0, st>>>(
+        dy, reinterpret_cast<unsigned char*>(dM2), N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr);
+    DSEE_LAUNCH_CHECK();
+    return DSEE_OK;
+  }
+  DSEE_CHECK_ARG(workspace && C / 16 <= 64);
+  // a grid whose wave count is a multiple of C/16: every wave keeps its channel slab for its whole loop
+  const int nkb = C / 16, m = nkb / (nkb % 4 == 0 ? 4 : (nkb % 2 == 0 ? 2 : 1));
+  long grid = min((long)DOUT_SUMS_GRID, blocks) / m * m;
+  if (grid < m) grid = m;
+  wino43_dout_f16x2_kernel<true><<<(int)grid, 256, 0, st>>>(dy, reinterpret_cast<unsigned char*>(dM2), N, H, W, C, amax_dy,
+                                                            bound, workspace, dbias != nullptr, dnoise0 != nullptr,
+                                                            dnoise1 != nullptr, seed0, offset0, seed1, offset1,
+                                                            dsee_rng_epoch());
+  DSEE_LAUNCH_CHECK();
+  dout_f16x2_sums_finalize_kernel<<<dim3(dsee_cdiv(C, 8), 3), 256, 0, st>>>(workspace, (int)grid * 4, C, dbias, dnoise0,
+                                                                           dnoise1);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

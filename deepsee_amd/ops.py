@@ -377,6 +377,8 @@ def _gemm_name(split):
 
 # A operand of a forward Winograd GEMM written pre-split by the input transform (False: fp32 V, split inside the GEMM)
 PRESPLIT_A = True
+# A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
+PRESPLIT_DM = True
 FUSED_V_BOUND = 100.0       # |B^T d B| <= 100 max|d| for F(4x4,3x3): scale of a pre-split V from max |input|
 
 
@@ -504,7 +506,10 @@ def _dout_sums_ok(n, nb, cout_s, mode):
     return DOUT_SUMS and nb == n and mode != 1 and cout_s // 4 <= 256 and 256 % (cout_s // 4) == 0
 
 
-def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None, sums=None):
+DM_BOUND = 225.0      # |A dY A^T| <= 225 max|dY| for F(4x4,3x3) (absolute row sums of A: 1, 4, 4, 15, 15, 1)
+
+
+def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None, sums=None, pre_dm=False):
     """((V, amax_V), (dM, amax_dM)) of one image chunk for the Winograd-domain weight gradient: fp32 rows (modes 0, 2;
     `v` may be the (V, amax) the forward pass kept, `dm` the (A dY A^T, amax) its producer already wrote) or transposed
     bf16x3 (mode 1, no maxima).  `sums`: {"bias": bool, "n0": PhiloxNormal | None, "n1": ...} -- the bias gradient and the
@@ -522,7 +527,22 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
     elif v is None or (need and v[1] is None):
         v = (new(36, t, cin_s), amax_slot() if need else None)
         L.call("wino43_input", xc, v[0], nb, h, wd, cin_s, v[1])
-    if dm is None:
+    ga = getattr(gc, "dsee_amax", None)
+    if dm is None and pre_dm and ga is not None and v is not None and len(v) == 3:
+        # dY's maximum is known (its producer wrote it): A dY A^T leaves the transform pre-split, for the weight gradient's
+        # P operand and the adjoint data-gradient GEMM's A operand alike
+        dm2 = _i16(36 * t * cout_s * 2)
+        n0, n1 = (sums.get("n0"), sums.get("n1")) if sums else (None, None)
+        if sums:
+            sums["dbias"] = new(cout_s) if sums.get("bias") else None
+            sums["dn0"], sums["dn1"] = (new(cout_s) if n0 is not None else None), (new(cout_s) if n1 is not None else None)
+        any_sum = bool(sums) and (sums["dbias"] is not None or n0 is not None or n1 is not None)
+        ws = scratch(L.lib().dsee_wino43_dout_f16x2_workspace(), "doutsums2") if any_sum else None
+        L.call("wino43_dout_f16x2", gc, dm2, nb, h, wd, cout_s, ga, DM_BOUND, ws, sums["dbias"] if sums else None,
+               sums["dn0"] if sums else None, n0.seed if n0 is not None else 0, n0.offset if n0 is not None else 0,
+               sums["dn1"] if sums else None, n1.seed if n1 is not None else 0, n1.offset if n1 is not None else 0)
+        dm = (dm2, ga, True)
+    elif dm is None:
         dm = (new(36, t, cout_s), amax_slot() if need else None)
         if sums:
             n0, n1 = sums.get("n0"), sums.get("n1")
@@ -558,7 +578,9 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
     dv = torch.empty(36, t, r_s, dtype=torch.float16, device="cuda") if split == 3 else new(36, t, r_s)
     dvs = amax_slot() if split == 3 else None
     with _timed(_gemm_name(split), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, 36, rows, split)):
-        if split == 3:
+        if len(dm) == 3:
+            L.call("gemm_f16x2_pre", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, dm[1], DM_BOUND, u_t[1])
+        elif split == 3:
             L.call("gemm_f16_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0, dm[1], u_t[1], 1, dvs)
         elif split == 2:
             L.call("gemm_f16x2_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0, dm[1], u_t[1])
@@ -585,13 +607,18 @@ def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None
         rows_t = L.wrows(cin_s)
         u_t = _wino_u(w_for_dx, co, ci, 2, rows_t, L.kpad(1, 1, cout_s), _split_kind(cout_s, cin_s))
         dx = new(n, h, wd, cin_s) if nb != n else None
+    # A dY A^T pre-split when the whole chain can take it: split V kept by the forward (-> wgrad split 6), and the adjoint GEMM
+    # (if any) on the 256 x 256 pre-split-A kernel
+    pre_dm = (PRESPLIT_DM and mode == 2 and nb == n and _split_kind(cout_s, cin_s) == 2 and t % 256 == 0
+              and cout_s % 16 == 0 and (not with_dx or (cin_s % 256 == 0 and (36 * t // 256) * (cin_s // 256) >= 512)))
     for n0 in range(0, n, nb):
-        v, dm = _wino_wgrad_operands(x[n0:n0 + nb], g[n0:n0 + nb], nb, h, wd, cin_s, cout_s, mode,
-                                     v_fwd if (mode == 2 and nb == n) else None, sums=sums)
+        gc = g if nb == n else g[n0:n0 + nb]
+        v, dm = _wino_wgrad_operands(x[n0:n0 + nb], gc, nb, h, wd, cin_s, cout_s, mode,
+                                     v_fwd if (mode == 2 and nb == n) else None, sums=sums, pre_dm=pre_dm)
         dw = new(co, ci, 3, 3)
         with _timed(_wgrad_name(mode), 2.0 * 36 * t * cin_s * cout_s):
             L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci,
-                   5 if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
+                   (6 if len(dm) == 3 else 5) if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
         total = dw if total is None else total.add_(dw)
         if with_dx:
             dxc = _wino_dgrad_from_dm(dm, u_t, nb, h, wd, cout_s, cin_s, rows_t)
@@ -1029,7 +1056,8 @@ class UpNoise(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.ups:
                 dx = new(*ctx.xshape)
-                L.call("sumpool", dy, dx, n, h, w, c, ctx.ups)
+                dx.dsee_amax = amax_slot()     # (dx is the output gradient of the previous block's conv_1)
+                L.call("sumpool_amax", dy, dx, n, h, w, c, ctx.ups, dx.dsee_amax)
             else:
                 dx = dy
         if ctx.philox is not None and ctx.needs_input_grad[1]:
@@ -1296,8 +1324,10 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
         from . import parallel
         parallel.allreduce_sums(sums[0:2], cfg.world, cfg.group)
         count *= cfg.world
-    L.call("modulate_bwd_apply", dh.contiguous(), out, x, scale, mean, invstd, sums, add, dx, n, h * w, c, 1.0 / count,
-           LRELU_SLOPE)          # dx += add: the gradient of the other consumer of x (the resblock shortcut)
+    da = amax_slot()             # max |dx|: dx is the output gradient of the convolution in front of this norm
+    L.call("modulate_bwd_apply_amax", dh.contiguous(), out, x, scale, mean, invstd, sums, add, dx, n, h * w, c, 1.0 / count,
+           LRELU_SLOPE, da)      # dx += add: the gradient of the other consumer of x (the resblock shortcut)
+    dx.dsee_amax = da
     return dx, dgb, sums[2:4], dm
 
 

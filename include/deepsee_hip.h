@@ -153,6 +153,10 @@ int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups,
  * rows_p % 256 == 0, rows_q == 160 or rows_q % 128 == 0.  Weight gradients of architecture.py:98,122, normalization.py:107-120. */
 int dsee_gemm_f16x2_tn_qpre(const float* P, const void* Q2, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                             int splits, const float* amax_p, const float* amax_x, float q_bound, hipStream_t stream);
+/* ... and with P pre-split too: P2 = dsee_wino43_dout_f16x2's dM2 [rows_p/16][groups*T][2][16] (scale of p_bound x *amax_dy). */
+int dsee_gemm_f16x2_tn_pqpre(const void* P2, const void* Q2, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                             int splits, const float* amax_dy, float p_bound, const float* amax_x, float q_bound,
+                             hipStream_t stream);
 /* Evaluation metrics on the device: per image PSNR, SSIM and RMSE of `fake` against `real`, both fp32 NHWC
  * [N][H][W][Cs] in [-1, 1] (channels 0..2 used).  Replaces MetricsEvaluator.collect_samples' per-sample CPU loop
  * (evaluator/evaluation.py:88-137: util/util.py:72-103 tensor2im quantisation, evaluator/calculate_PSNR_SSIM.py:71-79
@@ -210,6 +214,15 @@ int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, flo
  * weights (architecture.py:111-112 noise_middle, :127,133-134 noise_skip; normalization.py:289-304) with eps_k the Philox
  * stream (seed_k, offset_k) dsee_wino43_output drew in the forward pass.  Replaces the separate dsee_channel_dot /
  * dsee_channel_dot_rng passes over dY.  Any of the three outputs may be NULL (not all); 256 % (C/4) == 0. */
+/* ... and written PRE-SPLIT (round 3): dM2 [C/16][36*T][2][16] fp16 with the scale power-of-two scale of bound x *amax_dy, bound
+ * >= DSEE_WINO_DM_BOUND (|A dY A^T| <= 225 max|dY|), amax_dy = max |dY| written by dY's producer (dsee_modulate_bwd_apply,
+ * dsee_sumpool).  Consumers: dsee_gemm_f16x2_pre (adjoint data gradient) and dsee_wino43_wgrad(split = 6).  The three channel
+ * sums of dsee_wino43_dout_sums are optional (workspace: dsee_wino43_dout_f16x2_workspace() bytes when any is requested). */
+#define DSEE_WINO_DM_BOUND 225.0f
+size_t dsee_wino43_dout_f16x2_workspace(void);
+int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
+                           float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
+                           float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t stream);
 size_t dsee_wino43_dout_sums_workspace(int C);
 int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C, float* amax, float* workspace,
                           float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0, float* dnoise1, uint64_t seed1,
@@ -223,7 +236,9 @@ size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
                       long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, const float* amax_v,
                       const float* amax_dm, hipStream_t stream);
-/* split = 5: V is the PRE-SPLIT fp16x2 transform dsee_wino43_input_f16x2 wrote for the forward pass with bound
+/* split = 6: as split = 5 and dM is the pre-split dM2 of dsee_wino43_dout_f16x2 (bound DSEE_WINO_DM_BOUND), amax_dm = max |dY|
+ * (dsee_gemm_f16x2_tn_pqpre; dsee_wino43_wgrad only).
+ * split = 5: V is the PRE-SPLIT fp16x2 transform dsee_wino43_input_f16x2 wrote for the forward pass with bound
  * DSEE_WINO_V_BOUND (cast to const float*), amax_v = max |x| of the layer input (dsee_gemm_f16x2_tn_qpre).
  * split = 3: as split = 2 with two-term fp16 splits (dsee_gemm_f16x2_tn_f32; amax_v / amax_dm = max |V|, max |dM|).
  * split = 2: V / dM are the plain fp32 transforms (dsee_wino43_input / dsee_wino43_dout), transposed and split inside
@@ -359,6 +374,10 @@ int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* 
 int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                             const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
                             float inv_count, float slope, hipStream_t stream);
+/* ... also writing max |dx| (64-line form): the operand bound of dsee_wino43_dout_f16x2 for the convolution in front of the norm */
+int dsee_modulate_bwd_apply_amax(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
+                                 const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
+                                 float inv_count, float slope, float* amax_dx, hipStream_t stream);
 
 /* ------------------------------------------------------------------ label-map kernels (uint8 [N][H][W])
  * mlp_shared = ReLU(conv3x3(one-hot)) (normalization.py:98-101) as a 9-tap gather-sum of weight columns. */
@@ -400,6 +419,7 @@ int dsee_upsample_noise_rng_fwd_stats(const float* x, const float* noise_w, floa
 int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* workspace, uint64_t seed, uint64_t offset,
                          hipStream_t stream);
 int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t stream);
+int dsee_sumpool_amax(const float* dy, float* dx, int N, int H, int W, int C, int ups, float* amax_dx, hipStream_t stream);
 size_t dsee_channel_dot_workspace(long M, int C);
 int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, float* workspace, hipStream_t stream);
 int dsee_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t stream);

@@ -439,6 +439,73 @@ def test_gemm_f16x2_tn_pre_split_q(groups, t, rp, rq, splits, bound):
     assert err < (5e-7 if bound <= 8 else 4e-6)
 
 
+@pytest.mark.parametrize("groups,t,rp,rq,splits", [(2, 1024, 256, 256, 2), (3, 512, 256, 160, 1), (36, 256, 512, 512, 1),
+                                                   (4, 512, 256, 128, 2)])
+def test_gemm_f16x2_tn_both_operands_pre_split(groups, t, rp, rq, splits):
+    """dsee_gemm_f16x2_tn_pqpre: P (A dY A^T, bound 225) and Q (B^T d B, bound 100) both arrive pre-split in the tile-major
+    image of dsee_wino43_dout_f16x2 / dsee_wino43_input_f16x2; every MFMA fragment comes out of an LDS transpose read.
+    Against float64, on NaN-poisoned LDS, bit-identical from launch to launch."""
+    from deepsee_amd import lib as L
+    g = torch.Generator().manual_seed(3 * t + rq)
+    p = torch.randn(groups * t, rp, generator=g) * 3.0
+    q = torch.randn(groups * t, rq, generator=g) * 0.02
+    am_p, am_q = float(p.abs().max()), float(q.abs().max())
+    # the producers scale with bound x max|input|: emulate inputs whose transform maxima sit 225 / 100 above them
+    p2 = _split2_rows(p, _pow2_scale(225.0 * am_p / 40.0)).cuda()
+    q2 = _split2_rows(q, _pow2_scale(100.0 * am_q / 12.0)).cuda()
+    ts = t // splits
+    ref = torch.einsum("ztp,ztq->zpq", p.view(groups * splits, ts, rp).double(), q.view(groups * splits, ts, rq).double())
+    sink = torch.zeros(1, device="cuda")
+    first = None
+    for it in range(3):
+        L.call("selftest_lds_poison", sink)
+        c = torch.full((groups * splits, rp, rq), float("nan"), device="cuda")
+        L.call("gemm_f16x2_tn_pqpre", p2, q2, c, groups, t, rp, rq, rq, splits, _amax(am_p / 40.0), 225.0,
+               _amax(am_q / 12.0), 100.0)
+        torch.cuda.synchronize()
+        assert torch.isfinite(c).all()
+        first = c.clone() if first is None else first
+        assert torch.equal(c, first)
+    err = ((first.cpu().double() - ref).norm() / ref.norm()).item()
+    print("TN with both operands pre-split: vs f64 %.2e" % err)
+    assert err < 2e-6
+
+
+@pytest.mark.parametrize("n,h,c", [(2, 32, 128), (8, 16, 512), (1, 64, 256)])
+def test_dout_transform_pre_split_with_channel_sums(n, h, c):
+    """dsee_wino43_dout_f16x2: A dY A^T written as the pre-split fp16x2 image (scale from 225 x max|dY|, known before the
+    kernel runs) equals the fp32 transform of dsee_wino43_dout to 2^-21 of the tensor maximum, and the bias / noise-weight
+    gradients that ride along equal the separate channel_dot / channel_dot_rng passes."""
+    from deepsee_amd import lib as L, ops
+    g = torch.Generator().manual_seed(n + h + c)
+    dy = (torch.randn(n, h, h, c, generator=g) * 0.37).cuda()
+    t = n * (h // 4) ** 2
+    ref, ra = ops.new(36, t, c), ops.amax_slot()
+    L.call("wino43_dout", dy, ref, n, h, h, c, ra)
+    am = ops.tensor_amax(dy)
+    dm2 = ops._i16(36 * t * c * 2)
+    ws = ops.scratch(L.lib().dsee_wino43_dout_f16x2_workspace(), "doutsums2")
+    db, d0, d1 = ops.new(c), ops.new(c), ops.new(c)
+    L.call("wino43_dout_f16x2", dy, dm2, n, h, h, c, am, 225.0, ws, db, d0, 11, 4096, d1, 12, 8192)
+    only = ops._i16(36 * t * c * 2)
+    L.call("wino43_dout_f16x2", dy, only, n, h, h, c, am, 225.0, None, None, None, 0, 0, None, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(only, dm2)
+    sc = _pow2_scale(225.0 * float(dy.abs().max()))
+    dec = dm2.view(torch.float16).view(c // 16, 36 * t, 2, 16).float().sum(2).permute(1, 0, 2).reshape(36, t, c) / sc
+    assert float((dec - ref).abs().max()) <= 2.0 ** -21 * float(ref.abs().max())
+    assert float(ref.abs().max()) <= 225.0 * float(dy.abs().max())
+    want_b = ops.channel_dot(dy, None, c)
+    assert rel(db.cpu(), want_b.cpu()) < 1e-5
+    m = n * h * h
+    wsd = ops.scratch(L.lib().dsee_channel_dot_workspace(m, c), "chdot")
+    for got, seed, off in ((d0, 11, 4096), (d1, 12, 8192)):
+        want = ops.new(c)
+        L.call("channel_dot_rng", dy, want, m, c, wsd, seed, off)
+        torch.cuda.synchronize()
+        assert rel(got.cpu(), want.cpu()) < 1e-5
+
+
 def test_f16x2_special_values():
     """Edges of the operand split: zero operands (scale 1, result exactly 0), values 2^20 below the operand maximum
     (h1 subnormal: absolute error <= 2^-39 of the maximum), huge / tiny magnitudes (the power-of-two scale keeps fp16 in
