@@ -309,18 +309,22 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
 // BEFORE the transform runs: the producer of x supplies max|x| and no second pass over V is needed.  A wave = 16
 // consecutive tiles x one slab, lane = (tile l >> 2, channel quad l & 3); lane pairs swap halves so that every lane stores
 // 16 contiguous bytes and a wave instruction fills 1 KB (16 rows x 64 B) of the image.
+// WIDE (C % 64 == 0): a wave = 4 consecutive tiles x four slabs (64 channels), lane = (tile l >> 4, slab (l >> 2) & 3, quad
+// l & 3): the 16 lanes of a tile read 256 contiguous bytes of every pixel (64-byte runs cost the narrow form 20 % of its
+// bandwidth) and a store instruction still writes whole 64-byte rows, 256 bytes contiguous per slab.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void wino43_input_f16x2_kernel(const float* __restrict__ x, unsigned char* __restrict__ V2,
                                                                  int N, int H, int W, int C,
                                                                  const float* __restrict__ amax, float bound) {
   const float sc = dsee_pow2_scale(bound * dsee_amax_read(amax));
-  const int nkb = C >> 4, th = H / 4, tw = W / 4;
-  const long T = (long)N * th * tw, total = (T >> 4) * nkb * 64;
+  const int nkb = WIDE ? C >> 6 : C >> 4, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = (WIDE ? T >> 2 : T >> 4) * nkb * 64;
   const size_t slab = (size_t)36 * T * 64;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long w = i >> 6;
     const int l = (int)(i & 63);
-    const int kb = (int)(w % nkb);
-    const long t = (w / nkb) * 16 + (l >> 2);
+    const int kb = WIDE ? (int)(w % nkb) * 4 + ((l >> 2) & 3) : (int)(w % nkb);
+    const long t = WIDE ? (w / nkb) * 4 + (l >> 4) : (w / nkb) * 16 + (l >> 2);
     const int q = kb * 4 + (l & 3);
     const int tx = (int)(t % tw);
     const long r = t / tw;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void wino43_input_f16x2_kernel(const float* __
         const unsigned ra = (unsigned)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         const unsigned rb = (unsigned)__builtin_amdgcn_mov_dpp((int)sb, 0xB1, 0xF, 0xF, true);
         const u32x4 wv = odd ? (u32x4){ra, rb, p1a, p1b} : (u32x4){p0a, p0b, ra, rb};
-        *reinterpret_cast<u32x4*>(rowp + (size_t)(k * 6 + j) * T * 64) = wv;
+        __builtin_nontemporal_store(wv, reinterpret_cast<u32x4*>(rowp + (size_t)(k * 6 + j) * T * 64));   // read next by another kernel
       }
     }
   }
@@ -390,7 +394,7 @@ __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
 // SUMS: bias / noise-weight gradients as in wino43_dout_kernel; a wave keeps its 16-channel slab for the whole loop
 // (gridDim.x * 4 is a multiple of C/16), reduces over its 16 tile lanes and writes part[global wave][3][16].
 struct DoutSums;
-template <bool SUMS>
+template <bool SUMS, bool WIDE>
 __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __restrict__ dy, unsigned char* __restrict__ dM2,
                                                                 int N, int H, int W, int C, const float* __restrict__ amax,
                                                                 float bound, float* __restrict__ part, int want_bias,
@@ -404,15 +408,15 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
       off1 += *epoch;
     }
   }
-  const int nkb = C >> 4, C4 = C / 4, th = H / 4, tw = W / 4;
-  const long T = (long)N * th * tw, total = (T >> 4) * nkb * 64;
+  const int nkb = WIDE ? C >> 6 : C >> 4, C4 = C / 4, th = H / 4, tw = W / 4;   // channel groups of a wave (64 / 16 channels)
+  const long T = (long)N * th * tw, total = (WIDE ? T >> 2 : T >> 4) * nkb * 64;
   const size_t slab = (size_t)36 * T * 64;
   f32x4 sb = {0.f, 0.f, 0.f, 0.f}, s0 = sb, s1 = sb;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long w = i >> 6;
     const int l = (int)(i & 63);
-    const int kb = (int)(w % nkb);
-    const long t = (w / nkb) * 16 + (l >> 2);
+    const int kb = WIDE ? (int)(w % nkb) * 4 + ((l >> 2) & 3) : (int)(w % nkb);
+    const long t = WIDE ? (w / nkb) * 4 + (l >> 4) : (w / nkb) * 16 + (l >> 2);
     const int q = kb * 4 + (l & 3);
     const int tx = (int)(t % tw);
     const long r = t / tw;
@@ -458,14 +462,16 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
         const unsigned ra = (unsigned)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         const unsigned rb = (unsigned)__builtin_amdgcn_mov_dpp((int)sbb, 0xB1, 0xF, 0xF, true);
         const u32x4 wv = odd ? (u32x4){ra, rb, p1a, p1b} : (u32x4){p0a, p0b, ra, rb};
-        *reinterpret_cast<u32x4*>(rowp + (size_t)(k * 6 + j) * T * 64) = wv;
+        __builtin_nontemporal_store(wv, reinterpret_cast<u32x4*>(rowp + (size_t)(k * 6 + j) * T * 64));   // read next by another kernel
       }
     }
   }
   if constexpr (SUMS) {
-    // fold the 16 tile lanes of the wave (lane bits 2..5); lanes 0..3 then hold the sums of channel quads 0..3 of the slab
+    // fold the tile lanes of the wave (WIDE: lane bits 4, 5; else bits 2..5); the low QL lanes then hold the sums of the
+    // wave's channel quads; part[global wave][3][CW channels]
+    constexpr int QL = WIDE ? 16 : 4, CW = QL * 4;
 #pragma unroll
-    for (int o = 4; o < 64; o <<= 1)
+    for (int o = QL; o < 64; o <<= 1)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         sb[e] += __shfl_xor(sb[e], o, 64);
@@ -473,29 +479,29 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
         s1[e] += __shfl_xor(s1[e], o, 64);
       }
     const int l = threadIdx.x & 63;
-    if (l < 4) {
+    if (l < QL) {
       const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-      float* o = part + (size_t)gw * 48 + l * 4;
+      float* o = part + (size_t)gw * 3 * CW + l * 4;
       if (want_bias) *reinterpret_cast<f32x4*>(o) = sb;
-      if (want_n0) *reinterpret_cast<f32x4*>(o + 16) = s0;
-      if (want_n1) *reinterpret_cast<f32x4*>(o + 32) = s1;
+      if (want_n0) *reinterpret_cast<f32x4*>(o + CW) = s0;
+      if (want_n1) *reinterpret_cast<f32x4*>(o + 2 * CW) = s1;
     }
   }
 }
 
-// out_w[c] = sum over the waves that own channel slab c / 16 (global wave index = slab mod C/16) of part[wave][w][c % 16]
+// out_w[c] = sum over the waves that own channel group c / cw (global wave index = group mod C/cw) of part[wave][w][c % cw]
 __global__ __launch_bounds__(256) void dout_f16x2_sums_finalize_kernel(const float* __restrict__ part, int waves, int C,
-                                                                       float* __restrict__ o0, float* __restrict__ o1,
-                                                                       float* __restrict__ o2) {
+                                                                       int cw, float* __restrict__ o0,
+                                                                       float* __restrict__ o1, float* __restrict__ o2) {
   __shared__ float sv[32][8];
   const int w = blockIdx.y;
   float* out = w == 0 ? o0 : (w == 1 ? o1 : o2);
   if (!out) return;   // (block-uniform)
   const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl, nkb = C >> 4;
+  const int c = blockIdx.x * 8 + cl, nkb = C / cw;
   float v = 0.f;
   if (c < C)
-    for (int g = (c >> 4) + lane * nkb; g < waves; g += 32 * nkb) v += part[(size_t)g * 48 + w * 16 + (c & 15)];
+    for (int g = c / cw + lane * nkb; g < waves; g += 32 * nkb) v += part[(size_t)g * 3 * cw + w * cw + c % cw];
   sv[lane][cl] = v;
   __syncthreads();
   if (lane == 0 && c < C) {
@@ -1083,8 +1089,12 @@ int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C
                             hipStream_t st) {
   DSEE_CHECK_ARG(x && V2 && amax_x && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 100.f);
   DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 16 == 0);
-  wino43_input_f16x2_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
-      x, reinterpret_cast<unsigned char*>(V2), N, H, W, C, amax_x, bound);
+  if (C % 64 == 0)
+    wino43_input_f16x2_kernel<true><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+        x, reinterpret_cast<unsigned char*>(V2), N, H, W, C, amax_x, bound);
+  else
+    wino43_input_f16x2_kernel<false><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+        x, reinterpret_cast<unsigned char*>(V2), N, H, W, C, amax_x, bound);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1128,7 +1138,7 @@ int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C
   return DSEE_OK;
 }
 
-size_t dsee_wino43_dout_f16x2_workspace(void) { return (size_t)DOUT_SUMS_GRID * 4 * 48 * sizeof(float); }
+size_t dsee_wino43_dout_f16x2_workspace(void) { return (size_t)DOUT_SUMS_GRID * 4 * 3 * 64 * sizeof(float); }
 
 /* dM = A dY A^T as the pre-split fp16x2 operand dM2 [C/16][36*T][2][16] (scale dsee_pow2_scale(bound * *amax_dy), bound >=
  * 225, amax_dy >= max |dY| written by dY's producer) + optionally the channel sums of dsee_wino43_dout_sums.
@@ -1140,25 +1150,37 @@ int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int 
   DSEE_CHECK_ARG(dy && dM2 && amax_dy && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 225.f);
   const long T = (long)N * (H / 4) * (W / 4);
   DSEE_CHECK_ARG(T % 16 == 0);
-  const bool sums = dbias || dnoise0 || dnoise1;
+  const bool sums = dbias || dnoise0 || dnoise1, wide = C % 64 == 0;
+  const int cw = wide ? 64 : 16, nkb = C / cw;
   const long blocks = (T / 16) * (C / 16) / 4 + 1;
+  unsigned char* out = reinterpret_cast<unsigned char*>(dM2);
   if (!sums) {
-    wino43_dout_f16x2_kernel<false><<<(int)min(16384L, blocks), 256, 0, st>>>(
-        dy, reinterpret_cast<unsigned char*>(dM2), N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr);
+    const int grid = (int)min(16384L, blocks);
+    if (wide)
+      wino43_dout_f16x2_kernel<false, true><<<grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0, 0, 0,
+                                                                  0, 0, nullptr);
+    else
+      wino43_dout_f16x2_kernel<false, false><<<grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0, 0, 0,
+                                                                   0, 0, nullptr);
     DSEE_LAUNCH_CHECK();
     return DSEE_OK;
   }
   DSEE_CHECK_ARG(workspace && C / 16 <= 64);
-  // a grid whose wave count is a multiple of C/16: every wave keeps its channel slab for its whole loop
-  const int nkb = C / 16, m = nkb / (nkb % 4 == 0 ? 4 : (nkb % 2 == 0 ? 2 : 1));
+  // a grid whose wave count is a multiple of the channel groups: every wave keeps its channels for its whole loop
+  const int m = nkb / (nkb % 4 == 0 ? 4 : (nkb % 2 == 0 ? 2 : 1));
   long grid = min((long)DOUT_SUMS_GRID, blocks) / m * m;
   if (grid < m) grid = m;
-  wino43_dout_f16x2_kernel<true><<<(int)grid, 256, 0, st>>>(dy, reinterpret_cast<unsigned char*>(dM2), N, H, W, C, amax_dy,
-                                                            bound, workspace, dbias != nullptr, dnoise0 != nullptr,
-                                                            dnoise1 != nullptr, seed0, offset0, seed1, offset1,
-                                                            dsee_rng_epoch());
+  DSEE_CHECK_ARG((grid * 4) % nkb == 0);
+  if (wide)
+    wino43_dout_f16x2_kernel<true, true><<<(int)grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, workspace,
+                                                                    dbias != nullptr, dnoise0 != nullptr, dnoise1 != nullptr,
+                                                                    seed0, offset0, seed1, offset1, dsee_rng_epoch());
+  else
+    wino43_dout_f16x2_kernel<true, false><<<(int)grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, workspace,
+                                                                     dbias != nullptr, dnoise0 != nullptr, dnoise1 != nullptr,
+                                                                     seed0, offset0, seed1, offset1, dsee_rng_epoch());
   DSEE_LAUNCH_CHECK();
-  dout_f16x2_sums_finalize_kernel<<<dim3(dsee_cdiv(C, 8), 3), 256, 0, st>>>(workspace, (int)grid * 4, C, dbias, dnoise0,
+  dout_f16x2_sums_finalize_kernel<<<dim3(dsee_cdiv(C, 8), 3), 256, 0, st>>>(workspace, (int)grid * 4, C, cw, dbias, dnoise0,
                                                                            dnoise1);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;

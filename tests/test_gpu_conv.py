@@ -471,7 +471,7 @@ def test_gemm_f16x2_tn_both_operands_pre_split(groups, t, rp, rq, splits):
     assert err < 2e-6
 
 
-@pytest.mark.parametrize("n,h,c", [(2, 32, 128), (8, 16, 512), (1, 64, 256)])
+@pytest.mark.parametrize("n,h,c", [(2, 32, 128), (8, 16, 512), (1, 64, 256), (2, 32, 48)])
 def test_dout_transform_pre_split_with_channel_sums(n, h, c):
     """dsee_wino43_dout_f16x2: A dY A^T written as the pre-split fp16x2 image (scale from 225 x max|dY|, known before the
     kernel runs) equals the fp32 transform of dsee_wino43_dout to 2^-21 of the tensor maximum, and the bias / noise-weight
