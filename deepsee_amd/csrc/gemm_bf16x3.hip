@@ -993,13 +993,100 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   convert(0, 0);
   int par = 0, ck = 0, qcur = 0;
   long ct = blockIdx.x;
+  typedef short v4i16 __attribute__((ext_vector_type(4)));
+  if constexpr (PPRE && NW == 8) {
+    // ---- both operands pre-split: nothing but DMA, transpose reads and MFMAs is left, and the two waves of a SIMD (w, w + 4)
+    // run half a slab apart as in gemm3a's ping-pong -- in its L interval a wave reads its fragments, requests slab k+2 and
+    // waits for its own part of slab k+1; in its M interval it only issues MFMAs, so each SIMD's matrix pipe always has one
+    // wave feeding it.  Stage (k+2) % 3 is rewritten in L(k), after its last readers L(k-1) of both groups.
+    auto trf = [&](const unsigned char* q) {
+      const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q));
+      const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q + 256));
+      return (u32x4){((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                     ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                     ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                     ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16)};
+    };
+    const bool late = wave >= 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+    for (;;) {
+      const unsigned char* sa_ = smem + qcur * FA;
+      const unsigned char* sb = smem + OFF_FB + qcur * FB;
+      u32x4 af[MT][TERMS], bf[NT][TERMS];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) af[i][p] = trf(sa_ + (wm * MT + i) * 2048 + qfrag + p * 32);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) bf[j][p] = trf(sb + (wn * NT + j) * 2048 + qfrag + p * 32);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(0);      // slab k+2
+      __builtin_amdgcn_sched_barrier(0);
+      wait_slab();   // this wave's part of slab k+1 landed before the barrier that publishes it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < products<TERMS>(); ++q)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mfma_product<TERMS>(q, af[i], bf[j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      qcur = qcur == 2 ? 0 : qcur + 1;
+      ++ck;
+      if constexpr (FL > 0) {
+        if ((ck & (FL - 1)) == 0 || ck == nk) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              tot[i][j] += acc[i][j];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        }
+      }
+      if (ck == nk) {
+        long z, bm;
+        int bn;
+        decode(ct, z, bm, bn);
+        float* cz = a.C + z * a.c_z_elems;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const long mb = bm * BM + wm * MT * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
+            f32x16& d = FL > 0 ? tot[FL > 0 ? i : 0][FL > 0 ? j : 0] : acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              cz[(mb + (r & 3) + 8 * (r >> 2)) * a.ldc + n] = d[r] * oscale;
+              d[r] = 0.f;
+            }
+          }
+        }
+        ck = 0;
+        ct += G;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ct >= ntile) break;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+  } else
   for (;;) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const unsigned char* sa_ = PPRE ? smem + qcur * FA : smem + OFF_IA + par * IMGA;
     const unsigned char* sb = QPRE ? smem + OFF_FB + qcur * FB : smem + OFF_IB + par * IMGB;
-    typedef short v4i16 __attribute__((ext_vector_type(4)));
     // 8 consecutive tiles of one channel (two 4 x 16 transpose reads, 256 bytes = 4 tile rows apart) as an MFMA k-fragment
     auto tr_frag = [&](const unsigned char* q) {
       const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q));
