@@ -994,11 +994,13 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   int par = 0, ck = 0, qcur = 0;
   long ct = blockIdx.x;
   typedef short v4i16 __attribute__((ext_vector_type(4)));
-  if constexpr (PPRE && NW == 8) {
-    // ---- both operands pre-split: nothing but DMA, transpose reads and MFMAs is left, and the two waves of a SIMD (w, w + 4)
-    // run half a slab apart as in gemm3a's ping-pong -- in its L interval a wave reads its fragments, requests slab k+2 and
-    // waits for its own part of slab k+1; in its M interval it only issues MFMAs, so each SIMD's matrix pipe always has one
-    // wave feeding it.  Stage (k+2) % 3 is rewritten in L(k), after its last readers L(k-1) of both groups.
+  if constexpr (QPRE && NW == 8) {
+    // ---- pre-split Q (and P): the two waves of a SIMD (w, w + 4) run half a slab apart as in gemm3a's ping-pong -- in its L
+    // interval a wave reads its fragments, requests slab k+2, waits for its own part of slab k+1 (and, with an fp32 P,
+    // converts its own 32 P rows of slab k+1 into the other image); in its M interval it only issues MFMAs, so each SIMD's
+    // matrix pipe always has one wave feeding it.  Raw stage (k+2) % 3 and image (k+1) % 2 are rewritten in L(k), after
+    // their last readers L(k-1) of both groups; a complete image k % 2 (all eight waves' rows) exists one barrier before
+    // its first reader.
     auto trf = [&](const unsigned char* q) {
       const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q));
       const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(q + 256));
@@ -1012,21 +1014,29 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();
     for (;;) {
-      const unsigned char* sa_ = smem + qcur * FA;
+      const unsigned char* sa_ = PPRE ? smem + qcur * FA : smem + OFF_IA + par * IMGA;
       const unsigned char* sb = smem + OFF_FB + qcur * FB;
       u32x4 af[MT][TERMS], bf[NT][TERMS];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int p = 0; p < TERMS; ++p) af[i][p] = trf(sa_ + (wm * MT + i) * 2048 + qfrag + p * 32);
+        for (int p = 0; p < TERMS; ++p) {
+          if constexpr (PPRE) af[i][p] = trf(sa_ + (wm * MT + i) * 2048 + qfrag + p * 32);
+          else af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
+        }
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int p = 0; p < TERMS; ++p) bf[j][p] = trf(sb + (wn * NT + j) * 2048 + qfrag + p * 32);
       __builtin_amdgcn_sched_barrier(0);
-      issue(0);      // slab k+2
+      issue(par);    // slab k+2 (fp32 P: into the stage this wave converted in its previous L interval)
       __builtin_amdgcn_sched_barrier(0);
       wait_slab();   // this wave's part of slab k+1 landed before the barrier that publishes it
+      if constexpr (!PPRE) {
+        asm volatile("" ::: "memory");
+        convert(par ^ 1, par ^ 1);
+        par ^= 1;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

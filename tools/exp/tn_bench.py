@@ -24,3 +24,13 @@ for name, f in (("fp32 P, fp32 Q", lambda: L.call("gemm_f16x2_tn_f32", p, q, c, 
                 ("both pre-split (ping-pong)", lambda: L.call("gemm_f16x2_tn_pqpre", p2, q2, c, g, t, rp, rq, rq, splits, am, 225.0, am, 100.0))):
     ms = timeit(f)
     print("TN 512x512 @256^2 %-28s %.3f ms  %.0f TF/s fp32-eq (%.2f of 839)" % (name, ms, fl / ms / 1e9, fl / ms / 1e9 / 839))
+# the SEAN table weight gradient: 36 x 8 per-image groups, T/N = 4096 tiles, P = 1024 gamma/beta rows, Q = 160 columns
+g, t, rp, rq, splits = 288, 4096, 1024, 160, 1
+p = torch.randn(g * t, rp, device="cuda"); q = torch.randn(g * t, rq, device="cuda")
+q2 = (torch.randn(g * t * rq * 2, device="cuda") * 1000).half().view(torch.int16)
+c = torch.empty(g * splits, rp, rq, device="cuda")
+fl = 2.0 * g * t * rp * rq
+for name, f in (("fp32 P, fp32 Q", lambda: L.call("gemm_f16x2_tn_f32", p, q, c, g, t, rp, rq, rq, splits, am, am)),
+                ("fp32 P, pre-split Q (ping-pong)", lambda: L.call("gemm_f16x2_tn_qpre", p, q2, c, g, t, rp, rq, rq, splits, am, am, 100.0))):
+    ms = timeit(f)
+    print("TN table 1024x160 @256^2 %-32s %.3f ms  %.0f TF/s fp32-eq (%.2f of 839)" % (name, ms, fl / ms / 1e9, fl / ms / 1e9 / 839))
