@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void chdot_finalize_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                      float* __restrict__ dx, long total4, int act, float slope) {
+                                                      float* __restrict__ dx, long total4, int act, float slope,
+                                                      float* __restrict__ amax = nullptr) {
+  float vmax = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
     const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
@@ -102,7 +104,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = d[k] * dsee_act_grad_from_out(v[k], act, slope);
     *reinterpret_cast<f32x4*>(dx + i * 4) = r;
+    vmax = fmaxf(vmax, dsee_absmax4(r));
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);
 }
 
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total4,
@@ -533,6 +537,15 @@ int dsee_act_fwd(const float* x, float* y, long n, int act, float slope, hipStre
 int dsee_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float slope, hipStream_t st) {
   DSEE_CHECK_ARG(dy && y && dx && n % 4 == 0);
   act_bwd_kernel<<<egrid(n / 4), 256, 0, st>>>(dy, y, dx, n / 4, act, slope);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* dsee_act_bwd that also writes max |dx| (64-line form): dx is the output gradient a Winograd layer transforms pre-split */
+int dsee_act_bwd_amax(const float* dy, const float* y, float* dx, long n, int act, float slope, float* amax_dx,
+                      hipStream_t st) {
+  DSEE_CHECK_ARG(dy && y && dx && amax_dx && n % 4 == 0);
+  act_bwd_kernel<<<egrid(n / 4), 256, 0, st>>>(dy, y, dx, n / 4, act, slope, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

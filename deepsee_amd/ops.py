@@ -683,7 +683,11 @@ class Conv2d(torch.autograd.Function):
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
-        if ctx.act != L.ACT_NONE:
+        if ctx.act != L.ACT_NONE and ctx.wino and PRESPLIT_DM:
+            g = torch.empty_like(dy)
+            g.dsee_amax = amax_slot()     # (the A dY A^T transform below is written pre-split with this bound)
+            L.call("act_bwd_amax", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE, g.dsee_amax)
+        elif ctx.act != L.ACT_NONE:
             g = torch.empty_like(dy)
             L.call("act_bwd", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE)
         else:

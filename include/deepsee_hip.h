@@ -424,6 +424,8 @@ size_t dsee_channel_dot_workspace(long M, int C);
 int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, float* workspace, hipStream_t stream);
 int dsee_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t stream);
 int dsee_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float slope, hipStream_t stream);
+int dsee_act_bwd_amax(const float* dy, const float* y, float* dx, long n, int act, float slope, float* amax_dx,
+                      hipStream_t stream);   /* + max |dx| (64-line form) for dsee_wino43_dout_f16x2 */
 int dsee_axpby(const float* a, float alpha, const float* b, float beta, float* y, long n, hipStream_t stream);
 /* F.avg_pool2d(3, stride 2, pad 1, count_include_pad=False)  (discriminator.py:46-49) */
 int dsee_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream);
