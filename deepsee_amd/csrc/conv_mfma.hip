@@ -1583,7 +1583,9 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
   if (split) {
     DSEE_CHECK_ARG(rows % 128 == 0);
     const int sper = wino_sper(T / N, ld, rows, N), Kpad = dsee_conv_kpad(1, 1, ld);
-    int rc = split == 5   ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v,
+    int rc = split == 6   ? dsee_gemm_f16x2_tn_pqpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm,
+                                                     DSEE_WINO_DM_BOUND, amax_v, DSEE_WINO_V_BOUND, st)
+             : split == 5 ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v,
                                                     DSEE_WINO_V_BOUND, st)
              : split == 4 ? dsee_gemm_f16_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)
              : split == 3 ? dsee_gemm_f16x2_tn_f32(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v, st)

@@ -870,10 +870,11 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     decode(live ? lt : (long)blockIdx.x, z, bm, bn);
     if constexpr (PPRE) {
       // instruction jj of this wave: channel slab bm * (BM/16) + wave + NW * jj of dM2, the slab's 16 tile rows
-      pa = uniform_ptr(a.A + z * a.a_z_bytes);
+      // (the tile's first slab goes into the 64-bit base: with 1 024 gamma/beta rows the slabs span more than 4 GB)
+      pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * (BM / 16) * a.a_group_bytes);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
-        voffa[jj] = (unsigned)((unsigned long)(bm * (BM / 16) + wave + NW * jj) * (unsigned long)a.a_group_bytes) + lane * 16;
+        voffa[jj] = (unsigned)((unsigned long)(wave + NW * jj) * (unsigned long)a.a_group_bytes) + lane * 16;
       live_bytes_a = __builtin_amdgcn_readfirstlane(live ? (int)0xFFFFFFF0u : 0);
     } else {
       pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * BM * 4);
@@ -881,10 +882,10 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     }
     if constexpr (QPRE) {
       // instruction j of this wave: channel slab bn * QS + wave + NW * j, the slab's 16 tile rows (64 bytes each)
-      pb = uniform_ptr(a.B + z * a.b_z_bytes);
+      pb = uniform_ptr(a.B + z * a.b_z_bytes + (long)bn * QS * a.b_group_bytes);
 #pragma unroll
       for (int j = 0; j < QI; ++j)
-        voffb[j] = (unsigned)((unsigned long)(bn * QS + wave + NW * j) * (unsigned long)a.b_group_bytes) + lane * 16;
+        voffb[j] = (unsigned)((unsigned long)(wave + NW * j) * (unsigned long)a.b_group_bytes) + lane * 16;
       live_bytes_b = __builtin_amdgcn_readfirstlane(live ? (int)0xFFFFFFF0u : 0);
     } else {
       pb = uniform_ptr(a.B + z * a.b_z_bytes + (long)bn * BN * 4);
@@ -1373,17 +1374,19 @@ int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N
 /* The same GEMM with the A operand PRE-SPLIT by its producer: A2 [K/16][M][2][16] fp16 = dsee_wino43_input_f16x2's output,
  * scaled by dsee_pow2_scale(a_bound * *amax_a).  No fp32 staging and no conversion pass inside the kernel (the in-kernel
  * split of dsee_gemm_f16x2_af32 costs 0.33 of its 1.95 ms at 512 -> 512 @256^2, profiles/r02_gemm_ablation.md).
- * 256 x 256 tiles only: rows_per_group % 256 == 0 and N % 256 == 0. */
+ * 256 x 256 tiles (256 x 128 when N is an odd multiple of 128): rows_per_group % 256 == 0 and N % 128 == 0. */
 int dsee_gemm_f16x2_pre(const void* A2, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                         const float* amax_a, float a_bound, const float* amax_b, hipStream_t st) {
   DSEE_CHECK_ARG(A2 && B2 && C && amax_a && amax_b && a_bound > 0.f && M > 0 && N > 0 && K > 0 && K % 16 == 0);
-  DSEE_CHECK_ARG(rows_per_group % 256 == 0 && M % rows_per_group == 0 && N % 256 == 0 && b_rows >= N);
+  DSEE_CHECK_ARG(rows_per_group % 256 == 0 && M % rows_per_group == 0 && N % 128 == 0 && b_rows >= N);
   Gemm3Args a = {};
   a.A = (const unsigned char*)A2; a.B = (const unsigned char*)B2; a.C = C;
   a.amax_a = amax_a; a.amax_b = amax_b; a.a_bound = a_bound;
   a.M = M; a.N = N; a.K = K; a.ldc = N; a.rows_per_group = rows_per_group;
   a.a_slab_bytes = M * 64;
   a.b_group_bytes = (long)b_rows * K * 4; a.b_slab_bytes = (long)b_rows * 64; a.nz = 1;
+  // N = 128 (the embedding's adjoint data gradient, K = 1024 gamma/beta channels): 256 x 128 tiles, same 8-wave loop
+  if (N % 256) return launch_gemm3a<2, 4, 4, 1, 2, false, true>(a, st);
   return launch_gemm3a<2, 4, 4, 2, 2, false, true>(a, st);
 }
 
@@ -1478,7 +1481,7 @@ int dsee_gemm_f16x2_tn_qpre(const float* P, const void* Q2, float* C, int groups
                             int splits, const float* amax_p, const float* amax_x, float q_bound, hipStream_t st) {
   DSEE_CHECK_ARG(P && Q2 && C && amax_p && amax_x && q_bound > 0.f && groups > 0 && T % 16 == 0 && rows_p % 256 == 0);
   DSEE_CHECK_ARG(splits > 0 && (T / 16) % splits == 0 && ldc >= rows_q && (rows_q == 160 || rows_q % 128 == 0));
-  DSEE_CHECK_ARG((long)rows_p * 64 < 0x7FFFFFFFL && (long)(rows_q / 16) * groups * T * 64 < 0xFFFFFFF0L);
+  DSEE_CHECK_ARG((long)rows_p * 64 < 0x7FFFFFFFL && (long)16 * groups * T * 64 < 0xFFFFFFF0L);
   Gemm3Args a = {};
   a.A = (const unsigned char*)P; a.B = (const unsigned char*)Q2; a.C = C;
   a.amax_a = amax_p; a.amax_b = amax_x; a.b_bound = q_bound;
@@ -1501,7 +1504,7 @@ int dsee_gemm_f16x2_tn_pqpre(const void* P2, const void* Q2, float* C, int group
   DSEE_CHECK_ARG(P2 && Q2 && C && amax_dy && amax_x && p_bound > 0.f && q_bound > 0.f && groups > 0 && T % 16 == 0);
   DSEE_CHECK_ARG(rows_p % 256 == 0 && splits > 0 && (T / 16) % splits == 0 && ldc >= rows_q);
   DSEE_CHECK_ARG(rows_q == 160 || rows_q % 128 == 0);
-  DSEE_CHECK_ARG((long)(rows_p / 16) * groups * T * 64 < 0xFFFFFFF0L && (long)(rows_q / 16) * groups * T * 64 < 0xFFFFFFF0L);
+  DSEE_CHECK_ARG((long)16 * groups * T * 64 < 0xFFFFFFF0L);   // 16 channel slabs of a 256-wide tile from one 64-bit base
   Gemm3Args a = {};
   a.A = (const unsigned char*)P2; a.B = (const unsigned char*)Q2; a.C = C;
   a.amax_a = amax_dy; a.amax_b = amax_x; a.a_bound = p_bound; a.b_bound = q_bound;

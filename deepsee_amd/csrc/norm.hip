@@ -363,6 +363,52 @@ __device__ __forceinline__ float store_ata(const f32x4 (&v)[4][4], float* __rest
   return vmax;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// The same 36 values written into the PRE-SPLIT fp16x2 image dM2 [rows/16][36*T][2][16] (winograd.hip:
+// wino43_dout_f16x2_kernel): the four lanes of a 16-column slab (consecutive channel quads, same tile) exchange halves so
+// that every lane stores 16 contiguous bytes of the 64-byte row (term 0 | term 1).  `l` = lane, col = packed column.
+__device__ __forceinline__ void store_ata_split(const f32x4 (&v)[4][4], unsigned char* __restrict__ dM2, long T, long t,
+                                                int col, float sc, int l) {
+  f32x4 tmp[6][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 c4[4], o[6];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c4[k] = v[k][j];
+    a6n(c4, o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
+  }
+  const bool odd = (l & 1) != 0;
+  const size_t slab = (size_t)36 * T * 64;
+  unsigned char* rowp = dM2 + (size_t)(col >> 4) * slab + (size_t)t * 64 + (odd ? 32 + ((l & 3) - 1) * 8 : (l & 3) * 8);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    f32x4 o[6];
+    a6n(tmp[k], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      _Float16 h0[4], h1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = o[j][e] * sc;
+        h0[e] = (_Float16)x;
+        h1[e] = (_Float16)(x - (float)h0[e]);
+      }
+      auto pk = [](_Float16 a, _Float16 b) {
+        return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+      };
+      const unsigned p0a = pk(h0[0], h0[1]), p0b = pk(h0[2], h0[3]), p1a = pk(h1[0], h1[1]), p1b = pk(h1[2], h1[3]);
+      const unsigned sa = odd ? p0a : p1a, sb = odd ? p0b : p1b;
+      const unsigned ra = (unsigned)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+      const unsigned rb = (unsigned)__builtin_amdgcn_mov_dpp((int)sb, 0xB1, 0xF, 0xF, true);
+      const u32x4 wv = odd ? (u32x4){ra, rb, p1a, p1b} : (u32x4){p0a, p0b, ra, rb};
+      __builtin_nontemporal_store(wv, reinterpret_cast<u32x4*>(rowp + (size_t)(k * 6 + j) * T * 64));
+    }
+  }
+}
+
 // Pass 1 of the BN + modulate + LeakyReLU backward with the gamma/beta gradient written straight in the Winograd
 // domain: dM[xi][tile][packed gamma col] = (A (g*xhat) A^T)[xi], [packed beta col] = (A g A^T)[xi] -- the operand of the
 // weight / table gradient AND (adjoint form) of the embedding's data gradient; the [M][2C] tensor dgb and the separate
@@ -425,6 +471,92 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_kernel(
       *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 4 + k) * C + c0) = v;
     }
   }
+}
+
+// The pre-split form with its own thread mapping: a wave = 4 consecutive tiles x 64 channels (lane = (tile l >> 4, channel quad
+// l & 15)), so that the 16 lanes of a tile read 256 contiguous bytes of every pixel and a store instruction writes, per
+// 16-column slab, the 64-byte rows of 4 consecutive tiles = 256 contiguous bytes (the (tile, quad) mapping of the fp32 form
+// would scatter 64-byte rows: 2.66 vs 2.2 ms at N = 8, 256^2, C = 512).  A wave keeps its 64 channels for its whole loop
+// (gridDim.x * 4 is a multiple of C/64); the per-channel sums are folded over the wave's 4 tile lanes and written as
+// part[global wave][4][64], summed per channel group in wave order by norm_bwd_split_sums_kernel.
+__global__ __launch_bounds__(256) void norm_bwd_reduce_wino_split_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
+    unsigned char* __restrict__ dM2, float* __restrict__ part, int N, int H, int W, int C, float slope,
+    const float* __restrict__ amax, float bound) {
+  const float sc = dsee_pow2_scale(bound * dsee_amax_read(amax));
+  const int ncg = C >> 6, th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = (T >> 2) * ncg * 64;
+  const int l = threadIdx.x & 63;
+  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c0 = (int)(gw % ncg) * 64 + (l & 15) * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
+  const int pcol = (c0 >> 6) * 128 + ((c0 >> 5) & 1) * 64 + (c0 & 31);
+  f32x4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = ((i >> 6) / ncg) * 4 + (l >> 4);
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th), n = (int)(r / th);
+    f32x4 gg[4][4], gx[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t o = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + c0;
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = dv[e] * (yv[e] > 0.f ? 1.f : slope);
+        const f32x4 d = g * *reinterpret_cast<const f32x4*>(scale + o);
+        gg[k][j] = g;
+        gx[k][j] = g * xh;
+        acc[0] += d;
+        acc[1] += d * xh;
+        acc[2] += gx[k][j];
+        acc[3] += g;
+      }
+    store_ata_split(gx, dM2, T, t, pcol, sc, l);
+    store_ata_split(gg, dM2, T, t, pcol + 32, sc, l);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[k][e] += __shfl_xor(acc[k][e], 16, 64);
+      acc[k][e] += __shfl_xor(acc[k][e], 32, 64);
+    }
+  if (l < 16) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(part + ((size_t)gw * 4 + k) * 64 + l * 4) = acc[k];
+  }
+}
+
+// sums[k][c] = sum over the waves that own channel group c / 64 (global wave index = group mod C/64) of part[wave][k][c % 64]
+__global__ __launch_bounds__(256) void norm_bwd_split_sums_kernel(const float* __restrict__ part, int waves, int C,
+                                                                  float* __restrict__ sums) {
+  __shared__ float sv[32][8];
+  const int k = blockIdx.y, cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl, ncg = C >> 6;
+  float v = 0.f;
+  if (c < C)
+    for (int g = (c >> 6) + lane * ncg; g < waves; g += 32 * ncg) v += part[((size_t)g * 4 + k) * 64 + (c & 63)];
+  sv[lane][cl] = v;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    for (int i = 1; i < 32; ++i) v += sv[i][cl];
+    sums[(size_t)k * C + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void amax_product_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float floor_b, float* __restrict__ out) {
+  const float va = dsee_amax_read(a), vb = fmaxf(dsee_amax_read(b), floor_b);
+  if (threadIdx.x == 0) out[0] = va * vb;
 }
 
 __global__ __launch_bounds__(256) void sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums,
@@ -636,7 +768,8 @@ static int wino_reduce_blocks(int N, int H, int W, int C) {
 }
 
 size_t dsee_modulate_bwd_wino_workspace(int N, int H, int W, int C) {
-  return (size_t)wino_reduce_blocks(N, H, W, C) * 4 * C * sizeof(float);
+  // fp32 form: one row [4][C] per block; pre-split form: one row [4][64] per wave (4 per block)
+  return (size_t)(wino_reduce_blocks(N, H, W, C) + 4) * 4 * (C > 256 ? C : 256) * sizeof(float);   // (+4: grid rounded up to C/64 groups)
 }
 
 int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
@@ -651,6 +784,38 @@ int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* 
   RedGeom g = make_geom(N, H * W, C, 1);
   g.chunks = blocks;  // one partial row [4][C] per block
   sums_finalize_kernel<<<dsee_cdiv((long)4 * C, 8), 256, 0, st>>>(workspace, sums, 4, g);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* ... with dM written PRE-SPLIT: dM2 [rows/16][36*T][2][16] fp16 scaled by the power of two of bound x *amax_g, where
+ * *amax_g >= max |dh| * max(1, max |xhat|) is known before the kernel runs (dsee_amax_product of the maxima the producers of dh
+ * and of the forward pass wrote) and bound >= DSEE_WINO_DM_BOUND.  T % 16 == 0. */
+int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const float* x, const float* scale,
+                                        const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
+                                        int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
+                                        hipStream_t st) {
+  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && dM2 && sums && workspace && amax_g && bound >= 225.f);
+  DSEE_CHECK_ARG(C % 64 == 0 && C <= 1024 && 256 % (C / 4) == 0 && rows == 2 * C && H % 4 == 0 && W % 4 == 0);
+  DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 16 == 0);
+  // a grid whose wave count is a multiple of the C/64 channel groups (every wave keeps its channels)
+  const int ncg = C / 64, m = ncg / (ncg % 4 == 0 ? 4 : (ncg % 2 == 0 ? 2 : 1));
+  int blocks = wino_reduce_blocks(N, H, W, C) / m * m;
+  if (blocks < m) blocks = m;
+  DSEE_CHECK_ARG(blocks <= wino_reduce_blocks(N, H, W, C) || blocks == m);
+  norm_bwd_reduce_wino_split_kernel<<<blocks, 256, 0, st>>>(dh, h, x, scale, mean, invstd,
+                                                            reinterpret_cast<unsigned char*>(dM2), workspace, N, H, W, C, slope,
+                                                            amax_g, bound);
+  DSEE_LAUNCH_CHECK();
+  norm_bwd_split_sums_kernel<<<dim3(dsee_cdiv(C, 8), 4), 256, 0, st>>>(workspace, blocks * 4, C, sums);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* out (64-line slot, zeroed by the caller) <- max(a) * max(floor_b, max(b)): the operand bound of a product of two tensors */
+int dsee_amax_product(const float* a, const float* b, float floor_b, float* out, hipStream_t st) {
+  DSEE_CHECK_ARG(a && b && out);
+  amax_product_kernel<<<1, 64, 0, st>>>(a, b, floor_b, out);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -57,6 +57,7 @@ struct FusedArgs {
   const float* invstd;
   float* out;
   float* amax_h;   // optional: max |out| (64-line form) -- the operand bound of the convolution that consumes h
+  float* amax_xhat;   // optional: max |xhat| -- with max |dh| the bound of the backward pass's gamma/beta gradient
   float* scale;              // may be NULL
   long T;                    // tiles of the whole batch
   long v_slab_bytes, u_slab_bytes, u_group_bytes;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   const f32x4 bg = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + rg * 64 + chunk_r * 4) : z4;
   const f32x4 bb = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + rg * 64 + 32 + chunk_r * 4) : z4;
   const int chw = ((wq * 4 + oc) ^ (tl_w & 7)) * 4;       // write phase: this lane's channel quad 16 wq + 4 oc, swizzled
-  float hmax = 0.f;
+  float hmax = 0.f, xmax = 0.f;
   static_for<(DSEE_FUSED_ABL & 16) ? 0 : 4>([&](auto k_c) {
     constexpr int k = decltype(k_c)::value;
     static_for<4>([&](auto j_c) {
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
       __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + off));
       hmax = fmaxf(hmax, dsee_absmax4(v));
+      xmax = fmaxf(xmax, dsee_absmax4(xh));
     }
     if constexpr (k < 3) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -498,6 +500,15 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     if (lane == 0) {
       unsigned* line = reinterpret_cast<unsigned*>(a.amax_h + ((blockIdx.x * 8 + wave) & (DSEE_AMAX_LINES - 1)) * DSEE_AMAX_STRIDE);
       const unsigned bits = __builtin_bit_cast(unsigned, hmax);
+      if (bits > __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(line, bits);
+    }
+  }
+  if (a.amax_xhat) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+    if (lane == 0) {
+      unsigned* line = reinterpret_cast<unsigned*>(a.amax_xhat + ((blockIdx.x * 8 + wave) & (DSEE_AMAX_LINES - 1)) * DSEE_AMAX_STRIDE);
+      const unsigned bits = __builtin_bit_cast(unsigned, xmax);
       if (bits > __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(line, bits);
     }
   }
@@ -528,7 +539,7 @@ void dsee_fused_set_stamps(float* p) { g_fused_stamps = p; }
 int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
                          const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                          float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                         float slope, float* amax_h, hipStream_t st) {
+                         float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
   DSEE_CHECK_ARG(V2 && U2 && amax_cat && amax_u && x && mean && invstd && out_h);
   DSEE_CHECK_ARG(rows == 2 * C && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && (K == 128 || K == 160));
   DSEE_CHECK_ARG(groups == 1 || groups == N);
@@ -547,6 +558,7 @@ int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, 
   a.out = out_h;
   a.scale = out_scale;
   a.amax_h = amax_h;
+  a.amax_xhat = amax_xhat;
   a.T = T;
   a.v_slab_bytes = 36L * T * 64;
   a.u_slab_bytes = (long)rows * 64;

@@ -806,8 +806,10 @@ template <typename TM>
 __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const TM* __restrict__ dV,
                                                                    const float* __restrict__ mask, int mask_ld,
                                                                    float* __restrict__ dx, int N, int H, int W, int C,
-                                                                   const float* __restrict__ mscale) {
+                                                                   const float* __restrict__ mscale,
+                                                                   float* __restrict__ amax = nullptr) {
   const float ms = mscale ? *mscale : 1.f;
+  float vmax = 0.f;
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -885,8 +887,10 @@ __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const TM* __r
           for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
         }
         st4b(dx + px * C + q * 4, v);
+        vmax = fmaxf(vmax, dsee_absmax4(v));
       }
-    }
+  }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);   // max |dx|: dx is the gradient w.r.t. a norm's output (-> dM2 bound)
 }
 
 // G g G^T of one 3x3 filter -> u[36]
@@ -1236,6 +1240,15 @@ int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, f
                                                       dvscale);
   else
     wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, mask, mask_ld, dx, N, H, W, C, nullptr);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* dsee_wino43_input_adjoint (fp32 dV) that also writes max |dx| (64-line form) */
+int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int W, int C, float* amax_dx, hipStream_t st) {
+  DSEE_CHECK_ARG(dV && dx && amax_dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
+  wino43_input_adjoint_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dV, nullptr, 0, dx, N, H, W, C,
+                                                                                          nullptr, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

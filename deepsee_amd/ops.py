@@ -379,6 +379,8 @@ def _gemm_name(split):
 PRESPLIT_A = True
 # A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
 PRESPLIT_DM = True
+# ... and the gamma/beta gradient of a SPADE/SEAN norm as well (False: fp32 dM from the norm backward's reduce pass)
+PRESPLIT_GB = True
 FUSED_V_BOUND = 100.0       # |B^T d B| <= 100 max|d| for F(4x4,3x3): scale of a pre-split V from max |input|
 
 
@@ -587,7 +589,11 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
         else:
             L.call("gemm_bf16x3_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0)
     dx = new(nb, h, wd, r_s)
-    L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s, dvs)
+    if mask is None and dvs is None and PRESPLIT_DM:
+        dx.dsee_amax = amax_slot()     # (dx is the gradient w.r.t. a norm's output: bound of that norm's gamma/beta gradient)
+        L.call("wino43_input_adjoint_amax", dv, dx, nb, h, wd, r_s, dx.dsee_amax)
+    else:
+        L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s, dvs)
     return dx
 
 
@@ -1305,7 +1311,7 @@ def bn_stats(x, running_mean, running_var, training):
 FUSE_DM = True
 
 
-def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=None):
+def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=None, xhat_amax=None):
     """Backward of BN + modulate + LeakyReLU: (dx, dgb, col_sums [2][C], dM).  With SyncBN (`cfg`) the two per-channel
     sums of the BN backward are all-reduced over the ranks between the reduce and the apply pass.  `as_dm`: the
     gamma/beta gradient leaves the reduce pass as dM = A (g*xhat | g) A^T [36][T][rows] (dgb is None)."""
@@ -1313,8 +1319,20 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     dx = torch.empty_like(x)
     sums = new(4, c)
     dgb = dm = None
-    if as_dm:
-        dm = (new(36, n * (h // 4) * (w // 4), rows), amax_slot() if (GEMM_SPLIT and (GEMM_F16X2 or HALF)) else None)
+    t = n * (h // 4) * (w // 4)
+    dha = getattr(dh, "dsee_amax", None)
+    if as_dm and PRESPLIT_DM and PRESPLIT_GB and xhat_amax is not None and dha is not None and t % 256 == 0 and not HALF:
+        # max |dh| (written by the kernel that produced dh) x max(1, max |xhat|) (written by the forward pass) bounds both halves
+        # (g * xhat | g) of the gradient: dM leaves the reduce pass pre-split, for the table / embedding weight gradient's P
+        # operand and the adjoint data-gradient GEMM's A operand
+        ga = amax_slot()
+        L.call("amax_product", dha, xhat_amax, 1.0, ga)
+        dm = (_i16(36 * t * rows * 2), ga, True)
+        ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
+        L.call("modulate_bwd_reduce_wino_f16x2", dh.contiguous(), out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c,
+               LRELU_SLOPE, ws, ga, DM_BOUND)
+    elif as_dm:
+        dm = (new(36, t, rows), amax_slot() if (GEMM_SPLIT and (GEMM_F16X2 or HALF)) else None)
         ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
         L.call("modulate_bwd_reduce_wino", dh.contiguous(), out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c,
                LRELU_SLOPE, ws, dm[1])
@@ -1473,10 +1491,12 @@ class SeanNormTable(torch.autograd.Function):
             with _timed("spade_fused_fwd", 2.0 * 36 * t * ld * rows,
                         4.0 * 36 * t * ld + 4.0 * n * h * w * c * (3 if need_scale else 2)):
                 hm = amax_slot()     # max |h|: the convolution that consumes h writes its V pre-split with this bound
+                xm = amax_slot() if need_scale else None     # max |xhat|: bounds the backward pass's gamma/beta gradient
                 L.call("spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
                        scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE,
-                       hm)
+                       hm, xm)
                 out.dsee_amax = hm
+                ctx.xhat_amax = xm
             keep = None
             if KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
                 if PRESPLIT_A:
@@ -1541,7 +1561,11 @@ class SeanNormTable(torch.autograd.Function):
         as_dm = (FUSE_DM and wino_w and nb == n and _wgrad_mode(ld, rows) != 1 and (fused_d or not ctx.has_a)
                  and 256 % (c // 4) == 0)
         add = ctx.grad_sink.take() if ctx.grad_sink is not None else None
-        dx, dgb, cs, dm_all = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync, as_dm, add)
+        # (pre-split dM needs both of its consumers on the pre-split kernels: the TN weight gradient reads the kept V2, the
+        # adjoint GEMM takes 256-row tiles)
+        pre_ok = vcat is not None and len(vcat) == 3 and _wgrad_mode(ld, rows) == 2 and (not ctx.has_a or fused_d)
+        dx, dgb, cs, dm_all = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync, as_dm, add,
+                                           getattr(ctx, "xhat_amax", None) if pre_ok else None)
 
         def wino_wgrad():
             dw2a = dtable = None
@@ -1565,10 +1589,10 @@ class SeanNormTable(torch.autograd.Function):
                 with _timed(_wgrad_name(mode), 2.0 * 36 * nb * tpi * ld * rows):
                     if ctx.has_t:
                         L.call("wino43_wgrad_table", v[0], dm[0], wsw, nbytes, dwc, dtable[n0:n0 + nb], nb * tpi, nb, ca,
-                               rows, lab.nc, 5 if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
+                               rows, lab.nc, (6 if len(dm) == 3 else 5) if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
                     else:
                         L.call("wino43_wgrad", v[0], dm[0], wsw, nbytes, dwc, nb * tpi, ld, rows, rows, NHIDDEN,
-                               5 if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
+                               (6 if len(dm) == 3 else 5) if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
                 if dwc is not None:
                     dw2a = dwc if dw2a is None else dw2a.add_(dwc)
                 if fused_d:

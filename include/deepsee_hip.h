@@ -142,7 +142,8 @@ int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N
 /* ... and with the A operand pre-split by its producer (round 3): A2 [K/16][M][2][16] fp16 written by
  * dsee_wino43_input_f16x2 with the power-of-two scale of a_bound x *amax_a fixed BEFORE the transform runs (a_bound >= 100
  * bounds |B^T d B| / max|d|), so the GEMM streams both operands global -> LDS without staging or conversion.  256 x 256
- * tiles only (rows_per_group % 256 == 0, N % 256 == 0).  Layers: architecture.py:98,122 (forward convolutions). */
+ * (256 x 128 for N an odd multiple of 128) tiles: rows_per_group % 256 == 0, N % 128 == 0.  Layers: architecture.py:98,122
+ * (forward convolutions), the adjoint data gradients. */
 int dsee_gemm_f16x2_pre(const void* A2, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                         const float* amax_a, float a_bound, const float* amax_b, hipStream_t stream);
 int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
@@ -196,14 +197,16 @@ int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, in
  *   h [, scale] = dsee_spade_fused_fwd(...)   K = 128 (SPADE / capped) or 160 (SEAN: 128 + 32 one-hot), rows = 2 C,
  *        C % 32 == 0, (H/4)*(W/4) % 64 == 0, groups = N (per-image style tables) or 1; out_scale may be NULL.
  *        amax_h (optional, 64-line form, zeroed by the caller): receives max |h| -- the bound the convolution that consumes h
- *        needs BEFORE its input transform runs (dsee_wino43_input_f16x2 + dsee_gemm_f16x2_pre). */
+ *        needs BEFORE its input transform runs (dsee_wino43_input_f16x2 + dsee_gemm_f16x2_pre); amax_xhat (optional, same
+ *        form): receives max |xhat|, which with max |dh| bounds the gamma/beta gradient of the backward pass
+ *        (dsee_modulate_bwd_reduce_wino_f16x2). */
 #define DSEE_WINO_V_BOUND 100.0f   /* |B^T d B| <= 100 max|d| for the F(4x4,3x3) input transform */
 int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C, const float* amax_x, float bound,
                             hipStream_t stream);
 int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
                          const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                          float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                         float slope, float* amax_h, hipStream_t stream);
+                         float slope, float* amax_h, float* amax_xhat, hipStream_t stream);
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
                             float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,
@@ -237,7 +240,7 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
                       long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, const float* amax_v,
                       const float* amax_dm, hipStream_t stream);
 /* split = 6: as split = 5 and dM is the pre-split dM2 of dsee_wino43_dout_f16x2 (bound DSEE_WINO_DM_BOUND), amax_dm = max |dY|
- * (dsee_gemm_f16x2_tn_pqpre; dsee_wino43_wgrad only).
+ * (dsee_gemm_f16x2_tn_pqpre).
  * split = 5: V is the PRE-SPLIT fp16x2 transform dsee_wino43_input_f16x2 wrote for the forward pass with bound
  * DSEE_WINO_V_BOUND (cast to const float*), amax_v = max |x| of the layer input (dsee_gemm_f16x2_tn_qpre).
  * split = 3: as split = 2 with two-term fp16 splits (dsee_gemm_f16x2_tn_f32; amax_v / amax_dm = max |V|, max |dM|).
@@ -371,6 +374,16 @@ size_t dsee_modulate_bwd_wino_workspace(int N, int H, int W, int C);
 int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                                   const float* invstd, float* dM, int rows, float* sums, int N, int H, int W, int C,
                                   float slope, float* workspace, float* amax, hipStream_t stream);
+/* dsee_modulate_bwd_reduce_wino with dM written PRE-SPLIT (round 3): dM2 [rows/16][36*T][2][16] fp16, scale = power of two of
+ * bound x *amax_g with *amax_g >= max |dh| * max(1, max |xhat|) (dsee_amax_product of the maxima written by
+ * dsee_wino43_input_adjoint_amax and dsee_spade_fused_fwd), bound >= DSEE_WINO_DM_BOUND.  Consumers: dsee_wino43_wgrad[_table]
+ * (split = 6) and dsee_gemm_f16x2_pre (adjoint data gradient of the embedding). */
+int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const float* x, const float* scale,
+                                        const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
+                                        int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
+                                        hipStream_t stream);
+int dsee_amax_product(const float* a, const float* b, float floor_b, float* out, hipStream_t stream);
+int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int W, int C, float* amax_dx, hipStream_t stream);
 int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                             const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
                             float inv_count, float slope, hipStream_t stream);

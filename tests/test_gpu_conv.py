@@ -506,6 +506,39 @@ def test_dout_transform_pre_split_with_channel_sums(n, h, c):
         assert rel(got.cpu(), want.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("n,h,c", [(2, 32, 64), (1, 64, 128), (4, 32, 512)])
+def test_norm_backward_reduce_writes_pre_split_gradient(n, h, c):
+    """dsee_modulate_bwd_reduce_wino_f16x2: the gamma/beta gradient A (g*xhat | g) A^T leaves the norm backward's reduce pass
+    as the pre-split fp16x2 image, scaled from the a-priori bound 225 x max|dh| x max(1, max|xhat|) (dsee_amax_product of two
+    maxima written by earlier kernels).  Equal to the fp32 form to 2^-21 of the tensor maximum; identical per-channel sums; the
+    bound really bounds."""
+    from deepsee_amd import lib as L, ops
+    g = torch.Generator().manual_seed(n * h + c)
+    x = (torch.randn(n, h, h, c, generator=g) * 2 + 0.3).cuda()
+    dh = (torch.randn(n, h, h, c, generator=g) * 0.01).cuda()
+    out = torch.randn(n, h, h, c, generator=g).cuda()             # (only its sign is used: LeakyReLU branch)
+    scale = (torch.rand(n, h, h, c, generator=g) + 0.5).cuda()
+    mean, invstd = (torch.randn(c, generator=g) * 0.3).cuda(), (torch.rand(c, generator=g) + 0.5).cuda()
+    rows, t = 2 * c, n * (h // 4) ** 2
+    ws = ops.scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, h, c), "norm")
+    ref, ra, sums_ref = ops.new(36, t, rows), ops.amax_slot(), ops.new(4, c)
+    L.call("modulate_bwd_reduce_wino", dh, out, x, scale, mean, invstd, ref, rows, sums_ref, n, h, h, c, 0.2, ws, ra)
+    a_dh, a_xh = ops.tensor_amax(dh), ops.tensor_amax(((x - mean) * invstd).contiguous())
+    ga = ops.amax_slot()
+    L.call("amax_product", a_dh, a_xh, 1.0, ga)
+    dm2, sums = ops._i16(36 * t * rows * 2), ops.new(4, c)
+    L.call("modulate_bwd_reduce_wino_f16x2", dh, out, x, scale, mean, invstd, dm2, rows, sums, n, h, h, c, 0.2, ws, ga, 225.0)
+    torch.cuda.synchronize()
+    bound = 225.0 * float(ga.max())
+    want = float(dh.abs().max()) * max(1.0, float(((x - mean) * invstd).abs().max()))
+    assert abs(float(ga.max()) - want) <= 1e-6 * want
+    assert float(ref.abs().max()) <= bound
+    dec = dm2.view(torch.float16).view(rows // 16, 36 * t, 2, 16).float().sum(2).permute(1, 0, 2).reshape(36, t, rows)
+    dec = dec / _pow2_scale(bound)
+    assert float((dec - ref).abs().max()) <= 2.0 ** -20 * float(ref.abs().max())
+    assert rel(sums.cpu(), sums_ref.cpu()) < 1e-5          # (same sums, folded in a different fixed order)
+
+
 def test_f16x2_special_values():
     """Edges of the operand split: zero operands (scale 1, result exactly 0), values 2^20 below the operand maximum
     (h1 subnormal: absolute error <= 2^-39 of the maximum), huge / tiny magnitudes (the power-of-two scale keeps fp16 in
@@ -652,11 +685,13 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale):
     for it in range(4):
         L.call("selftest_lds_poison", sink)
         out.fill_(float("nan"))
-        hm = ops.amax_slot()
+        hm, xm = ops.amax_slot(), ops.amax_slot()
         L.call("spade_fused_fwd", v2, u, ac, 100.0, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), out, sc, n, h, h, c, rows, K,
-               n if per_image else 1, add_one, 0.2, hm)
+               n if per_image else 1, add_one, 0.2, hm, xm)
         torch.cuda.synchronize()
         assert float(hm.max()) == float(out.abs().max())      # the maximum the consumer's operand scale is built from
+        xh_max = float((((xd - mean.cuda()) * invstd.cuda()).abs()).max())
+        assert abs(float(xm.max()) - xh_max) <= 1e-5 * xh_max
         assert torch.isfinite(out).all(), "NaN from a poisoned LDS stage (launch %d)" % it
         if first is None:
             first = out.clone()
@@ -735,7 +770,7 @@ def test_small_channel_keeps_its_precision_in_the_fused_spade_kernel():
     u, ua = ops._wino_u(w2a.cuda(), rows, ca, False, rows, K, 2)
     out = torch.empty_like(xd)
     L.call("spade_fused_fwd", v2, u, ac, ops.FUSED_V_BOUND, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), out, None, n, h, h,
-           c, rows, K, 1, 1.0, 0.2, None)
+           c, rows, K, 1, 1.0, 0.2, None, None)
     torch.cuda.synchronize()
     got = out.cpu().double().permute(0, 3, 1, 2)
     e5, e_all = rel(got[:, 5], ref[:, 5]), rel(got, ref)

@@ -671,7 +671,7 @@ def test_half_mode_vs_oracle():
 
 SWITCHES = [("KEEP_V", False), ("ADJOINT_DGRAD", False), ("FUSE_DM", False), ("FUSE_NOISE", False), ("GEMM_AF32", False),
             ("FUSED_NORM", False), ("THIN_GEMM", False), ("GEMM_F16X2", False), ("GEMM_SPLIT", False),
-            ("WINOGRAD_WGRAD", False), ("WINOGRAD_MOD", False), ("CONV_F16X2_MIN_FLOP", 0.0), ("DOUT_SUMS", False), ("SHARE_STATS", False), ("PRODUCER_STATS", False), ("PRESPLIT_A", False), ("PRESPLIT_DM", False)]
+            ("WINOGRAD_WGRAD", False), ("WINOGRAD_MOD", False), ("CONV_F16X2_MIN_FLOP", 0.0), ("DOUT_SUMS", False), ("SHARE_STATS", False), ("PRODUCER_STATS", False), ("PRESPLIT_A", False), ("PRESPLIT_DM", False), ("PRESPLIT_GB", False)]
 
 
 def test_kernel_path_switches():

@@ -29,7 +29,7 @@ def bench(n, h, c, ld, per_image, reps=5, scale=True):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         L.call("spade_fused_fwd", v2, u, ac, 100.0, ua, b2, x, mean, invstd, out, sc if scale else None, n, h, h, c, rows, ld,
-               n if per_image else 1, 1.0, 0.2, None)
+               n if per_image else 1, 1.0, 0.2, None, None)
         e.record()
         torch.cuda.synchronize()
         ts.append(s.elapsed_time(e))
