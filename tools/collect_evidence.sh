@@ -26,8 +26,9 @@ python $R/tools/rocpd_summary.py /tmp/prof/ev_results.db > $O/kernel_stats.md
 for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-run --no-graphs > /dev/null 2>&1; done
 python $R/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE/*counter_collection.csv /tmp/pmc_WRITE_SIZE/*counter_collection.csv > $O/pmc_traffic.json
 ls -la $O
-for v in True False True False; do python tools/exp/ab.py PRESPLIT_DM=$v -- --steps 8 --warmup 2 --no-cpu-baseline --no-f32-run 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('PRESPLIT_DM=$v ms_per_step', d['ms_per_step'])"; done > $O/ab_presplit_dm.txt
+cd $R
+for sw in PRESPLIT_DM PRESPLIT_GB; do for v in True False True False; do python tools/exp/ab.py $sw=$v -- --steps 8 --warmup 2 --no-cpu-baseline --no-f32-run 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=$v ms_per_step', d['ms_per_step'])"; done; done > $O/ab_presplit_dm.txt
 cd $R && bash tools/exp/build_fused_abl.sh 1 2 4 8 16 64 > /dev/null 2>&1
 for m in 1 2 4 8 16 64; do DSEE_LIB=tools/exp/libfabl_$m.so python tools/exp/fused_kernel_bench.py 2>&1 | grep -v amdgpu.ids; done > $O/fused_ablation.txt
 cd $R && python -m pytest tests -q -m gpu -s > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log | tail -2
