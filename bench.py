@@ -239,6 +239,7 @@ def main():
         ms = sum(s.elapsed_time(e) for s, e, _ in recs)
         kernels[name] = {"launches": len(recs), "ms": ms, "tflop": sum(f for _, _, f in recs) / 1e12,
                          "gb": ops.PROFILE_BYTES.get(name, 0.0) / 1e9}
+    fused_is_r3 = "spade_fused_fwd" in kernels
     fused = kernels.pop("spade_fused_fwd", None) or kernels.pop("spade_modulate_fused", None)
     norm_fwd = {k: kernels.pop(k) for k in list(kernels) if k.startswith("norm_forward@")}
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
@@ -345,7 +346,17 @@ def main():
                              "timed_half_steps_replayed": tm.graph_stats["replayed"] - replays_before, "timed_half_steps": 2 * args.steps,
                              "note": "G and D step replayed as hipGraphs (one per encoder-branch variant; first occurrence "
                                      "eager, second captured); host_enqueue_ms_per_step is the Python time per step"}
-        if fused:
+        if fused and not fused_is_r3:
+            # 16-bit mode / --arith bf16x3: the norms take the round-2 path (gamma/beta GEMM, then this fused output transform)
+            g = fused["gb"] / (fused["ms"] / 1e3)
+            out["spade_fused"] = {
+                "kernel": "wino43_output_modulate (round-2 form: output transform + BN-normalise + SPADE/SEAN modulate + "
+                          "LeakyReLU over the gamma/beta GEMM's product M; the fused round-3 kernel exists in the two-term "
+                          "fp16x2 form only)",
+                "bound": "hbm", "launches": fused["launches"], "ms_per_step": fused["ms"], "achieved": g,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
+                "bytes_note": "bytes the kernel moves: M read, x read, h and scale written"}
+        elif fused:
             g = fused["gb"] / (fused["ms"] / 1e3)
             out["spade_fused"] = {
                 "kernel": "spade_fused_fwd (gamma/beta Winograd GEMM, output transform folded in registers, BN-normalise + "
