@@ -1029,7 +1029,8 @@ __global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ slab, float
                                     : (size_t)(ci >> 5) * (KH * KW * 32) + (size_t)tap * 32 + (ci & 31);
     const size_t o = (size_t)co * Kpad + kcol;
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += slab[(size_t)s * rows * Kpad + o];
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) v += slab[(size_t)s * rows * Kpad + o];   // (8 partial loads in flight per thread)
     dw[i] = v;
   }
 }
@@ -1046,6 +1047,7 @@ __global__ void wgrad_table_unpack_kernel(const float* __restrict__ slab, float*
     const int tap = (int)(t % ntaps), n = (int)(t / ntaps);
     float v = 0.f;
     if (r < L)
+#pragma unroll 8
       for (int j = 0; j < sper; ++j)
         v += slab[((size_t)(n * sper + j) * rows + row) * Kpad + k0 + tap * 32 + r];
     dt[i] = v;
