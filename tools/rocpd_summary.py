@@ -17,7 +17,7 @@ rows = list(con.execute(q))
 tot = sum(r[2] for r in rows)
 print("| kernel | calls | total ms | avg us | min us | max us | % |")
 print("|---|---|---|---|---|---|---|")
-for name, n, t, mn, mx in rows[:40]:
+for name, n, t, mn, mx in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     nm = name if len(name) < 110 else name[:107] + "..."
     print("| `%s` | %d | %.2f | %.1f | %.1f | %.1f | %.2f |" % (nm, n, t / 1e6, t / n / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / tot))
 print("\ntotal GPU kernel time %.1f ms over %d kernels (%d distinct)" % (tot / 1e6, sum(r[1] for r in rows), len(rows)))
