@@ -131,59 +131,71 @@ __global__ void onehot_pack_kernel(const float* __restrict__ w, float* __restric
   wt[i] = w[((size_t)co * L + r) * 9 + tap];
 }
 
-// Weight gradient of the one-hot conv.  Block = 128 channels x 8 tap groups; each thread owns its channel's
-// accumulator column in LDS ([9*L][128] floats), so no atomics and a fixed summation order.
+// Weight gradient of the one-hot conv.  Block = 128 channels x 8 tap groups (group g owns tap g, group 7 taps 7 and 8, group 0
+// also the bias).  A thread keeps the LT label accumulators of its tap(s) and channel in REGISTERS and updates them with a
+// compare-select chain (acc[k] += label == k ? g : 0): the LDS form -- one float atomic per pixel, tap and channel -- was
+// bound by the LDS atomic unit at 0.45 ms for 0.5 M pixels whatever the number of waves or the load pipelining.  Fixed
+// summation order per thread, partial rows [9*L + 1][128] per block as before.
+template <int LT>
 __global__ __launch_bounds__(1024) void onehot_conv_wgrad_kernel(const uint8_t* __restrict__ lab,
                                                                 const float* __restrict__ dact, int dld,
                                                                 const float* __restrict__ act, int ald, int N,
                                                                 int H, int W, int shift, int R, int Rw, int L,
                                                                 int chunk_px, float* __restrict__ part) {
-  extern __shared__ float accs[];  // [9*L + 1][128]   (last row: bias gradient)
   const int c = threadIdx.x & 127, tg = threadIdx.x >> 7;
   const int rows = 9 * L + 1;
-  for (int i = threadIdx.x; i < rows * 128; i += 1024) accs[i] = 0.f;
-  __syncthreads();
   const long M = (long)N * R * Rw;
   const long m0 = (long)blockIdx.x * chunk_px, m1 = min(M, m0 + chunk_px);
-  // 8 tap groups x 128 channels (16 waves per CU: the loop is a chain of dependent global -> LDS operations and one block
-  // fills a CU's LDS; with 2 groups = 4 waves it ran at 1.1 TB/s): group g owns tap g, group 7 taps 7 and 8, group 0 the bias
-  const int t0 = tg, t1 = tg == 7 ? 9 : tg + 1;
-  // 8 pixels per trip: the global loads of a trip are issued together (the loop is latency-bound otherwise) and
-  // the LDS updates are fire-and-forget ds_add_f32 (each address is owned by exactly one thread, program order kept)
-  constexpr int U = 8;
+  const int t0 = tg;
+  const bool two = tg == 7;        // (wave-uniform: a wave = 64 channels of one tap group)
+  float acc0[LT], acc1[LT], accb = 0.f;
+#pragma unroll
+  for (int k = 0; k < LT; ++k) acc0[k] = acc1[k] = 0.f;
+  constexpr int U = 8;   // pixels per trip: their loads are issued together
   for (long mb = m0; mb < m1; mb += U) {
     float gv[U];
+    int r0[U], r1[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const long m = mb + j;
-      float g = 0.f;
-      if (m < m1) {
-        g = act[(size_t)m * ald + c] > 0.f ? dact[(size_t)m * dld + c] : 0.f;
-      }
-      gv[j] = g;
+      gv[j] = m < m1 ? (act[(size_t)m * ald + c] > 0.f ? dact[(size_t)m * dld + c] : 0.f) : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const long m = mb + j;
-      if (m >= m1) break;
-      const float g = gv[j];
       const int w = (int)(m % Rw);
       const long t = m / Rw;
       const int h = (int)(t % R), n = (int)(t / R);
-      for (int tap = t0; tap < t1; ++tap) {
-        const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
-        if (hh >= 0 && hh < R && ww >= 0 && ww < Rw) {
-          const int r = lab_at(lab, n, H, W, shift, hh, ww);
-          __hip_atomic_fetch_add(&accs[(tap * L + r) * 128 + c], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+      {
+        const int hh = h + t0 / 3 - 1, ww = w + t0 % 3 - 1;
+        r0[j] = (m < m1 && hh >= 0 && hh < R && ww >= 0 && ww < Rw) ? lab_at(lab, n, H, W, shift, hh, ww) : -1;
       }
-      if (tg == 0)
-        __hip_atomic_fetch_add(&accs[(9 * L) * 128 + c], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      r1[j] = -1;
+      if (two) {
+        const int hh = h + 1, ww = w + 1;   // tap 8
+        r1[j] = (m < m1 && hh < R && ww < Rw) ? lab_at(lab, n, H, W, shift, hh, ww) : -1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const float g = gv[j];
+      accb += g;
+#pragma unroll
+      for (int k = 0; k < LT; ++k) acc0[k] += r0[j] == k ? g : 0.f;
+      if (two) {
+#pragma unroll
+        for (int k = 0; k < LT; ++k) acc1[k] += r1[j] == k ? g : 0.f;
+      }
     }
   }
-  __syncthreads();
   float* o = part + (size_t)blockIdx.x * rows * 128;
-  for (int i = threadIdx.x; i < rows * 128; i += 1024) o[i] = accs[i];
+#pragma unroll
+  for (int k = 0; k < LT; ++k)
+    if (k < L) {
+      o[(t0 * L + k) * 128 + c] = acc0[k];
+      if (two) o[(8 * L + k) * 128 + c] = acc1[k];
+    }
+  if (tg == 0) o[(9 * L) * 128 + c] = accb;
 }
 
 __global__ void onehot_wgrad_finalize_kernel(const float* __restrict__ part, int nparts, int L, float* __restrict__ dw,
@@ -354,15 +366,10 @@ int dsee_onehot_conv3x3_wgrad(const uint8_t* lab, const float* dact, int dact_ld
   const long M = (long)N * R * Rw;
   int cp;
   const int parts = wgrad_parts(M, &cp);
-  const size_t lds = (size_t)(9 * L + 1) * 128 * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&onehot_conv_wgrad_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (9 * 32 + 1) * 128 * (int)sizeof(float));
-    attr_done = true;
-  }
-  onehot_conv_wgrad_kernel<<<parts, 1024, lds, st>>>(lab, dact, dact_ld, act, act_ld, N, H, W, shift, R, Rw, L, cp,
-                                                    workspace);
+  if (L <= 20)
+    onehot_conv_wgrad_kernel<20><<<parts, 1024, 0, st>>>(lab, dact, dact_ld, act, act_ld, N, H, W, shift, R, Rw, L, cp, workspace);
+  else
+    onehot_conv_wgrad_kernel<32><<<parts, 1024, 0, st>>>(lab, dact, dact_ld, act, act_ld, N, H, W, shift, R, Rw, L, cp, workspace);
   DSEE_LAUNCH_CHECK();
   onehot_wgrad_finalize_kernel<<<dsee_cdiv((long)(9 * L + 1) * 128, 256), 256, 0, st>>>(workspace, parts, L, dw_oihw,
                                                                                         dbias);
