@@ -533,3 +533,30 @@ def test_rank_core_sets_partition_the_allowed_cores():
     assert all(s == list(range(s[0], s[0] + 4)) for s in sets)
     assert parallel.rank_core_set(5, 8, [0, 1]) == [0, 1]          # fewer cores than ranks: everybody keeps what there is
     assert parallel.pin_rank_cores(0, 1) is None                   # single rank: untouched
+
+
+def test_presplit_path_selection_rules():
+    """Host-side rules that decide when a Winograd layer takes round 3's pre-split operand kernels (deepsee_amd/ops.py): the
+    input's maximum must have been written by its producer, the GEMM must be big enough for 256 x 256 tiles, and -- when the
+    weight gradient will read the same V2 -- the reduction width must be one the transpose-read TN kernel takes."""
+    import torch
+    from deepsee_amd import ops
+    x = torch.zeros(1)
+    assert not ops._presplit_ok(x, 32768, 32768, 512)                       # no maximum known in advance
+    x.dsee_amax = torch.zeros(2048)
+    assert ops._presplit_ok(x, 32768, 32768, 512)                           # 512 -> 512 @256^2, bs = 8
+    assert ops._presplit_ok(x, 2048, 2048, 512)                             # @64^2: 288 x 2 tiles of 256 x 256
+    assert not ops._presplit_ok(x, 512, 512, 512)                           # @32^2: too few tiles, 128 x 128 kernel
+    assert not ops._presplit_ok(x, 32768, 32768, 384)                       # output width not a multiple of 256
+    assert not ops._presplit_ok(x, 32768, 4096 + 64, 512)                   # group size not a multiple of 256
+    assert ops._presplit_ok(x, 32768, 32768, 512, k_s=160, keep=True) and ops._presplit_ok(x, 32768, 32768, 512, 256, True)
+    assert not ops._presplit_ok(x, 32768, 32768, 512, k_s=96, keep=True)    # TN kernel: 160 or a multiple of 128 columns
+    saved = ops.PRESPLIT_A
+    try:
+        ops.PRESPLIT_A = False
+        assert not ops._presplit_ok(x, 32768, 32768, 512)
+    finally:
+        ops.PRESPLIT_A = saved
+    # the channel sums that ride in the A dY A^T pass / the statistics rows of a producer need 256 % (C/4) == 0
+    assert ops._dout_sums_ok(8, 8, 512, 2) and not ops._dout_sums_ok(8, 4, 512, 2) and not ops._dout_sums_ok(8, 8, 512, 1)
+    assert ops._stats_rows_ok(512) and ops._stats_rows_ok(64) and not ops._stats_rows_ok(96 * 4 + 4)
