@@ -100,8 +100,31 @@ def effective_cores():
     return n
 
 
-def cpu_baseline():
-    """Oracle G+D iteration at bs=1 (32->256) on the host cores; ~10-30 s of CPU work."""
+def cpu_model():
+    """CPU model string of the host (/proc/cpuinfo)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_ram_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemTotal"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(bs=1, iters=3):
+    """The oracle's G+D iteration (32->256) on the host cores: 1 untimed warm-up + `iters` timed iterations at batch `bs`
+    (BASELINE.md 3).  The default (bs = 1, 3 iterations) is ~30 s of CPU work; `--cpu-baseline-bs 8` times the benchmark's
+    own batch (needs >= 64 GB of host RAM, ~7 GB RSS per image, minutes of CPU time)."""
     from oracle import deepsee_oracle as O
     cores = effective_cores()
     torch.set_num_threads(cores)
@@ -109,16 +132,25 @@ def cpu_baseline():
     o = O.Oracle(small, O.init_state(small, seed=0))
     b = O.synthetic_batch(small, 1, seed=1)
     o.run_generator_one_step(b)           # untimed: library warm-up on a tiny config
-    opt = O.make_opt()
+    ram = host_ram_gb()
+    if bs > 1 and ram < 64:
+        bs = 1
+    opt = O.make_opt(batchSize=bs)
     orc = O.Oracle(opt, O.init_state(opt, seed=0))
-    batch = O.synthetic_batch(opt, 1, seed=1234)
-    t0 = time.perf_counter()
-    orc.run_generator_one_step(batch)
-    orc.run_discriminator_one_step(batch)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 G+D iteration, bs=1, independent 8x 32->256 fp32, oracle/deepsee_oracle.py (PyTorch-CPU "
-                      "restatement pinned to the reference), %.1f s" % dt}
+    batch = O.synthetic_batch(opt, bs, seed=1234)
+    times = []
+    for it in range(iters + 1):           # iteration 0 is the warm-up at the real size
+        t0 = time.perf_counter()
+        orc.run_generator_one_step(batch)
+        orc.run_discriminator_one_step(batch)
+        if it:
+            times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    return {"value": bs / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(), "host_ram_gb": round(ram, 1), "batch": bs, "iterations": len(times),
+            "s_per_iteration": [round(t, 2) for t in times],
+            "sample": "1 warm-up + %d timed G+D iterations, bs=%d, independent 8x 32->256 fp32, oracle/deepsee_oracle.py "
+                      "(PyTorch-CPU restatement pinned to the reference), %.1f s per iteration" % (len(times), bs, dt)}
 
 
 def spawn_ranks(n):
@@ -155,6 +187,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="independent_8x_256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-bs", type=int, default=1,
+                    help="batch of the CPU baseline (8 = the benchmark's own batch: >= 64 GB of host RAM, minutes of CPU time)")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=3)
     ap.add_argument("--no-f32-run", action="store_true", help="skip the extra v_mfma_f32-only measurement")
     ap.add_argument("--batch-per-gpu", type=int, default=0)
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel from Python instead of replaying hipGraphs")
@@ -242,6 +277,7 @@ def main():
     fused_is_r3 = "spade_fused_fwd" in kernels
     fused = kernels.pop("spade_fused_fwd", None) or kernels.pop("spade_modulate_fused", None)
     norm_fwd = {k: kernels.pop(k) for k in list(kernels) if k.startswith("norm_forward@")}
+    conv_fwd = {k: kernels.pop(k) for k in list(kernels) if k.startswith("conv_forward@")}
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     kd = kernels[dom]
     tf = kd["tflop"] / (kd["ms"] / 1e3)
@@ -293,7 +329,9 @@ def main():
                       "MFMA products)",
             "f32": "fp32 (v_mfma_f32_32x32x2_f32)"}[kind]
         traffic, traffic_src = pmc_traffic(dom)
-        roof = {"bound": "mfma" if f_mfma >= f_hbm else "hbm", "kernel": dom,
+        # a kernel below half of BOTH rooflines is bound by neither: say so instead of picking the larger fraction
+        bound = "neither (issue/latency)" if max(f_mfma, f_hbm) < 0.5 else ("mfma" if f_mfma >= f_hbm else "hbm")
+        roof = {"bound": bound, "closer_to": "mfma" if f_mfma >= f_hbm else "hbm", "kernel": dom,
                 "achieved": tf if f_mfma >= f_hbm else gbps, "peak": peak if f_mfma >= f_hbm else HBM_PEAK_GBPS,
                 "unit": "TFLOP/s" if f_mfma >= f_hbm else "GB/s", "frac": max(f_mfma, f_hbm),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -341,7 +379,7 @@ def main():
         out["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # of 288 GB (kept V / M tensors included)
         out["host_enqueue_ms_per_step"] = host / args.steps * 1e3
         out["host_ms_per_step_incl_queue_backpressure"] = sum(host_steps) / args.steps * 1e3
-        out["hip_graphs"] = {"enabled": bool(tm.use_graphs), "captured": sorted("/".join(map(str, k)) for k in tm._graphs),
+        out["hip_graphs"] = {"enabled": bool(tm.use_graphs), "captured": sorted("/".join(map(str, k[:3])) for k in tm._graphs),
                              "extra_warmup_steps": extra_warmup,
                              "timed_half_steps_replayed": tm.graph_stats["replayed"] - replays_before, "timed_half_steps": 2 * args.steps,
                              "note": "G and D step replayed as hipGraphs (one per encoder-branch variant; first occurrence "
@@ -382,12 +420,27 @@ def main():
                 "algorithmic_gb_per_call": v["gb"] / v["launches"], "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": g / HBM_PEAK_GBPS,
                 "bytes_note": "SURVEY 8(d): 4 N R^2 (C [x, statistics pass] + C [x, apply pass] + C [out] + 128 [embedding]) + N R^2"}
+        if conv_fwd:
+            top = max(conv_fwd, key=lambda k: conv_fwd[k]["gb"] / conv_fwd[k]["launches"])
+            v = conv_fwd[top]
+            g, tfl = v["gb"] / (v["ms"] / 1e3), v["tflop"] / (v["ms"] / 1e3)
+            pk = kernel_peak("winograd_gemm_" + kind) if kind in ("f16x2", "bf16x3") else (
+                F16_MFMA_PEAK_TFLOPS if kind == "fp16" else FP32_MFMA_PEAK_TFLOPS)
+            out["roofline"]["conv_layer"] = {
+                "what": "one whole 3x3 convolution forward at the top resolution (input transform + Winograd-domain GEMM + "
+                        "output transform), " + top.split("@")[1],
+                "launches": v["launches"], "ms_per_call": v["ms"] / v["launches"],
+                "algorithmic_gb_per_call": v["gb"] / v["launches"], "hbm_achieved_gbps": g, "hbm_frac": g / HBM_PEAK_GBPS,
+                "winograd_tflop_per_call": v["tflop"] / v["launches"], "mfma_achieved_tflops_fp32_equiv": tfl,
+                "mfma_peak": pk, "mfma_frac": tfl / pk,
+                "bytes_note": "algorithmic bytes = x read + y written (4 N R^2 (Cin + Cout)); the Winograd formulation "
+                              "additionally writes and re-reads V and M (DESIGN 3)"}
         if f32_only:
             out["f32_mfma_only"] = f32_only
         if bf16x3:
             out["bf16x3_exact"] = bf16x3
         if world == 1 and not args.no_cpu_baseline and headline and not ops.HALF:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_bs, args.cpu_baseline_iters)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -117,24 +117,36 @@ class TrainerManager(BaseManager):
             self.d_losses, _ = self._d_step(data)
 
     # ---- hipGraph capture / replay
-    def _static_inputs(self, which, data):
-        """Copy the batch into buffers whose addresses the captured kernels know."""
-        st = self._static.setdefault(which, {})
+    @staticmethod
+    def _shape_signature(data):
+        """Shapes / dtypes of a batch: graphs, their static input buffers and the eager-first / capture-second counters are
+        keyed by it, so a batch of another shape (a loader without drop_last: the last partial batch of an epoch) gets its
+        own eager pass -- which sizes the workspaces for THAT shape outside any capture -- and its own graph, and never
+        replays kernels that baked in the addresses or sizes of another shape."""
+        sig = []
+        for k in sorted(data):
+            v = data[k]
+            if isinstance(v, torch.Tensor):
+                sig.append((k, tuple(v.shape), str(v.dtype)))
+            elif isinstance(v, ops.Labels):
+                sig.append((k, tuple(v.t.shape), "labels%d" % v.nc))
+        return tuple(sig)
+
+    def _static_inputs(self, skey, data):
+        """Copy the batch into buffers whose addresses the captured kernels know (one set per step and batch shape)."""
+        st = self._static.setdefault(skey, {})
         out = {}
         for k, v in data.items():
             if isinstance(v, torch.Tensor):
                 v = v.cuda(non_blocking=True) if not v.is_cuda else v
-                if k not in st or st[k].shape != v.shape or st[k].dtype != v.dtype:
-                    if k in st:     # a new shape invalidates every captured graph of this step
-                        self._graphs = {g: r for g, r in self._graphs.items() if g[0] != which}
-                        self._seen = {g: c for g, c in self._seen.items() if g[0] != which}
+                if k not in st:
                     st[k] = torch.empty_like(v)
                 st[k].copy_(v)
                 if hasattr(v, "dsee_layout"):
                     st[k].dsee_layout = v.dsee_layout
                 out[k] = st[k]
             elif isinstance(v, ops.Labels):
-                if k not in st or st[k].t.shape != v.t.shape:
+                if k not in st:
                     st[k] = ops.Labels(torch.empty_like(v.t), v.nc)
                 st[k].t.copy_(v.t)
                 out[k] = st[k]
@@ -151,13 +163,14 @@ class TrainerManager(BaseManager):
         noise = model.noise
         if not hasattr(noise, "step"):            # (a replayed oracle tape: no graphs)
             return step_fn(data)
-        key = (which,) + tuple(model.encoder_branch(False, step=noise.step + 1))
+        sig = self._shape_signature(data)
+        key = (which,) + tuple(model.encoder_branch(False, step=noise.step + 1)) + (sig,)
         seen = self._seen.get(key, 0)
         self._seen[key] = seen + 1
         if seen == 0 or ops.PROFILE is not None:
             self.graph_stats["eager"] += 1
             return step_fn(data)                  # first occurrence: eager (sizes every workspace, sets kernel attributes)
-        sd = self._static_inputs(which, data)
+        sd = self._static_inputs((which, sig), data)
         optim.sync_lr()
         rec = self._graphs.get(key)
         if rec is None:
@@ -174,11 +187,14 @@ class TrainerManager(BaseManager):
                 losses, generated = step_fn(sd, pinned=pinned, opt_step=not multi)
             ops.begin_capture()                   # (pools created on the capture stream belong to the graph)
             noise.step, noise.offset = state      # the capture ran the Python side once; the replay below is the real step
+            # tensors the forward leaves in model.logs live in the shared graph pool as well: copied out after every replay
+            logged = {k: v for k, v in model.logs.items() if isinstance(v, torch.Tensor)} if which == "G" else {}
             rec = {"graph": g, "losses": losses, "generated": generated, "pinned": pinned,
                    "grads": [p.grad for p in optim.params], "full": model.last_encoded_style_is_full,
                    "noisy": model.last_encoded_style_is_noisy,
                    "out_losses": {k: torch.empty_like(v) for k, v in losses.items()},
-                   "out_generated": None if generated is None else torch.empty_like(generated)}
+                   "out_generated": None if generated is None else torch.empty_like(generated),
+                   "logs": logged, "out_logs": {k: torch.empty_like(v) for k, v in logged.items()}}
             self._graphs[key] = rec
             self.graph_stats["captured"] += 1
         else:
@@ -195,6 +211,11 @@ class TrainerManager(BaseManager):
             rec["out_losses"][k].copy_(v)
         if rec["generated"] is not None:
             rec["out_generated"].copy_(rec["generated"])
+        for k, v in rec["logs"].items():
+            rec["out_logs"][k].copy_(v)
+            if hasattr(v, "dsee_layout"):
+                rec["out_logs"][k].dsee_layout = v.dsee_layout
+            model.logs[k] = rec["out_logs"][k]
         return rec["out_losses"], rec["out_generated"]
 
     def get_latest_losses(self):

@@ -122,12 +122,27 @@ class DeviceNoise:
         _REGISTERED_EPOCH = self.epoch
         L.lib().dsee_rng_set_epoch(ctypes.c_void_p(self.epoch.data_ptr()))
 
+    def ensure_registered(self):
+        """Re-register this object's epoch if another DeviceNoise (a second model in the process) registered its own since:
+        called by every consumer of a Philox stream drawn here (ops.PhiloxNormal.bind), forward and backward."""
+        if _REGISTERED_EPOCH is not self.epoch:
+            self._register()
+
     def begin_step(self):
         """Start of a training forward: stream offsets restart at 0 and the device epoch advances."""
         self.step += 1
         self.offset = 0
         self.epoch.add_(EPOCH_STRIDE)
         self._register()
+
+    def state_dict(self):
+        """What a resumed run needs to CONTINUE the branch-coin and noise sequences instead of repeating them from the start
+        of training (saved next to the checkpoints, SRModel.save)."""
+        return {"step": int(self.step), "epoch": int(self.epoch.item())}
+
+    def load_state_dict(self, state):
+        self.step = int(state["step"])
+        self.epoch.fill_(int(state["epoch"]))
 
     def coin(self, tag, step=None):
         import random as _r
@@ -148,7 +163,7 @@ class DeviceNoise:
         for s in shape_nhwc:
             n *= s
         assert n % 4 == 0
-        t = ops.PhiloxNormal(shape_nhwc, self.seed, self.offset)
+        t = ops.PhiloxNormal(shape_nhwc, self.seed, self.offset, self)
         self.offset += n // 4
         return t
 

@@ -148,11 +148,25 @@ class PhiloxNormal:
     """A N(0,1) tensor that is never materialised: the Philox stream (seed, offset) of dsee_rng_fill, regenerated in
     registers by the consumers (UpNoise forward and the noise-weight gradient)."""
 
-    def __init__(self, shape, seed, offset):
+    def __init__(self, shape, seed, offset, source=None):
         self.shape, self.seed, self.offset = tuple(shape), int(seed), int(offset)
+        self.source = source     # the DeviceNoise whose device-side epoch offsets this stream
+
+    def bind(self):
+        """Make the library read THIS stream's epoch (one device int64 per DeviceNoise, i.e. per model): with two models
+        in a process, a backward pass that regenerates a forward's draws must not pick up the other model's epoch."""
+        if self.source is not None:
+            self.source.ensure_registered()
 
     def materialize(self):
+        self.bind()
         return rng_fill(self.shape, self.seed, self.offset, True)
+
+
+def _bind_rng(*streams):
+    for e in streams:
+        if isinstance(e, PhiloxNormal):
+            e.bind()
 
 
 def rng_fill(shape, seed, offset, normal=True):
@@ -188,7 +202,7 @@ CONV_F16X2_MIN_FLOP = 1e9
 def tensor_amax(t, cache=None):
     """Device-side max |t| (2048-float slot).  `cache`: a dict shared by the consumers of the same tensors (the data and
     the weight gradient both read dy, the forward conv and the weight gradient both read x): one pass per tensor."""
-    if getattr(t, "dsee_amax", None) is not None:      # carried by its producer (spectral-norm group launch)
+    if carried_amax(t) is not None:      # carried by its producer (spectral-norm group launch)
         return t.dsee_amax
     key = (t.data_ptr(), t.numel(), t._version)
     if cache is not None and key in cache:
@@ -331,6 +345,23 @@ def amax_slot():
     return t
 
 
+def tag_amax(t, slot):
+    """Attach the operand bound `slot` (device max |t|, written by t's producer) to an ACTIVATION / GRADIENT tensor together
+    with the tensor version it was measured at.  Such a tensor may cross the autograd engine, which sums fan-in gradients
+    in place (InputBuffer add_): the sum keeps one addend's Python attributes but not its maximum.  The in-place add bumps
+    `_version`, so carried_amax() then ignores the stale bound."""
+    t.dsee_amax, t.dsee_amax_ver = slot, t._version
+    return slot
+
+
+def carried_amax(t):
+    """The operand bound attached to `t`, or None -- also None when `t` was modified in place after the bound was measured."""
+    a = getattr(t, "dsee_amax", None)
+    if a is not None and getattr(t, "dsee_amax_ver", t._version) != t._version:
+        return None
+    return a
+
+
 def begin_capture():
     """Called right before a hipGraph capture starts: the zero-fill of an operand-maximum pool must be part of the graph
     that uses its slots (a replay has to find them zeroed), so pools handed out earlier are dropped."""
@@ -387,7 +418,7 @@ FUSED_V_BOUND = 100.0       # |B^T d B| <= 100 max|d| for F(4x4,3x3): scale of a
 def _presplit_ok(xc, t, t_g, r_s, k_s=0, keep=False):
     """dsee_gemm_f16x2_pre takes 256 x 256 tiles only; below 512 of them the 128 x 128 kernel fills the chip better.
     `keep`: the weight gradient will read the same V2 (dsee_gemm_f16x2_tn_qpre: 160 or a multiple of 128 columns)."""
-    return (PRESPLIT_A and getattr(xc, "dsee_amax", None) is not None and t_g % 256 == 0 and r_s % 256 == 0
+    return (PRESPLIT_A and carried_amax(xc) is not None and t_g % 256 == 0 and r_s % 256 == 0
             and (36 * t // 256) * (r_s // 256) >= 512 and (not keep or k_s == 160 or k_s % 128 == 0))
 
 
@@ -462,8 +493,8 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     nb = _wino_chunk(n, h, wd, max(r_s, k_s))
     for n0 in range(0, n, nb):
         xc = x if nb == n else x[n0:n0 + nb]
-        if nb != n and getattr(x, "dsee_amax", None) is not None:
-            xc.dsee_amax = x.dsee_amax          # (the maximum of the whole batch bounds every chunk)
+        if nb != n and carried_amax(x) is not None:
+            tag_amax(xc, x.dsee_amax)           # (the maximum of the whole batch bounds every chunk)
         m, ms = _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, False, split, keep if nb == n else None, ua)
         nz = (None, 0, 0) if noise is None else (noise[0], noise[1].seed, noise[1].offset + n0 * h * wd * r_s // 4)
         rz = ((None, 0, 0) if res_noise is None else
@@ -529,7 +560,7 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
     elif v is None or (need and v[1] is None):
         v = (new(36, t, cin_s), amax_slot() if need else None)
         L.call("wino43_input", xc, v[0], nb, h, wd, cin_s, v[1])
-    ga = getattr(gc, "dsee_amax", None)
+    ga = carried_amax(gc)
     if dm is None and pre_dm and ga is not None and v is not None and len(v) == 3:
         # dY's maximum is known (its producer wrote it): A dY A^T leaves the transform pre-split, for the weight gradient's
         # P operand and the adjoint data-gradient GEMM's A operand alike
@@ -590,7 +621,7 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
             L.call("gemm_bf16x3_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0)
     dx = new(nb, h, wd, r_s)
     if mask is None and dvs is None and PRESPLIT_DM:
-        dx.dsee_amax = amax_slot()     # (dx is the gradient w.r.t. a norm's output: bound of that norm's gamma/beta gradient)
+        tag_amax(dx, amax_slot())      # (dx is the gradient w.r.t. a norm's output: bound of that norm's gamma/beta gradient)
         L.call("wino43_input_adjoint_amax", dv, dx, nb, h, wd, r_s, dx.dsee_amax)
     else:
         L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s, dvs)
@@ -643,6 +674,7 @@ class Conv2d(torch.autograd.Function):
                 res_noise_eps=None, res_sink=None, exact=False, stats=False):
         """`exact`: keep a direct convolution on the fp32 MFMA (no operand-maximum passes over its activations)."""
         ctx.exact = bool(exact)
+        _bind_rng(noise_eps, res_noise_eps)
         co, ci, kh, kw = w.shape
         n, hi, wi, cin_s = x.shape
         assert cin_s == L.pad4(ci), (cin_s, ci)
@@ -663,9 +695,13 @@ class Conv2d(torch.autograd.Function):
             # the fp32 V of x is the weight gradient's Q operand: keep it instead of transforming x again (2.25x the
             # bytes of x; KEEP_V = False trades the memory back for one more transform pass)
             keep = [] if (KEEP_V and ctx.needs_input_grad[1] and _wgrad_mode(cin_s, cout_s) == 2) else None
-            out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act, keep=keep,
-                             noise=None if noise_w is None else (noise_w, noise_eps),
-                             res_noise=None if res_noise_w is None else (res_noise_w, res_noise_eps), stats=stats)
+            # bench.py: the whole layer (input transform + GEMMs + output transform) on its algorithmic bytes (x in, y out)
+            # and its Winograd-domain FLOPs (2.25 multiplies per output and channel pair instead of 9)
+            with _timed("conv_forward@%dx%d %d->%d" % (hi, wi, cin_s, cout_s), 2.0 * 36 * (n * hi * wi // 16) * cin_s * cout_s,
+                        4.0 * n * hi * wi * (cin_s + cout_s)):
+                out = _wino_conv(x, w, n, hi, wi, cin_s, cout_s, False, pad_vec(bias, cout_s), res, act, keep=keep,
+                                 noise=None if noise_w is None else (noise_w, noise_eps),
+                                 res_noise=None if res_noise_w is None else (res_noise_w, res_noise_eps), stats=stats)
             vkeep = keep[0] if keep else None
         else:
             ctx.amax_cache = {}   # max |x| found here is reused by the weight gradient
@@ -685,13 +721,14 @@ class Conv2d(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, out, vk, vk_amax = ctx.saved_tensors
         w.dsee_amax, w.dsee_u = ctx.w_amax, ctx.w_u
+        _bind_rng(ctx.noise, ctx.res_noise)
         vkeep = ((vk, vk_amax, True) if ctx.v_pre else (vk, vk_amax)) if vk is not None else None
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
         if ctx.act != L.ACT_NONE and ctx.wino and PRESPLIT_DM:
             g = torch.empty_like(dy)
-            g.dsee_amax = amax_slot()     # (the A dY A^T transform below is written pre-split with this bound)
+            tag_amax(g, amax_slot())      # (the A dY A^T transform below is written pre-split with this bound)
             L.call("act_bwd_amax", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE, g.dsee_amax)
         elif ctx.act != L.ACT_NONE:
             g = torch.empty_like(dy)
@@ -1038,6 +1075,7 @@ class UpNoise(torch.autograd.Function):
         n, h0, w0, c = x.shape
         y = new(n, h0 << ups, w0 << ups, c)
         ctx.philox = eps if isinstance(eps, PhiloxNormal) else None
+        _bind_rng(eps)
         if ctx.philox is not None:
             assert eps.shape == tuple(y.shape)
             if stats and PRODUCER_STATS and _stats_rows_ok(c):
@@ -1060,13 +1098,14 @@ class UpNoise(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (eps,) = ctx.saved_tensors
+        _bind_rng(ctx.philox)
         dy = dy.contiguous()
         n, h, w, c = dy.shape
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ctx.ups:
                 dx = new(*ctx.xshape)
-                dx.dsee_amax = amax_slot()     # (dx is the output gradient of the previous block's conv_1)
+                tag_amax(dx, amax_slot())      # (dx is the output gradient of the previous block's conv_1)
                 L.call("sumpool_amax", dy, dx, n, h, w, c, ctx.ups, dx.dsee_amax)
             else:
                 dx = dy
@@ -1320,7 +1359,7 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     sums = new(4, c)
     dgb = dm = None
     t = n * (h // 4) * (w // 4)
-    dha = getattr(dh, "dsee_amax", None)
+    dha = carried_amax(dh)
     if as_dm and PRESPLIT_DM and PRESPLIT_GB and xhat_amax is not None and dha is not None and t % 256 == 0 and not HALF:
         # max |dh| (written by the kernel that produced dh) x max(1, max |xhat|) (written by the forward pass) bounds both halves
         # (g * xhat | g) of the gradient: dM leaves the reduce pass pre-split, for the table / embedding weight gradient's P
@@ -1349,7 +1388,7 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     da = amax_slot()             # max |dx|: dx is the output gradient of the convolution in front of this norm
     L.call("modulate_bwd_apply_amax", dh.contiguous(), out, x, scale, mean, invstd, sums, add, dx, n, h * w, c, 1.0 / count,
            LRELU_SLOPE, da)      # dx += add: the gradient of the other consumer of x (the resblock shortcut)
-    dx.dsee_amax = da
+    tag_amax(dx, da)
     return dx, dgb, sums[2:4], dm
 
 
@@ -1495,7 +1534,7 @@ class SeanNormTable(torch.autograd.Function):
                 L.call("spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
                        scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE,
                        hm, xm)
-                out.dsee_amax = hm
+                tag_amax(out, hm)
                 ctx.xhat_amax = xm
             keep = None
             if KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:

@@ -88,8 +88,26 @@ class FlatAdam:
         self._held = None
 
     def zero_grad(self, set_to_none=True):
+        """set_to_none=True (default, torch's default): every .grad becomes None and the next backward pass simply keeps the
+        tensors it produces.  set_to_none=False (torch's other mode): existing .grad tensors are zero-filled in place and
+        kept -- autograd then accumulates into them (one add kernel per parameter) and, as in torch, Adam treats every such
+        tensor as "has a gradient"."""
         for p in self.params:
-            p.grad = None
+            if set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad.detach_()
+                p.grad.zero_()
+
+    def grad_view(self, name):
+        """The gradient of parameter `name` as step() consumed it: a view of the flat gradient buffer -- after the step of a
+        data-parallel run the SUM over the ranks (the Adam kernel applies 1/world and the value clip on the fly; neither is
+        written back).  `p.grad` itself is NOT this view: it stays the local tensor the backward pass produced (un-reduced,
+        un-clipped; the reference's clip_grad_value_ rewrites p.grad in place, trainer_manager.py:39-40), so code that
+        inspects gradients after a step should read them here."""
+        i = self.names.index(name)
+        o, p = self.offsets[i], self.params[i]
+        return self.grad[o:o + p.numel()].view(p.shape)
 
     def staging(self):
         """A pinned staging tensor for step(pinned=...) (hipGraph capture: allocate BEFORE the capture starts)."""
@@ -129,7 +147,7 @@ class FlatAdam:
             self._lr_sent = lrs
 
     def step(self, clip=-1.0, pinned=None):
-        """`pinned`: a pinned int32 staging tensor owned by the caller -- required while a hipGraph is being captured (the
+        """`pinned`: a pinned int64 staging tensor (FlatAdam.staging()) owned by the caller -- required while a hipGraph is being captured (the
         captured host-to-device copy reads it on every replay, so it must hold this step's `touched` flags for good)."""
         hook = self.reduce_hook
         multi = hook is not None and hook.active

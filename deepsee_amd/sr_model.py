@@ -205,6 +205,13 @@ class SRModel(nn.Module):
                 tmp = "%s.tmp.%d" % (path, os.getpid())
                 torch.save({"model": OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())}, tmp)
                 os.replace(tmp, path)
+        if hasattr(self.noise, "state_dict"):
+            # not part of the reference's layout (its noise is torch's global generator, never saved): the position of the
+            # Philox / branch-coin sequences, so that --continue_train continues them instead of replaying them from step 0
+            path = self._ckpt("noise_state", epoch)
+            tmp = "%s.tmp.%d" % (path, os.getpid())
+            torch.save(self.noise.state_dict(), tmp)
+            os.replace(tmp, path)
 
     def load_weights(self):
         opt = self.opt
@@ -213,6 +220,9 @@ class SRModel(nn.Module):
                 continue
             ck = torch.load(self._ckpt(label, opt.which_epoch), map_location="cpu")
             self.load_net_state(net, ck["model"] if "model" in ck else ck)
+        path = self._ckpt("noise_state", opt.which_epoch)
+        if opt.isTrain and os.path.exists(path) and hasattr(self.noise, "load_state_dict"):
+            self.noise.load_state_dict(torch.load(path, map_location="cpu"))
 
     @staticmethod
     def load_net_state(net, state):

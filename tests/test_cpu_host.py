@@ -560,3 +560,49 @@ def test_presplit_path_selection_rules():
     # the channel sums that ride in the A dY A^T pass / the statistics rows of a producer need 256 % (C/4) == 0
     assert ops._dout_sums_ok(8, 8, 512, 2) and not ops._dout_sums_ok(8, 4, 512, 2) and not ops._dout_sums_ok(8, 8, 512, 1)
     assert ops._stats_rows_ok(512) and ops._stats_rows_ok(64) and not ops._stats_rows_ok(96 * 4 + 4)
+
+
+def test_carried_operand_bound_is_dropped_after_an_in_place_update():
+    """a gradient tensor carries max |g| (written by its producer) to the kernel that pre-splits A g A^T with it.
+    The autograd engine sums fan-in gradients IN PLACE into one addend: the sum keeps that addend's Python attributes but may
+    be up to 2x larger.  The bound is stored with the tensor version it was measured at and ignored once the version moved."""
+    import torch
+    from deepsee_amd import ops
+    g = torch.ones(4)
+    slot = torch.zeros(2048)
+    ops.tag_amax(g, slot)
+    assert ops.carried_amax(g) is slot
+    assert ops.carried_amax(g.contiguous()) is slot          # (the same object)
+    g.add_(torch.ones(4))                                    # what InputBuffer::add does to the first gradient
+    assert ops.carried_amax(g) is None
+    assert not ops._presplit_ok(g, 32768, 32768, 512)
+    w = torch.ones(4)
+    w.dsee_amax = slot                                       # weights: tagged without a version, always trusted
+    assert ops.carried_amax(w) is slot
+    # a fan-in in a real graph: y = f(x) + h(x) where both branches return tagged gradients
+    class Tagged(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+        @staticmethod
+        def backward(ctx, dy):
+            dx = dy * 2
+            ops.tag_amax(dx, slot)
+            return dx
+    seen = []
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+        @staticmethod
+        def backward(ctx, dy):
+            seen.append(ops.carried_amax(dy))
+            return dy
+    x = torch.ones(4, requires_grad=True)
+    p = Probe.apply(x)
+    (Tagged.apply(p) + Tagged.apply(p)).sum().backward()
+    assert seen == [None]                                    # the engine's sum of two tagged gradients carries no bound
+    seen.clear()
+    x = torch.ones(4, requires_grad=True)
+    Tagged.apply(Probe.apply(x)).sum().backward()
+    assert seen == [slot] or seen[0] is slot                 # single consumer: the bound arrives

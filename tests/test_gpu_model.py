@@ -97,6 +97,13 @@ def run_case(over, seed, iters=1, sync_before_d=True):
     return orc, tm, out
 
 
+# Model-level gradients under the REAL losses (hinge / L1 terms: sign-function gradients; ReLU / LeakyReLU kinks): ~3x the
+# worst values observed over all cases on the MI355X (median 2.6e-3, max 8.0e-3: profiles/r03_gpu_tests.log) -- loose enough for the
+# kink-flip floor described in DESIGN 4, tight enough to catch a 3x regression.  The kink-free 1e-3 claim is carried by
+# test_full_size_smooth_loss_backward and the benchmark-shape layer tests.
+GRAD_MEDIAN_BOUND, GRAD_MAX_BOUND = 6e-3, 2.5e-2
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_train_step_matches_oracle(name):
     """Full G+D step with the real losses.  Forward quantities are tight.  Gradients of the REAL loss are only
@@ -119,7 +126,7 @@ def test_train_step_matches_oracle(name):
     gmax = max(float(v.norm()) for v in r["ggrads"].values())
     errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
                   for k, v in r["ggrads"].items())
-    assert errs[len(errs) // 2] < 2e-2 and errs[-1] < 1e-1, (errs[len(errs) // 2], errs[-1])
+    assert errs[len(errs) // 2] < GRAD_MEDIAN_BOUND and errs[-1] < GRAD_MAX_BOUND, (errs[len(errs) // 2], errs[-1])
     # the D step started from the oracle's post-G-step state on both sides: losses and gradients are tight
     for k, v in r["dl"].items():
         assert abs(r["hdl"][k] - v) <= 1e-4 * abs(v), (k, r["hdl"][k], v)
@@ -166,7 +173,7 @@ def test_full_size_step_matches_oracle():
     gmax = max(float(v.norm()) for v in r["ggrads"].values())
     errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
                   for k, v in r["ggrads"].items())
-    assert errs[len(errs) // 2] < 2e-2 and errs[-1] < 1e-1, (errs[len(errs) // 2], errs[-1])
+    assert errs[len(errs) // 2] < GRAD_MEDIAN_BOUND and errs[-1] < GRAD_MAX_BOUND, (errs[len(errs) // 2], errs[-1])
     for k, v in r["dl"].items():
         assert abs(r["hdl"][k] - v) <= 2e-3 * abs(v), (k, r["hdl"][k], v)
     print("full size: |fake - oracle| / |oracle| = %.2e, G-grad rel err median %.2e max %.2e, losses %s"
@@ -198,7 +205,7 @@ def test_benchmark_config_step_matches_oracle():
     gmax = max(float(v.norm()) for v in r["ggrads"].values())
     errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
                   for k, v in r["ggrads"].items())
-    assert errs[len(errs) // 2] < 2e-2 and errs[-1] < 1e-1, (errs[len(errs) // 2], errs[-1])
+    assert errs[len(errs) // 2] < GRAD_MEDIAN_BOUND and errs[-1] < GRAD_MAX_BOUND, (errs[len(errs) // 2], errs[-1])
     print("configs[1] at bs = %d (host RAM %.0f GB): |fake - oracle| / |oracle| = %.2e, G-grad rel err median %.2e max %.2e, "
           "losses %s" % (bs, ram_gb, dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
 
@@ -775,3 +782,55 @@ def test_training_loop_with_device_loader_and_metrics(tmp_path):
     assert all(math.isfinite(v) for d in la for v in d.values())
     assert (tmp_path / "loop" / "latest_net_SR.pth").exists()
     assert abs(tm.optimizer_G.param_groups[0]["lr"] - tm.opt.lr / 2 * 1.0) < 1e-12      # epoch 1 <= niter: no decay yet
+
+
+def test_vgg_weights_option_loads_torchvision_state_dict(tmp_path):
+    """opt.vgg_weights end to end (architecture.py:154: the reference downloads torchvision's vgg19): a state dict with
+    torchvision's key names -- ALL of vgg19(): 'features.N.*' for the 16 convolutions incl. the three behind the last
+    tap, and the classifier -- saved with torch.save and named by the option.  The model must load the 13 tap
+    convolutions, ignore the rest, stop warning about random features, and its five taps must equal the oracle's VGG on
+    the same weights."""
+    import warnings
+    from deepsee_amd import ops
+    from deepsee_amd.sr_model import SRModel
+    from deepsee_amd.options import make_opt
+    g = torch.Generator().manual_seed(5)
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+    state, cin, idx = {}, 3, 0
+    for v in cfg:
+        if v == "M":
+            idx += 1
+            continue
+        state["features.%d.weight" % idx] = torch.randn(v, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        state["features.%d.bias" % idx] = torch.randn(v, generator=g) * 0.05
+        cin, idx = v, idx + 2
+    for i, (o, k) in zip((0, 3, 6), ((64, 128), (64, 64), (10, 64))):   # (classifier keys, shapes irrelevant: ignored)
+        state["classifier.%d.weight" % i] = torch.randn(o, k, generator=g)
+        state["classifier.%d.bias" % i] = torch.randn(o, generator=g)
+    path = str(tmp_path / "vgg19-torchvision-keys.pth")
+    torch.save(state, path)
+    over = dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)     # the "no pretrained VGG19 weights" notice must NOT fire
+        m = SRModel(make_opt(vgg_weights=path, **over))
+    assert m.vgg_pretrained
+    own = m.vgg.state_dict()
+    assert len(own) == 26 and all(k in state for k in own)
+    for k, v in own.items():
+        assert torch.equal(v.detach().cpu().reshape(state[k].shape), state[k]), k
+    # a state dict that lacks a tap convolution is refused
+    broken = {k: v for k, v in state.items() if not k.startswith("features.28.")}
+    with pytest.raises(RuntimeError):
+        m.load_vgg_state(broken)
+    # the state dict of vgg19().features alone ('N.weight') is accepted as well
+    m.load_vgg_state({k[len("features."):]: v for k, v in state.items() if k.startswith("features.")})
+    # taps vs the oracle on the same weights
+    oopt = O.make_opt(**over)
+    states = O.recipe_state(oopt, gain=1.0)
+    states["VGG"] = {k: state[k].clone() for k in O.vgg_spec()}
+    orc = O.Oracle(oopt, states, O.RecordingCtl())
+    x = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    want = orc.vgg_features(x)
+    got = m.vgg(ops.to_nhwc(x.cuda()))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert rel(ops.to_nchw(a, b.shape[1]).cpu(), b) < 1e-5, i
