@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--arith", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
                     help="how the fp32 Winograd-domain GEMMs run on the matrix cores: two-term fp16 split (default), exact "
                          "3-term bf16 split, or v_mfma_f32")
+    ap.add_argument("--plan", nargs="*", default=[], metavar="FIELD=VALUE",
+                    help="KernelPlan fields of the model (deepsee_amd/plan.py), e.g. --plan fused_norm=False (A/B runs)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -212,11 +214,13 @@ def main():
     if world != args.gpus:   # never report a number for a world size other than the one asked for
         raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local)
-    ops.GEMM_SPLIT, ops.GEMM_F16X2 = args.arith != "f32", args.arith == "f16x2"
     preset, n_default, ref = CONFIGS[args.config]
     n = args.batch_per_gpu or n_default
     headline = args.config == "independent_8x_256"
-    opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype, hip_graphs=not args.no_graphs)
+    # the kernel-path choices of this run are the MODEL's plan (deepsee_amd/plan.py), not module state
+    opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype, hip_graphs=not args.no_graphs,
+                   kernel_plan=dict(dict(gemm_split=args.arith != "f32", gemm_f16x2=args.arith == "f16x2"),
+                                    **{kv.split("=")[0]: eval(kv.split("=", 1)[1]) for kv in args.plan}))
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)   # (the no-pretrained-VGG notice: synthetic benchmark)
@@ -286,8 +290,12 @@ def main():
     f_mfma, f_hbm = tf / peak, gbps / HBM_PEAK_GBPS
     mfma_ms = sum(k["ms"] for k in kernels.values())
 
-    def short_run(note):
-        tm.use_graphs = False     # (the graphs were captured with the default arithmetic)
+    base_plan = tm.sr_model.plan
+
+    def short_run(note, **plan):
+        """3 steps of the same model under a plan of its own (eager: the graphs were captured under the base plan)."""
+        tm.use_graphs = False
+        tm.sr_model.plan = base_plan.replace(**plan)
         step()
         fence()
         t1 = time.perf_counter()
@@ -298,21 +306,20 @@ def main():
         return {"value": n / dt, "unit": "img/s", "ms_per_step": dt * 1e3, "steps": 3, "note": note}
 
     f32_only = bf16x3 = None
-    if world == 1 and ops.GEMM_SPLIT and not args.no_f32_run and headline and not ops.HALF:
-        ops.GEMM_SPLIT = False
-        f32_only = short_run("same step, Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 instead of split operands")
-        ops.GEMM_SPLIT = True
-        if ops.GEMM_F16X2:
-            ops.GEMM_F16X2 = False
+    if world == 1 and base_plan.gemm_split and not args.no_f32_run and headline and not base_plan.half:
+        f32_only = short_run("same step, Winograd-domain GEMMs on v_mfma_f32_32x32x2_f32 instead of split operands",
+                             gemm_split=False)
+        if base_plan.gemm_f16x2:
             bf16x3 = short_run("same step, every split GEMM on the EXACT 3-term bf16 split (6 MFMA products per fp32 "
-                               "multiply-add; the SPADE/SEAN forward then takes the round-2 GEMM + output-transform path)")
-            ops.GEMM_F16X2 = True
+                               "multiply-add; the SPADE/SEAN forward then takes the round-2 GEMM + output-transform path)",
+                               gemm_f16x2=False)
+        tm.sr_model.plan = base_plan
         tm.use_graphs = not args.no_graphs
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        kind = "f16x2" if (ops.GEMM_SPLIT and ops.GEMM_F16X2) else ("bf16x3" if ops.GEMM_SPLIT else "f32")
-        if ops.HALF:
+        kind = "f16x2" if (base_plan.gemm_split and base_plan.gemm_f16x2) else ("bf16x3" if base_plan.gemm_split else "f32")
+        if base_plan.half:
             kind = "fp16"
         arithmetic = {
             "fp16": "half-precision compute mode (BASELINE configs[2]'s 16-bit arithmetic): Winograd-domain GEMMs with operands "
@@ -439,7 +446,7 @@ def main():
             out["f32_mfma_only"] = f32_only
         if bf16x3:
             out["bf16x3_exact"] = bf16x3
-        if world == 1 and not args.no_cpu_baseline and headline and not ops.HALF:
+        if world == 1 and not args.no_cpu_baseline and headline and not base_plan.half:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_bs, args.cpu_baseline_iters)
         print(json.dumps(out))
     if world > 1:

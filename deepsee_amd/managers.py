@@ -164,7 +164,8 @@ class TrainerManager(BaseManager):
         if not hasattr(noise, "step"):            # (a replayed oracle tape: no graphs)
             return step_fn(data)
         sig = self._shape_signature(data)
-        key = (which,) + tuple(model.encoder_branch(False, step=noise.step + 1)) + (sig,)
+        # (the plan is part of the key: a graph replays the kernels chosen under the plan it was captured with)
+        key = (which,) + tuple(model.encoder_branch(False, step=noise.step + 1)) + (sig, model.plan)
         seen = self._seen.get(key, 0)
         self._seen[key] = seen + 1
         if seen == 0 or ops.PROFILE is not None:

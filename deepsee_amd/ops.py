@@ -11,6 +11,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
+from .plan import KernelPlan, DEFAULT_PLAN, current as P   # P(): the active KernelPlan of this thread (deepsee_amd/plan.py)
 
 LRELU_SLOPE = 0.2
 BN_EPS = 1e-5
@@ -73,6 +74,16 @@ def scratch(nbytes, tag="ws"):
 
 def new(*shape):
     return torch.empty(*shape, dtype=torch.float32, device="cuda")
+
+
+def _under_plan(backward):
+    """Run an autograd node's backward under the KernelPlan its forward recorded (ctx.plan): the engine calls it on its own
+    thread, possibly while another model with another plan is mid-forward on the caller's."""
+    def wrapped(ctx, *grads):
+        with ctx.plan.active():
+            return backward(ctx, *grads)
+    wrapped.__doc__ = backward.__doc__
+    return wrapped
 
 
 def pad_vec(v, n):
@@ -193,12 +204,6 @@ def _pack_dgrad(w, cout_s, korder):
     return wp
 
 
-# Direct (non-Winograd) convolutions with >= CONV_F16X2_MIN_FLOP (1 GFLOP) of work run their MFMAs on fp16x2-split operands (the
-# split happens inside the kernel; two small max|.| passes over the input and the packed weights provide the scales).
-# Below the threshold the two extra launches cost more than the shorter MFMA chain saves.  0 disables.
-CONV_F16X2_MIN_FLOP = 1e9
-
-
 def tensor_amax(t, cache=None):
     """Device-side max |t| (2048-float slot).  `cache`: a dict shared by the consumers of the same tensors (the data and
     the weight gradient both read dy, the forward conv and the weight gradient both read x): one pass per tensor."""
@@ -216,7 +221,7 @@ def tensor_amax(t, cache=None):
 
 def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0, amax_cache=None, exact=False):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
-    if not exact and GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and _flops(geom) >= CONV_F16X2_MIN_FLOP:
+    if not exact and P().gemm_split and P().gemm_f16x2 and P().conv_f16x2_min_flop > 0 and _flops(geom) >= P().conv_f16x2_min_flop:
         ax, aw = tensor_amax(x, amax_cache), tensor_amax(wp)
         with _timed(_variant(geom).replace("halo", "igemm") + "_f16x2", _flops(geom)):   # (the halo kernel is fp32-only)
             L.call("conv2d_fwd_f16x2", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw)
@@ -231,7 +236,7 @@ def wgrad_raw(x, dout, geom, cout, cin, kh, kw, cin_first=0, amax_cache=None, ex
     ws = scratch(nbytes, "wgrad")
     dw = new(cout, cin, kh, kw)
     flops = _flops(geom) * ((cin + 31) // 32 * 32 if geom.korder else geom.Cin) / geom.Cin
-    if not exact and GEMM_SPLIT and GEMM_F16X2 and CONV_F16X2_MIN_FLOP > 0 and flops >= CONV_F16X2_MIN_FLOP:
+    if not exact and P().gemm_split and P().gemm_f16x2 and P().conv_f16x2_min_flop > 0 and flops >= P().conv_f16x2_min_flop:
         ax, ad = tensor_amax(x, amax_cache), tensor_amax(dout, amax_cache)
         with _timed("conv_wgrad_128x128_f16x2(+slab reduce)", flops):
             L.call("conv2d_wgrad_f16x2", C.byref(geom), x, dout, ws, C.c_size_t(nbytes), dw, cout, cin_first, cin, ax, ad)
@@ -252,19 +257,6 @@ def channel_dot(a, b, c):
 
 
 # ---- Winograd F(4x4,3x3) for the wide 3x3 / stride-1 layers (4x fewer fp32 MACs than the direct form)
-WINOGRAD = True
-WINOGRAD_WGRAD = True
-WINOGRAD_MOD = True
-# The switches below select between kernel paths that compute the same function.  They are module attributes (no
-# environment variables); the non-default side of each is exercised by tests/test_gpu_model.py::test_kernel_path_switches.
-# fp32 GEMMs of the Winograd domain on the 16-bit matrix cores via operand splitting (gemm_bf16x3.hip); False keeps them
-# on v_mfma_f32_32x32x2_f32 (bench.py's f32_mfma_exact comparison run)
-GEMM_SPLIT = True
-# A operand of the forward / data-gradient GEMMs kept in fp32 in HBM (4 instead of 6 bytes per element written by the
-# input transform and read by the GEMM) and split inside the GEMM kernel; False uses pre-split bf16x3 A operands
-GEMM_AF32 = True
-# keep the forward's fp32 V for the weight gradient (False: transform x again in the backward pass)
-KEEP_V = True
 
 
 def _wino_chunk(n, h, w, cmax, per_image=False):
@@ -274,7 +266,7 @@ def _wino_chunk(n, h, w, cmax, per_image=False):
     if h % 4 or w % 4:
         return None
     tpi = (h // 4) * (w // 4)
-    wide = GEMM_SPLIT and cmax % 32 == 0
+    wide = P().gemm_split and cmax % 32 == 0
     for nb in range(n, 0, -1):
         fits = 36 * nb * tpi * cmax * 6 < (1 << 34) if wide else 36 * nb * tpi * cmax * 4 < 0xF0000000
         if n % nb == 0 and fits and ((tpi if per_image else nb * tpi) % 128 == 0):
@@ -284,43 +276,28 @@ def _wino_chunk(n, h, w, cmax, per_image=False):
 
 def _wino_mod_chunk(n, h, w, c, rows, per_image):
     """Images per pass of the Winograd gamma/beta GEMM (None: use the direct kernel)."""
-    if not (WINOGRAD and WINOGRAD_MOD and c % 64 == 0 and rows == 2 * c and rows % 128 == 0):
+    if not (P().winograd and P().winograd_mod and c % 64 == 0 and rows == 2 * c and rows % 128 == 0):
         return None
     return _wino_chunk(n, h, w, rows, per_image)
 
 
 def _wino_ok(n, h, w, cin_s, cout_s, k, stride, pad, ups):
-    return (WINOGRAD and k == 3 and stride == 1 and pad == 1 and ups == 0 and cin_s % 32 == 0 and cout_s % 128 == 0
+    return (P().winograd and k == 3 and stride == 1 and pad == 1 and ups == 0 and cin_s % 32 == 0 and cout_s % 128 == 0
             and cin_s >= 128 and _wino_chunk(n, h, w, max(cin_s, cout_s)) is not None)
 
 
-# ... and with two-term fp16 splits (3 instead of 6 MFMA products per fp32 multiply-add, operands scaled by exact powers
-# of two; False keeps the 3-term bf16 form, bench.py's bf16x3_exact comparison run).  Needs the fp32-A kernels (the
-# operands are split in the GEMM).
-GEMM_F16X2 = True
-
-
 def _split_ok(k_s, r_s):
-    return GEMM_SPLIT and k_s % 32 == 0 and r_s % 128 == 0
-
-
-# Half-precision compute mode (BASELINE configs[2]'s 16-bit arithmetic; opt.precision = "fp16"): the Winograd-domain GEMMs
-# take operands scaled by powers of two and rounded to ONE fp16 term (one MFMA product, fp32 accumulate) and write their
-# products M / dV as scaled fp16; everything else -- activations, statistics, master weights, optimizer -- stays fp32.
-# fp16 and not bf16 because the F(4x4,3x3) transforms amplify operand rounding ~10x (per-layer error 2.6 % with bf16
-# operands, 0.33 % with scaled fp16; a direct bf16 convolution: 0.24 %).  Checked against the fp32 path (<= 3e-2 on
-# fake), not against the CPU reference.
-HALF = False
+    return P().gemm_split and k_s % 32 == 0 and r_s % 128 == 0
 
 
 def _split_kind(k_s, r_s):
     """0: fp32 GEMM operands; 1: bf16x3; 2: fp16x2 (fp32 A operand split inside the GEMM kernel); 3: one fp16 term."""
     if not _split_ok(k_s, r_s):
         return 0
-    af32 = GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF
-    if HALF and af32:
+    af32 = P().gemm_af32 and k_s * 4 * 256 < 0x7FFFFFFF
+    if P().half and af32:
         return 3
-    return 2 if (GEMM_F16X2 and af32) else 1
+    return 2 if (P().gemm_f16x2 and af32) else 1
 
 
 def _i16(n):
@@ -406,19 +383,13 @@ def _gemm_name(split):
     return {1: "winograd_gemm_bf16x3", 2: "winograd_gemm_f16x2", 3: "winograd_gemm_f16_1term"}[split]
 
 
-# A operand of a forward Winograd GEMM written pre-split by the input transform (False: fp32 V, split inside the GEMM)
-PRESPLIT_A = True
-# A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
-PRESPLIT_DM = True
-# ... and the gamma/beta gradient of a SPADE/SEAN norm as well (False: fp32 dM from the norm backward's reduce pass)
-PRESPLIT_GB = True
 FUSED_V_BOUND = 100.0       # |B^T d B| <= 100 max|d| for F(4x4,3x3): scale of a pre-split V from max |input|
 
 
 def _presplit_ok(xc, t, t_g, r_s, k_s=0, keep=False):
     """dsee_gemm_f16x2_pre takes 256 x 256 tiles only; below 512 of them the 128 x 128 kernel fills the chip better.
     `keep`: the weight gradient will read the same V2 (dsee_gemm_f16x2_tn_qpre: 160 or a multiple of 128 columns)."""
-    return (PRESPLIT_A and carried_amax(xc) is not None and t_g % 256 == 0 and r_s % 256 == 0
+    return (P().presplit_a and carried_amax(xc) is not None and t_g % 256 == 0 and r_s % 256 == 0
             and (36 * t // 256) * (r_s // 256) >= 512 and (not keep or k_s == 160 or k_s % 128 == 0))
 
 
@@ -455,7 +426,7 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
             L.call("gemm_f16x2_af32", v, u, m, 36 * t, r_s, k_s, t_g, rows, 0, va, u_amax)
         if keep is not None:
             keep.append((v, va))
-    elif split and GEMM_AF32 and k_s * 4 * 256 < 0x7FFFFFFF:
+    elif split and P().gemm_af32 and k_s * 4 * 256 < 0x7FFFFFFF:
         v = new(36, t, k_s)
         L.call("wino43_input", xc, v, nb, h, wd, k_s, None)
         with _timed(_gemm_name(1), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 1)):
@@ -499,7 +470,7 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
         nz = (None, 0, 0) if noise is None else (noise[0], noise[1].seed, noise[1].offset + n0 * h * wd * r_s // 4)
         rz = ((None, 0, 0) if res_noise is None else
               (res_noise[0], res_noise[1].seed, res_noise[1].offset + n0 * h * wd * r_s // 4))
-        if stats and PRODUCER_STATS and nb == n and ms is None and act != L.ACT_MASK and _stats_rows_ok(r_s):
+        if stats and P().producer_stats and nb == n and ms is None and act != L.ACT_MASK and _stats_rows_ok(r_s):
             rows = L.lib().dsee_stats_part_rows(C.c_long(nb * (h // 4) * (wd // 4) * (r_s // 4)))
             part = new(rows, 3, r_s)
             L.call("wino43_output_stats", m, bias, res, res_ld or r_s, y, nb, h, wd, r_s, act, LRELU_SLOPE, *nz, *rz, part)
@@ -513,9 +484,9 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
 def _wgrad_mode(cin_s, cout_s):
     """0: fp32-MFMA reduction; 1: bf16x3 with pre-split transposed operands; 2: bf16x3 with fp32 operands transposed and
     split inside the GEMM (256-row tiles: cout_s % 256 == 0, cin_s == 160 or % 128 == 0)."""
-    if not (GEMM_SPLIT and cout_s % 128 == 0 and cin_s % 32 == 0):
+    if not (P().gemm_split and cout_s % 128 == 0 and cin_s % 32 == 0):
         return 0
-    if GEMM_AF32 and cout_s % 256 == 0 and (cin_s == 160 or cin_s % 128 == 0) and max(cin_s, cout_s) * 64 < 0x7FFFFFFF:
+    if P().gemm_af32 and cout_s % 256 == 0 and (cin_s == 160 or cin_s % 128 == 0) and max(cin_s, cout_s) * 64 < 0x7FFFFFFF:
         return 2
     return 1
 
@@ -523,9 +494,9 @@ def _wgrad_mode(cin_s, cout_s):
 def _wgrad_split(mode):
     """`split` argument of dsee_wino43_wgrad[_table] for a weight-gradient mode: 3 = fp16x2, 4 = plain bf16, both on
     fp32 operands transposed in the kernel."""
-    if mode == 2 and HALF:
+    if mode == 2 and P().half:
         return 4
-    return 3 if (mode == 2 and GEMM_F16X2) else mode
+    return 3 if (mode == 2 and P().gemm_f16x2) else mode
 
 
 def _wgrad_name(mode):
@@ -536,7 +507,7 @@ def _wgrad_name(mode):
 
 def _dout_sums_ok(n, nb, cout_s, mode):
     """The channel sums over dY (bias / noise-weight gradients) can ride in the A dY A^T transform (dsee_wino43_dout_sums)."""
-    return DOUT_SUMS and nb == n and mode != 1 and cout_s // 4 <= 256 and 256 % (cout_s // 4) == 0
+    return P().dout_sums and nb == n and mode != 1 and cout_s // 4 <= 256 and 256 % (cout_s // 4) == 0
 
 
 DM_BOUND = 225.0      # |A dY A^T| <= 225 max|dY| for F(4x4,3x3) (absolute row sums of A: 1, 4, 4, 15, 15, 1)
@@ -554,7 +525,7 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
         L.call("wino43_input_split_t", xc, v, nb, h, wd, cin_s)
         L.call("wino43_dout_split_t", gc, dm, nb, h, wd, cout_s)
         return (v, None), (dm, None)
-    need = GEMM_SPLIT and (GEMM_F16X2 or HALF)   # maxima for the fp16 operand scales
+    need = P().gemm_split and (P().gemm_f16x2 or P().half)   # maxima for the fp16 operand scales
     if v is not None and len(v) == 3:
         pass                                     # the forward's pre-split V2 (dsee_wino43_wgrad split = 5)
     elif v is None or (need and v[1] is None):
@@ -590,17 +561,9 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
     return v, dm
 
 
-# bias and noise-weight gradients of a Winograd layer inside its A dY A^T pass (False: separate channel_dot passes over dY)
-DOUT_SUMS = True
-
-# data gradient in the adjoint form from the dM = A dY A^T the weight gradient needs anyway (False: transform dy
-# a second time with B^T . B and run the rotated-kernel convolution)
-ADJOINT_DGRAD = True
-
-
 def _adjoint_ok(k_s, r_s):
     """dV = dM x U^T on the fp32-A split GEMM: k_s = channels of dy (reduction), r_s = channels of dx."""
-    return ADJOINT_DGRAD and GEMM_AF32 and _split_ok(k_s, r_s) and k_s * 4 * 256 < 0x7FFFFFFF
+    return P().adjoint_dgrad and P().gemm_af32 and _split_ok(k_s, r_s) and k_s * 4 * 256 < 0x7FFFFFFF
 
 
 def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0):
@@ -620,7 +583,7 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
         else:
             L.call("gemm_bf16x3_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0)
     dx = new(nb, h, wd, r_s)
-    if mask is None and dvs is None and PRESPLIT_DM:
+    if mask is None and dvs is None and P().presplit_dm:
         tag_amax(dx, amax_slot())      # (dx is the gradient w.r.t. a norm's output: bound of that norm's gamma/beta gradient)
         L.call("wino43_input_adjoint_amax", dv, dx, nb, h, wd, r_s, dx.dsee_amax)
     else:
@@ -646,7 +609,7 @@ def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None
         dx = new(n, h, wd, cin_s) if nb != n else None
     # A dY A^T pre-split when the whole chain can take it: split V kept by the forward (-> wgrad split 6), and the adjoint GEMM
     # (if any) on the 256 x 256 pre-split-A kernel
-    pre_dm = (PRESPLIT_DM and mode == 2 and nb == n and _split_kind(cout_s, cin_s) == 2 and t % 256 == 0
+    pre_dm = (P().presplit_dm and mode == 2 and nb == n and _split_kind(cout_s, cin_s) == 2 and t % 256 == 0
               and cout_s % 16 == 0 and (not with_dx or (cin_s % 256 == 0 and (36 * t // 256) * (cin_s // 256) >= 512)))
     for n0 in range(0, n, nb):
         gc = g if nb == n else g[n0:n0 + nb]
@@ -673,6 +636,7 @@ class Conv2d(torch.autograd.Function):
     def forward(ctx, x, w, bias, res, stride, pad, ups, act, noise_w=None, noise_eps=None, res_noise_w=None,
                 res_noise_eps=None, res_sink=None, exact=False, stats=False):
         """`exact`: keep a direct convolution on the fp32 MFMA (no operand-maximum passes over its activations)."""
+        ctx.plan = P()
         ctx.exact = bool(exact)
         _bind_rng(noise_eps, res_noise_eps)
         co, ci, kh, kw = w.shape
@@ -686,15 +650,15 @@ class Conv2d(torch.autograd.Function):
         w.dsee_u = ctx.w_u = w_u
         vkeep = None
         ctx.wino = _wino_ok(n, hi, wi, cin_s, cout_s, kh, stride, pad, ups)
-        ctx.thin = (not THIN_GEMM and kh == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and cin_s % 256 == 0
+        ctx.thin = (not P().thin_gemm and kh == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and cin_s % 256 == 0
                     and cin_s <= 1024 and wi % 64 == 0 and res is None)
         if ctx.thin:
             out = new(n, hi, wi, cout_s)
             L.call("conv3x3_thin_fwd", x, w, bias, out, n, hi, wi, cin_s, co, act, LRELU_SLOPE)
         elif ctx.wino:
             # the fp32 V of x is the weight gradient's Q operand: keep it instead of transforming x again (2.25x the
-            # bytes of x; KEEP_V = False trades the memory back for one more transform pass)
-            keep = [] if (KEEP_V and ctx.needs_input_grad[1] and _wgrad_mode(cin_s, cout_s) == 2) else None
+            # bytes of x; keep_v = False trades the memory back for one more transform pass)
+            keep = [] if (P().keep_v and ctx.needs_input_grad[1] and _wgrad_mode(cin_s, cout_s) == 2) else None
             # bench.py: the whole layer (input transform + GEMMs + output transform) on its algorithmic bytes (x in, y out)
             # and its Winograd-domain FLOPs (2.25 multiplies per output and channel pair instead of 9)
             with _timed("conv_forward@%dx%d %d->%d" % (hi, wi, cin_s, cout_s), 2.0 * 36 * (n * hi * wi // 16) * cin_s * cout_s,
@@ -718,6 +682,7 @@ class Conv2d(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_under_plan
     def backward(ctx, dy):
         x, w, out, vk, vk_amax = ctx.saved_tensors
         w.dsee_amax, w.dsee_u = ctx.w_amax, ctx.w_u
@@ -726,7 +691,7 @@ class Conv2d(torch.autograd.Function):
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
-        if ctx.act != L.ACT_NONE and ctx.wino and PRESPLIT_DM:
+        if ctx.act != L.ACT_NONE and ctx.wino and P().presplit_dm:
             g = torch.empty_like(dy)
             tag_amax(g, amax_slot())      # (the A dY A^T transform below is written pre-split with this bound)
             L.call("act_bwd_amax", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE, g.dsee_amax)
@@ -736,10 +701,10 @@ class Conv2d(torch.autograd.Function):
         else:
             g = dy
         dx = dw = db = dres = None
-        fused = (ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        fused = (ctx.wino and P().winograd_wgrad and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                  and _wgrad_mode(geom.Cin, geom.Cout) != 1 and _adjoint_ok(geom.Cout, geom.Cin))
         sums = None
-        if ctx.wino and WINOGRAD_WGRAD and ctx.needs_input_grad[1]:
+        if ctx.wino and P().winograd_wgrad and ctx.needs_input_grad[1]:
             want = {"bias": bool(ctx.has_bias and ctx.needs_input_grad[2]),
                     "n0": ctx.noise if (ctx.noise is not None and ctx.needs_input_grad[8]) else None,
                     "n1": ctx.res_noise if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None}
@@ -767,7 +732,7 @@ class Conv2d(torch.autograd.Function):
             ws = scratch(L.lib().dsee_conv3x3_thin_wgrad_workspace(geom.Cin), "wgrad")
             dw = new(co, ci, 3, 3)
             L.call("conv3x3_thin_wgrad", x, g, ws, dw, geom.N, geom.Hi, geom.Wi, geom.Cin, co, ci)
-        elif ctx.needs_input_grad[1] and ctx.wino and WINOGRAD_WGRAD:
+        elif ctx.needs_input_grad[1] and ctx.wino and P().winograd_wgrad:
             dw = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, sums=sums)
         elif ctx.needs_input_grad[1]:
             dw = wgrad_raw(x, g, geom, co, ci, kh, kw, amax_cache=getattr(ctx, "amax_cache", None), exact=ctx.exact)
@@ -823,20 +788,10 @@ class GradSink:
         return g
 
 
-# NoiseInjection draws regenerated inside the consumer's output transform (False: stand-alone UpNoise passes)
-FUSE_NOISE = True
-
-
 def _fusable_noise(x, w, stride, pad, ups, eps):
     n, hi, wi, cin_s = x.shape
-    return (FUSE_NOISE and isinstance(eps, PhiloxNormal) and w.shape[2] == 3 and w.shape[0] > 4
+    return (P().fuse_noise and isinstance(eps, PhiloxNormal) and w.shape[2] == 3 and w.shape[0] > 4
             and _wino_ok(n, hi, wi, cin_s, L.pad4(w.shape[0]), 3, stride, pad, ups))
-
-
-# The generator's to-RGB layer (512 -> 3 channels at full resolution, sr.py:94-95) as a 1x1 GEMM with 27 outputs on the fp32
-# MFMA + a 9-point gather (ThinGather) instead of the VALU / cross-lane-reduction kernels of thin.hip: x is read once at HBM
-# rate forward, and the data / weight gradients are plain 1x1 implicit GEMMs (2.0 + 3.3 ms -> see DESIGN 5).
-THIN_GEMM = True
 
 
 class ThinGather(torch.autograd.Function):
@@ -867,7 +822,7 @@ class ThinGather(torch.autograd.Function):
 
 def _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
     co, ci, kh, kw = w.shape
-    return (THIN_GEMM and kh == 3 and kw == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and res is None
+    return (P().thin_gemm and kh == 3 and kw == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and res is None
             and noise is None and res_noise is None and x.shape[3] >= 128 and x.shape[3] % 32 == 0)
 
 
@@ -1005,7 +960,7 @@ class SNGroup:
         w0 = self.layers[0].weight_orig
         co, ci = w0.shape[0], w0.shape[1]
         same = all(tuple(m.weight_orig.shape) == tuple(w0.shape) for m in self.layers) and tuple(w0.shape[2:]) == (3, 3)
-        if not (same and WINOGRAD and GEMM_SPLIT and GEMM_F16X2 and GEMM_AF32 and not HALF and ci % 32 == 0 and co % 128 == 0
+        if not (same and P().winograd and P().gemm_split and P().gemm_f16x2 and P().gemm_af32 and not P().half and ci % 32 == 0 and co % 128 == 0
                 and ci % 128 == 0 and ci >= 128):
             return
         out, amax = self.last
@@ -1072,13 +1027,14 @@ class UpNoise(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, noise_w, eps, ups, stats=False):
         """`stats`: y feeds a training-mode BatchNorm: its statistics rows are written in the same pass."""
+        ctx.plan = P()
         n, h0, w0, c = x.shape
         y = new(n, h0 << ups, w0 << ups, c)
         ctx.philox = eps if isinstance(eps, PhiloxNormal) else None
         _bind_rng(eps)
         if ctx.philox is not None:
             assert eps.shape == tuple(y.shape)
-            if stats and PRODUCER_STATS and _stats_rows_ok(c):
+            if stats and P().producer_stats and _stats_rows_ok(c):
                 rows = L.lib().dsee_stats_part_rows(C.c_long(y.numel() // 4))
                 part = new(rows, 3, c)
                 L.call("upsample_noise_rng_fwd_stats", x, noise_w, y, n, h0 << ups, w0 << ups, c, ups, C.c_uint64(eps.seed),
@@ -1096,6 +1052,7 @@ class UpNoise(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_under_plan
     def backward(ctx, dy):
         (eps,) = ctx.saved_tensors
         _bind_rng(ctx.philox)
@@ -1299,17 +1256,8 @@ class SyncBNConfig:
         self.world, self.group, self.clamp = int(world), group, bool(clamp)
 
 
-SYNC_BN = None   # set by SRModel / parallel.attach when opt.sync_bn
-
-
-# one statistics pass per tensor, shared by the BatchNorms that normalise it (False: one pass per norm layer)
-SHARE_STATS = True
-# BatchNorm statistics rows written by the kernel that produces the norm's input (False: a statistics pass over x)
-PRODUCER_STATS = True
-
-
 def _stats_rows_ok(c):
-    return SYNC_BN is None and c % 4 == 0 and c // 4 <= 256 and 256 % (c // 4) == 0
+    return P().sync_bn is None and c % 4 == 0 and c // 4 <= 256 and 256 % (c // 4) == 0
 
 
 def bn_stats(x, running_mean, running_var, training):
@@ -1319,7 +1267,7 @@ def bn_stats(x, running_mean, running_var, training):
     if not training:
         L.call("norm_eval_stats", running_mean, running_var, c, BN_EPS, mean, invstd)
         return mean, invstd, None
-    cfg = SYNC_BN
+    cfg = P().sync_bn
     if cfg is None:
         # norm_0 and norm_s of a resblock normalise the same tensor: the partial (mean, M2) rows of the pass over x stay
         # attached to it, the second layer only folds them (its own running statistics)
@@ -1332,7 +1280,7 @@ def bn_stats(x, running_mean, running_var, training):
         if part is None:
             part = torch.empty(L.lib().dsee_norm_workspace(n, h * w, c, 1) // 4, dtype=torch.float32, device="cuda")
             L.call("norm_stats_partial", x, n, h * w, c, 1, part)
-            if SHARE_STATS:
+            if P().share_stats:
                 x.dsee_stats_part = part
         L.call("norm_stats_finalize", part, n, h * w, c, 1, BN_EPS, BN_MOMENTUM, mean, invstd, running_mean, running_var)
         return mean, invstd, None
@@ -1346,10 +1294,6 @@ def bn_stats(x, running_mean, running_var, training):
     return mean, invstd, cfg
 
 
-# gamma/beta gradient written by the norm backward directly in the Winograd domain (False: dgb + wino43_dout)
-FUSE_DM = True
-
-
 def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=None, xhat_amax=None):
     """Backward of BN + modulate + LeakyReLU: (dx, dgb, col_sums [2][C], dM).  With SyncBN (`cfg`) the two per-channel
     sums of the BN backward are all-reduced over the ranks between the reduce and the apply pass.  `as_dm`: the
@@ -1360,7 +1304,7 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     dgb = dm = None
     t = n * (h // 4) * (w // 4)
     dha = carried_amax(dh)
-    if as_dm and PRESPLIT_DM and PRESPLIT_GB and xhat_amax is not None and dha is not None and t % 256 == 0 and not HALF:
+    if as_dm and P().presplit_dm and P().presplit_gb and xhat_amax is not None and dha is not None and t % 256 == 0 and not P().half:
         # max |dh| (written by the kernel that produced dh) x max(1, max |xhat|) (written by the forward pass) bounds both halves
         # (g * xhat | g) of the gradient: dM leaves the reduce pass pre-split, for the table / embedding weight gradient's P
         # operand and the adjoint data-gradient GEMM's A operand
@@ -1371,7 +1315,7 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
         L.call("modulate_bwd_reduce_wino_f16x2", dh.contiguous(), out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c,
                LRELU_SLOPE, ws, ga, DM_BOUND)
     elif as_dm:
-        dm = (new(36, t, rows), amax_slot() if (GEMM_SPLIT and (GEMM_F16X2 or HALF)) else None)
+        dm = (new(36, t, rows), amax_slot() if (P().gemm_split and (P().gemm_f16x2 or P().half)) else None)
         ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
         L.call("modulate_bwd_reduce_wino", dh.contiguous(), out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c,
                LRELU_SLOPE, ws, dm[1])
@@ -1398,6 +1342,7 @@ class SpadeNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cat, w2, b2, running_mean, running_var, training, add_one, cat_ups, grad_sink=None):
+        ctx.plan = P()
         ctx.grad_sink = grad_sink
         n, h, w, c = x.shape
         rows, kin = w2.shape[0], w2.shape[1]
@@ -1416,6 +1361,7 @@ class SpadeNormAct(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_under_plan
     def backward(ctx, dh):
         x, cat, w2, out, scale, mean, invstd = ctx.saved_tensors
         geom = ctx.geom
@@ -1440,13 +1386,9 @@ class SpadeNormAct(torch.autograd.Function):
         return dx, dcat, dw2, db2, None, None, None, None, None, None
 
 
-# The fused SPADE / SEAN forward (dsee_spade_fused_fwd): fp16x2 operands, K = 128 | 160, whole 64-tile groups per image.
-FUSED_NORM = True
-
-
 def _fused_norm_ok(n, h, w, c, rows, ld):
     tpi = (h // 4) * (w // 4)
-    return (FUSED_NORM and GEMM_SPLIT and GEMM_F16X2 and GEMM_AF32 and not HALF and ld in (128, 160) and rows == 2 * c
+    return (P().fused_norm and P().gemm_split and P().gemm_f16x2 and P().gemm_af32 and not P().half and ld in (128, 160) and rows == 2 * c
             and c % 32 == 0 and h % 4 == 0 and w % 4 == 0 and tpi % 64 == 0
             and 36 * n * tpi * ld * 4 < 0xFFFFFFF0 and 36 * n * rows * ld * 4 < 0xFFFFFFF0)
 
@@ -1462,6 +1404,7 @@ class SeanNormTable(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, *args):
+        ctx.plan = P()
         n, h, w, c = x.shape
         # bench.py: the whole forward on SURVEY 8(d)'s algorithmic bytes (x twice, out, the 128-channel embedding, labels)
         with _timed("norm_forward@%dx%d" % (h, w), 0.0, 4.0 * n * h * w * (3 * c + NHIDDEN) + n * h * w):
@@ -1537,8 +1480,8 @@ class SeanNormTable(torch.autograd.Function):
                 tag_amax(out, hm)
                 ctx.xhat_amax = xm
             keep = None
-            if KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
-                if PRESPLIT_A:
+            if P().keep_v and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
+                if P().presplit_a:
                     keep = [(v2, ac, True)]     # the weight / table gradient reads the split V the kernel above consumed
                 else:
                     # ... or an fp32 V of its own as its Q operand
@@ -1551,7 +1494,7 @@ class SeanNormTable(torch.autograd.Function):
             b2c = b2.contiguous()
             split = _split_kind(ld, rows)
             # the fp32 V of `cat` is the Q operand of the weight / table gradient: kept for the backward pass
-            keep = [] if (KEEP_V and need_scale and nb == n and _wgrad_mode(ld, rows) == 2) else None
+            keep = [] if (P().keep_v and need_scale and nb == n and _wgrad_mode(ld, rows) == 2) else None
             for n0 in range(0, n, nb):
                 if has_t:
                     ua = weight_amax(w2a if has_a else None, tb[n0:n0 + nb]) if split >= 2 else None
@@ -1581,6 +1524,7 @@ class SeanNormTable(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_under_plan
     def backward(ctx, dh):
         x, cat, w2a, out, scale, mean, invstd, vc, vc_amax, actv_low = ctx.saved_tensors
         if w2a is not None:
@@ -1597,7 +1541,7 @@ class SeanNormTable(torch.autograd.Function):
         fused_d = (wino_w and ctx.has_a and _wgrad_mode(ld, rows) != 1 and _adjoint_ok(rows, NHIDDEN))
         dactv_fused = [None]
         # every consumer of the gamma/beta gradient reads dM: let the norm backward write it directly
-        as_dm = (FUSE_DM and wino_w and nb == n and _wgrad_mode(ld, rows) != 1 and (fused_d or not ctx.has_a)
+        as_dm = (P().fuse_dm and wino_w and nb == n and _wgrad_mode(ld, rows) != 1 and (fused_d or not ctx.has_a)
                  and 256 % (c // 4) == 0)
         add = ctx.grad_sink.take() if ctx.grad_sink is not None else None
         # (pre-split dM needs both of its consumers on the pre-split kernels: the TN weight gradient reads the kept V2, the

@@ -142,8 +142,9 @@ def attach(trainer, world, chunk_mb=24.0, rank=None, force=False):
     model.noise.seed += NOISE_SEED_STRIDE * rank
     model.dp_world, model.dp_rank = int(world), int(rank)
     opt = trainer.opt
-    ops.SYNC_BN = (ops.SyncBNConfig(world, None, getattr(opt, "sync_bn_clamp", True))
-                   if getattr(opt, "sync_bn", False) and (world > 1 or force) else None)
+    cfg = (ops.SyncBNConfig(world, None, getattr(opt, "sync_bn_clamp", True))
+           if getattr(opt, "sync_bn", False) and (world > 1 or force) else None)
+    model.plan = model.plan.replace(sync_bn=cfg)      # (per model: deepsee_amd/plan.py)
     if world > 1:
         for opt in (trainer.optimizer_G, trainer.optimizer_D):
             if opt is not None:

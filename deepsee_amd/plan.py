@@ -1,0 +1,113 @@
+"""KernelPlan: which of the equivalent kernel paths a model's operators take.
+
+Rounds 1-3 steered `deepsee_amd/ops.py` with ~18 mutable module attributes (and a process-wide `ops.HALF` for the precision),
+so two models of different precision could not coexist in a process and benchmarks had to mutate a module between
+measurements.  A plan is an immutable value owned by ONE model (`SRModel.plan`, built from `opt.precision` /
+`opt.kernel_plan`); `SRModel.forward` makes it the active plan of the calling thread for the duration of the forward pass,
+every autograd node records the plan it was built under (`ctx.plan`) and re-activates it in its backward -- which runs on the
+autograd engine's thread -- so a forward and its backward always agree, whatever other models do in between.  Code that calls
+operators directly (unit tests, micro-benchmarks) either runs under the default plan or inside `with plan.active():`.
+
+Every field selects between kernel paths that compute the SAME function (the non-default side of each is exercised by
+tests/test_gpu_model.py::test_kernel_path_switches); `half` alone changes the arithmetic (BASELINE configs[2]'s 16-bit mode).
+"""
+import contextlib
+import dataclasses
+import threading
+from typing import Any, Optional
+
+
+@dataclasses.dataclass(frozen=True)
+class KernelPlan:
+    # Winograd F(4x4,3x3) for the wide 3x3 / stride-1 layers (4x fewer fp32 MACs than the direct form): forward + data
+    # gradient | weight gradient | the SPADE/SEAN gamma/beta convolution
+    winograd: bool = True
+    winograd_wgrad: bool = True
+    winograd_mod: bool = True
+    # fp32 GEMMs of the Winograd domain on the 16-bit matrix cores via operand splitting (gemm_bf16x3.hip); False keeps them
+    # on v_mfma_f32_32x32x2_f32 (bench.py's f32_mfma_only comparison run)
+    gemm_split: bool = True
+    # A operand of the forward / data-gradient GEMMs kept in fp32 in HBM and split inside the GEMM kernel; False uses
+    # pre-split bf16x3 A operands (round 1's form)
+    gemm_af32: bool = True
+    # keep the forward's V for the weight gradient (False: transform x again in the backward pass)
+    keep_v: bool = True
+    # two-term fp16 splits (3 instead of 6 MFMA products per fp32 multiply-add, operands scaled by exact powers of two);
+    # False keeps the exact 3-term bf16 form (bench.py's bf16x3_exact comparison run)
+    gemm_f16x2: bool = True
+    # Half-precision compute mode (BASELINE configs[2]'s 16-bit arithmetic; opt.precision = "fp16"): the Winograd-domain
+    # GEMMs take operands scaled by powers of two and rounded to ONE fp16 term (one MFMA product, fp32 accumulate), stored
+    # as such in HBM, and write their products M / dV as scaled fp16; activations, statistics, master weights and the
+    # optimizer stay fp32.  fp16 and not bf16 because the F(4x4,3x3) transforms amplify operand rounding ~10x (per-layer
+    # error 2.6 % with bf16 operands, 0.33 % with scaled fp16; a direct bf16 convolution: 0.24 %).
+    half: bool = False
+    # A operand of a forward Winograd GEMM written pre-split by the input transform (False: fp32 V, split inside the GEMM)
+    presplit_a: bool = True
+    # A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
+    presplit_dm: bool = True
+    # ... and the gamma/beta gradient of a SPADE/SEAN norm as well (False: fp32 dM from the norm backward's reduce pass)
+    presplit_gb: bool = True
+    # bias and noise-weight gradients of a Winograd layer inside its A dY A^T pass (False: separate channel_dot passes)
+    dout_sums: bool = True
+    # data gradient in the adjoint form from the dM = A dY A^T the weight gradient needs anyway (False: transform dy a
+    # second time with B^T . B and run the rotated-kernel convolution)
+    adjoint_dgrad: bool = True
+    # NoiseInjection draws regenerated inside the consumer's output transform (False: stand-alone UpNoise passes)
+    fuse_noise: bool = True
+    # the generator's to-RGB layer (512 -> 3 channels at full resolution) as a 1x1 GEMM with 27 outputs + a 9-point gather
+    # (False: the VALU / cross-lane-reduction kernels of thin.hip)
+    thin_gemm: bool = True
+    # one statistics pass per tensor, shared by the BatchNorms that normalise it (False: one pass per norm layer)
+    share_stats: bool = True
+    # BatchNorm statistics rows written by the kernel that produces the norm's input (False: a statistics pass over x)
+    producer_stats: bool = True
+    # gamma/beta gradient written by the norm backward directly in the Winograd domain (False: dgb + wino43_dout)
+    fuse_dm: bool = True
+    # the fused SPADE / SEAN forward (dsee_spade_fused_fwd; False: GEMM + wino43_output_modulate)
+    fused_norm: bool = True
+    # norm backward in one pass behind the producer of dh (False: reduce pass + apply pass)
+    fused_norm_bwd: bool = True
+    # direct (non-Winograd) convolutions with at least this much work run their MFMAs on fp16x2-split operands; 0 disables
+    conv_f16x2_min_flop: float = 1e9
+    # SyncBN-over-RCCL (ops.SyncBNConfig) or None for north_star's sync-free BatchNorm
+    sync_bn: Optional[Any] = None
+
+    def replace(self, **changes):
+        return dataclasses.replace(self, **changes)
+
+    @contextlib.contextmanager
+    def active(self):
+        """Make this plan the one the operators of the calling thread consult."""
+        prev = getattr(_tls, "plan", None)
+        _tls.plan = self
+        try:
+            yield self
+        finally:
+            _tls.plan = prev
+
+    @classmethod
+    def fields(cls):
+        return [f.name for f in dataclasses.fields(cls)]
+
+
+DEFAULT_PLAN = KernelPlan()
+_tls = threading.local()
+
+
+def current():
+    """The active plan of this thread (DEFAULT_PLAN outside any `with plan.active()`)."""
+    return getattr(_tls, "plan", None) or DEFAULT_PLAN
+
+
+def from_opt(opt):
+    """The plan of a model built from `opt`: opt.precision ('fp32' | 'fp16') and the optional opt.kernel_plan (a KernelPlan,
+    or a dict of field overrides such as bench.py's --arith choices)."""
+    prec = getattr(opt, "precision", "fp32")
+    if prec not in ("fp32", "fp16"):
+        raise ValueError("opt.precision must be 'fp32' or 'fp16', got %r" % (prec,))
+    over = getattr(opt, "kernel_plan", None)
+    if isinstance(over, KernelPlan):
+        plan = over
+    else:
+        plan = DEFAULT_PLAN.replace(**dict(over or {}))
+    return plan.replace(half=(prec == "fp16"))

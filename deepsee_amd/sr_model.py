@@ -17,6 +17,7 @@ from . import lib as L
 from . import networks as N
 from . import ops
 from .optim import FlatAdam
+from .plan import from_opt as plan_from_opt
 
 
 def block_plan(opt):
@@ -74,10 +75,9 @@ class SRModel(nn.Module):
             raise RuntimeError("deepsee_amd.SRModel needs an MI355X (HIP) device: there is no CPU fallback")
         L.lib()  # fail loudly if libdeepsee_hip.so is missing
         self.opt = opt
-        prec = getattr(opt, "precision", "fp32")
-        if prec not in ("fp32", "fp16"):
-            raise ValueError("opt.precision must be 'fp32' or 'fp16', got %r" % (prec,))
-        ops.HALF = prec == "fp16"   # process-wide (one model per process): 16-bit matrix-core GEMMs, fp32 everything else
+        # which of the equivalent kernel paths this model's operators take, and its precision (opt.precision 'fp32' | 'fp16':
+        # 16-bit matrix-core GEMMs, fp32 everything else) -- an immutable value owned by THIS model (deepsee_amd/plan.py)
+        self.plan = plan_from_opt(opt)
         self.use_E = opt.netE is not None and len(opt.netE) > 0
         self.model_variant = "guided" if (self.use_E and "full" in opt.netE) else "independent"   # sr_model.py:26-30
         gen = torch.Generator().manual_seed(int(getattr(opt, "seed", 0)))
@@ -123,6 +123,10 @@ class SRModel(nn.Module):
         return True
 
     def forward(self, data, mode, **kwargs):
+        with self.plan.active():       # the backward pass re-activates it per autograd node (ops._under_plan)
+            return self._forward(data, mode, **kwargs)
+
+    def _forward(self, data, mode, **kwargs):
         d = self._native(data)
         if mode in ("generator", "discriminator"):
             self.noise.begin_step()     # fresh Philox positions / branch coins for this forward

@@ -551,12 +551,9 @@ def test_presplit_path_selection_rules():
     assert not ops._presplit_ok(x, 32768, 4096 + 64, 512)                   # group size not a multiple of 256
     assert ops._presplit_ok(x, 32768, 32768, 512, k_s=160, keep=True) and ops._presplit_ok(x, 32768, 32768, 512, 256, True)
     assert not ops._presplit_ok(x, 32768, 32768, 512, k_s=96, keep=True)    # TN kernel: 160 or a multiple of 128 columns
-    saved = ops.PRESPLIT_A
-    try:
-        ops.PRESPLIT_A = False
+    with ops.KernelPlan(presplit_a=False).active():
         assert not ops._presplit_ok(x, 32768, 32768, 512)
-    finally:
-        ops.PRESPLIT_A = saved
+    assert ops.P() is ops.DEFAULT_PLAN and ops._presplit_ok(x, 32768, 32768, 512)
     # the channel sums that ride in the A dY A^T pass / the statistics rows of a producer need 256 % (C/4) == 0
     assert ops._dout_sums_ok(8, 8, 512, 2) and not ops._dout_sums_ok(8, 4, 512, 2) and not ops._dout_sums_ok(8, 8, 512, 1)
     assert ops._stats_rows_ok(512) and ops._stats_rows_ok(64) and not ops._stats_rows_ok(96 * 4 + 4)
@@ -606,3 +603,51 @@ def test_carried_operand_bound_is_dropped_after_an_in_place_update():
     x = torch.ones(4, requires_grad=True)
     Tagged.apply(Probe.apply(x)).sum().backward()
     assert seen == [slot] or seen[0] is slot                 # single consumer: the bound arrives
+
+
+def test_kernel_plan_is_per_model_and_per_thread():
+    """deepsee_amd/plan.py: a plan is an immutable value; activating one is thread-local and nests; an autograd node's
+    backward runs under the plan its forward recorded even when another plan is active on the calling thread."""
+    import threading
+    import torch
+    from deepsee_amd import ops, plan as PL
+    from deepsee_amd.options import make_opt
+    assert PL.current() is PL.DEFAULT_PLAN and not PL.DEFAULT_PLAN.half
+    a = PL.from_opt(make_opt(precision="fp16"))
+    b = PL.from_opt(make_opt(kernel_plan=dict(gemm_f16x2=False)))
+    assert a.half and a.gemm_f16x2 and not b.half and not b.gemm_f16x2
+    with pytest.raises(Exception):
+        a.half = False                                 # frozen
+    with pytest.raises(ValueError):
+        PL.from_opt(make_opt(precision="bf16"))
+    with pytest.raises(TypeError):
+        PL.from_opt(make_opt(kernel_plan=dict(no_such_switch=1)))
+    with a.active():
+        assert ops.P() is a and ops._split_kind(512, 512) == 3
+        with b.active():
+            assert ops.P() is b and ops._split_kind(512, 512) == 1
+        assert ops.P() is a
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(PL.current()))
+        t.start(); t.join()
+        assert seen == [PL.DEFAULT_PLAN]               # another thread is not affected
+    assert ops.P() is PL.DEFAULT_PLAN and ops._split_kind(512, 512) == 2
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            ctx.plan = ops.P()
+            return x * 2
+
+        @staticmethod
+        @ops._under_plan
+        def backward(ctx, dy):
+            seen.append(ops.P())
+            return dy * 2
+    seen.clear()
+    x = torch.ones(2, requires_grad=True)
+    with a.active():
+        y = Node.apply(x)
+    with b.active():
+        y.sum().backward()
+    assert seen == [a]

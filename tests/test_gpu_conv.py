@@ -241,15 +241,11 @@ def test_bf16x3_adds_no_error_to_the_winograd_conv():
     ref = F.conv2d(x.double(), w.double(), padding=1)
     xd, wd = nhwc(x).cuda(), w.cuda()
     errs = {}
-    saved = (ops.WINOGRAD, ops.GEMM_SPLIT)
-    try:
-        for name, wino, split in (("direct", False, False), ("winograd_f32", True, False), ("winograd_bf16x3", True, True)):
-            ops.WINOGRAD, ops.GEMM_SPLIT = wino, split
+    for name, wino, split in (("direct", False, False), ("winograd_f32", True, False), ("winograd_bf16x3", True, True)):
+        with ops.KernelPlan(winograd=wino, gemm_split=split).active():
             y = ops.conv2d(xd, wd, None, None, 1, 1, 0, 0)
-            torch.cuda.synchronize()
-            errs[name] = float((nchw(y.cpu(), c).double() - ref).norm() / ref.norm())
-    finally:
-        ops.WINOGRAD, ops.GEMM_SPLIT = saved
+        torch.cuda.synchronize()
+        errs[name] = float((nchw(y.cpu(), c).double() - ref).norm() / ref.norm())
     print(errs)
     assert errs["direct"] < 1e-6
     assert errs["winograd_f32"] < 2e-5
@@ -712,7 +708,7 @@ def test_small_channel_keeps_its_precision_in_the_winograd_conv(shift):
     depend on the small operands alone are held to 1e-3 relative to THEIR OWN size against float64 (measured ~1e-5)."""
     from deepsee_amd import ops
     n, c, h, small = 2, 256, 64, 2.0 ** -shift
-    assert ops._wino_ok(n, h, h, c, c, 3, 1, 1, 0) and ops.GEMM_F16X2 and not ops.HALF
+    assert ops._wino_ok(n, h, h, c, c, 3, 1, 1, 0) and ops.P().gemm_f16x2 and not ops.P().half
     g = torch.Generator().manual_seed(2020)
     x = torch.randn(n, c, h, h, generator=g)
     x[:, 7] *= small

@@ -267,19 +267,20 @@ def smooth_loss_errors(over, seed=555, plain_f32=True):
     m.noise = N.ReplayNoise(ctl.tape)
     tm.optimizer_G.zero_grad()
     tm.optimizer_D.zero_grad()
-    d = m._native(tm.preprocess_input({k: v.clone() for k, v in batch.items()}))
-    fake, _ = m.generate_fake(d)
-    loss = (ops.ToNCHW.apply(fake, 3) * Rs["fake"].cuda()).sum()
-    douts = m.discriminate(d["labels"], fake, d["image_hr"], train_d=True)
-    k = 0
-    for o in douts:
-        for t in o:
-            c = Rs["d%d" % k].shape[1]
-            loss = loss + (ops.ToNCHW.apply(t, c) * Rs["d%d" % k].cuda()).sum() / Rs["d%d" % k][0].numel() ** 0.5
-            k += 1
-    for i, t in enumerate(m.vgg(fake)):
-        R = Rs["v%d" % i]
-        loss = loss + (ops.ToNCHW.apply(t, R.shape[1]) * R.cuda()).sum() / R[0].numel() ** 0.5
+    with m.plan.active():      # (model internals called directly: SRModel.forward is what normally activates the plan)
+        d = m._native(tm.preprocess_input({k: v.clone() for k, v in batch.items()}))
+        fake, _ = m.generate_fake(d)
+        loss = (ops.ToNCHW.apply(fake, 3) * Rs["fake"].cuda()).sum()
+        douts = m.discriminate(d["labels"], fake, d["image_hr"], train_d=True)
+        k = 0
+        for o in douts:
+            for t in o:
+                c = Rs["d%d" % k].shape[1]
+                loss = loss + (ops.ToNCHW.apply(t, c) * Rs["d%d" % k].cuda()).sum() / Rs["d%d" % k][0].numel() ** 0.5
+                k += 1
+        for i, t in enumerate(m.vgg(fake)):
+            R = Rs["v%d" % i]
+            loss = loss + (ops.ToNCHW.apply(t, R.shape[1]) * R.cuda()).sum() / R[0].numel() ** 0.5
     loss.backward()
     torch.cuda.synchronize()
     hg = {nm: _grad_or_zero(p) for o in (tm.optimizer_G, tm.optimizer_D) for nm, p in zip(o.names, o.params)}
@@ -468,21 +469,18 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
 
     # (SyncBN computes its statistics in a pass of its own; the plain run does the same here so that the two runs differ
     # by the collectives only -- beta1 = 0 Adam turns any rounding difference of step 1 into +-lr differences at step 2)
-    ops.PRODUCER_STATS = False
-    plain = steps(TrainerManager(make_opt(seed=3, **over)))
+    plain = steps(TrainerManager(make_opt(seed=3, kernel_plan=dict(producer_stats=False), **over)))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
-        tm = TrainerManager(make_opt(seed=3, sync_bn=True, sync_bn_clamp=False, **over))
+        tm = TrainerManager(make_opt(seed=3, sync_bn=True, sync_bn_clamp=False, kernel_plan=dict(producer_stats=False), **over))
         parallel.attach(tm, 1, chunk_mb=0.25, force=True)
-        assert tm.optimizer_G.reduce_hook.active and ops.SYNC_BN is not None
+        assert tm.optimizer_G.reduce_hook.active and tm.sr_model.plan.sync_bn is not None
         assert len(tm.optimizer_G.chunk_ranges(tm.optimizer_G.reduce_hook.chunk_elems)) > 4
         dp = steps(tm)
     finally:
-        ops.SYNC_BN = None
-        ops.PRODUCER_STATS = True
         dist.destroy_process_group()
     for a, b in zip(plain[0], dp[0]):
         for k in a:
@@ -617,7 +615,7 @@ def test_half_mode_tracks_fp32():
     try:
         for prec in ("fp32", "fp16"):
             tm = TrainerManager(make_opt(precision=prec, **over))
-            assert ops.HALF == (prec == "fp16")
+            assert tm.sr_model.plan.half == (prec == "fp16")
             traj, fake0 = [], None
             for it in range(6):
                 tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
@@ -629,7 +627,7 @@ def test_half_mode_tracks_fp32():
             runs[prec] = (fake0, traj)
             del tm
     finally:
-        ops.HALF = False
+        pass     # (the precision is the model's own plan: nothing process-wide to restore)
     dev = rel(runs["fp16"][0], runs["fp32"][0])
     print("fp16 mode vs fp32: |fake| deviation %.2e; losses at iteration 6: %s vs %s" % (dev, runs["fp16"][1][-1], runs["fp32"][1][-1]))
     assert dev < 3e-2, dev
@@ -659,7 +657,7 @@ def test_half_mode_vs_oracle():
     gl, fake = orc.run_generator_one_step({k: v.clone() for k, v in batch.items()})
     try:
         tm = TrainerManager(make_opt(precision="fp16", **over))
-        assert ops.HALF
+        assert tm.sr_model.plan.half
         tm.sr_model.load_states(states)
         tm.sr_model.noise = N.ReplayNoise(ctl.tape)
         tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
@@ -667,7 +665,7 @@ def test_half_mode_vs_oracle():
         hfake = tm.get_latest_generated().detach().cpu()
         hgl = {k: float(v) for k, v in tm.g_losses.items()}
     finally:
-        ops.HALF = False
+        pass     # (the precision is the model's own plan: nothing process-wide to restore)
     dev = rel(hfake, fake.detach())
     print("fp16 mode vs the CPU oracle: |fake - oracle| / |oracle| = %.2e, losses %s vs %s"
           % (dev, {k: round(v, 4) for k, v in hgl.items()}, {k: round(float(v.detach()), 4) for k, v in gl.items()}))
@@ -676,14 +674,16 @@ def test_half_mode_vs_oracle():
         assert abs(hgl[k] - float(v.detach())) <= 0.05 * abs(float(v.detach())) + 1e-3, (k, hgl[k], float(v.detach()))
 
 
-SWITCHES = [("KEEP_V", False), ("ADJOINT_DGRAD", False), ("FUSE_DM", False), ("FUSE_NOISE", False), ("GEMM_AF32", False),
-            ("FUSED_NORM", False), ("THIN_GEMM", False), ("GEMM_F16X2", False), ("GEMM_SPLIT", False),
-            ("WINOGRAD_WGRAD", False), ("WINOGRAD_MOD", False), ("CONV_F16X2_MIN_FLOP", 0.0), ("DOUT_SUMS", False), ("SHARE_STATS", False), ("PRODUCER_STATS", False), ("PRESPLIT_A", False), ("PRESPLIT_DM", False), ("PRESPLIT_GB", False)]
+SWITCHES = [("keep_v", False), ("adjoint_dgrad", False), ("fuse_dm", False), ("fuse_noise", False), ("gemm_af32", False),
+            ("fused_norm", False), ("thin_gemm", False), ("gemm_f16x2", False), ("gemm_split", False),
+            ("winograd_wgrad", False), ("winograd_mod", False), ("conv_f16x2_min_flop", 0.0), ("dout_sums", False),
+            ("share_stats", False), ("producer_stats", False), ("presplit_a", False), ("presplit_dm", False),
+            ("presplit_gb", False), ("fused_norm_bwd", False)]
 
 
 def test_kernel_path_switches():
-    """deepsee_amd.ops selects between kernel paths that compute the same function through module switches (no
-    environment variables).  Every switch's non-default side runs one G + D step of the benchmark's geometry (32 -> 256,
+    """A model's KernelPlan (deepsee_amd/plan.py; opt.kernel_plan) selects between kernel paths that compute the same
+    function -- per model, no module attributes, no environment variables.  Every field's non-default side runs one G + D step of the benchmark's geometry (32 -> 256,
     256-channel generator so the 256-row weight-gradient tiles, the fused SPADE kernel and the adjoint data gradient are
     all in play) from the same weights, inputs and device noise, and must reproduce the default path: generated image
     <= 1e-5, losses <= 1e-4, gradients to rounding order (see the tolerance note below)."""
@@ -694,8 +694,9 @@ def test_kernel_path_switches():
     batch = O.synthetic_batch(O.make_opt(**over), 2, seed=77)
     states = O.recipe_state(O.make_opt(**over), gain=1.0)
 
-    def one():
-        tm = TrainerManager(make_opt(**over))
+    def one(**plan):
+        tm = TrainerManager(make_opt(kernel_plan=plan, **over))
+        assert all(getattr(tm.sr_model.plan, k) == v for k, v in plan.items())
         tm.sr_model.load_states(states)
         tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
         torch.cuda.synchronize()
@@ -713,13 +714,9 @@ def test_kernel_path_switches():
     dmax = max(float(v.norm()) for v in ref[3].values())
     report, bad = [], []
     for name, value in SWITCHES:
-        default = getattr(ops, name)
-        assert default != value, name
-        setattr(ops, name, value)
-        try:
-            got = one()
-        finally:
-            setattr(ops, name, default)
+        assert getattr(ops.DEFAULT_PLAN, name) != value, name
+        got = one(**{name: value})       # a model with its own plan: nothing process-wide is touched
+        assert ops.P() is ops.DEFAULT_PLAN
         dev = rel(got[0], ref[0])
         gerr = sorted((float((got[2][k] - v).norm()) / max(float(v.norm()), 1e-2 * gmax), k) for k, v in ref[2].items())
         derr = sorted((float((got[3][k] - v).norm()) / max(float(v.norm()), 1e-2 * dmax), k) for k, v in ref[3].items())

@@ -1,6 +1,7 @@
 import sys, torch
 sys.path.insert(0, ".")
 from deepsee_amd import ops, lib as L
+from tools._plan import use_plan
 def timeit(fn, it=5):
     fn(); fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -10,11 +11,10 @@ def timeit(fn, it=5):
     return s.elapsed_time(e) / it
 for (n, r, c) in [(8, 256, 512), (8, 128, 512), (8, 64, 512), (8, 32, 512)]:
     x = torch.randn(n, r, r, c, device="cuda"); w = torch.randn(c, c, 3, 3, device="cuda") * 0.02
-    ops.WINOGRAD = True
-    ops.GEMM_SPLIT = False
+    use_plan(gemm_split=False)
     tw = timeit(lambda: ops._wino_conv(x, w, n, r, r, c, c, False))
     yf = ops._wino_conv(x, w, n, r, r, c, c, False)
-    ops.GEMM_SPLIT = True
+    use_plan()
     ts = timeit(lambda: ops._wino_conv(x, w, n, r, r, c, c, False))
     ys = ops._wino_conv(x, w, n, r, r, c, c, False)
     print("R=%d: winograd bf16x3 %.3f ms (%.0f TF/s algorithmic) | rel diff vs f32 mfma %.2e" % (r, ts, 2.0 * n * r * r * c * 9 * c / ts / 1e9, ((ys - yf).norm() / yf.norm()).item()))
@@ -29,10 +29,10 @@ for (n, r, c) in [(8, 256, 512), (8, 128, 512), (8, 64, 512), (8, 32, 512)]:
     ops.PROFILE = None
 
     g = torch.randn(n, r, r, c, device="cuda")
-    ops.GEMM_SPLIT = True
+    use_plan()
     tws = timeit(lambda: ops._wino_wgrad(x, g, n, r, r, c, c, c, c))
     a3 = ops._wino_wgrad(x, g, n, r, r, c, c, c, c)
-    ops.GEMM_SPLIT = False
+    use_plan(gemm_split=False)
     tw = timeit(lambda: ops._wino_wgrad(x, g, n, r, r, c, c, c, c))
     td = timeit(lambda: ops.wgrad_raw(x, g, geom, c, c, 3, 3))
     a, b = ops._wino_wgrad(x, g, n, r, r, c, c, c, c), ops.wgrad_raw(x, g, geom, c, c, 3, 3)

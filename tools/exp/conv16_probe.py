@@ -3,6 +3,7 @@ import sys, torch
 import torch.nn.functional as F
 sys.path.insert(0, ".")
 from deepsee_amd import ops, lib as L
+from tools._plan import use_plan
 def timeit(fn, it=6):
     fn(); fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,7 +22,7 @@ for name, n, h, ci, co, k, s, p, ups in cases:
     wp = ops._pack_fwd(w, ci, geom.korder)
     res = {}
     for mode, thr in (("f32", 0.0), ("f16x2", 1.0)):
-        ops.CONV_F16X2_MIN_FLOP = thr
+        use_plan(conv_f16x2_min_flop=thr)
         y = ops.conv_raw(x, wp, geom)
         res[mode] = (y, timeit(lambda: ops.conv_raw(x, wp, geom)))
     xr = x.permute(0, 3, 1, 2).double().cpu()

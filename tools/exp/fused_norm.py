@@ -5,6 +5,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import deepsee_oracle as O
 from deepsee_amd import ops, networks as Nw
+from tools._plan import use_plan
 
 
 def nhwc(x):
@@ -16,7 +17,7 @@ def rel(a, b):
 
 
 def run(kind, C, R, N, fused, grad=True, H=None, max_fm=256):
-    ops.FUSED_NORM = fused
+    use_plan(fused_norm=fused)
     g = torch.Generator().manual_seed(11 + C + R)
     Lc, S = 19, 128
     H = H or max(R, 64)
@@ -43,7 +44,7 @@ def run(kind, C, R, N, fused, grad=True, H=None, max_fm=256):
 
 
 def timeit(kind, C, R, N, fused, grad, reps=5):
-    ops.FUSED_NORM = fused
+    use_plan(fused_norm=fused)
     g = torch.Generator().manual_seed(3)
     Lc, S, H = 19, 128, 256
     label = F.interpolate(torch.randint(0, Lc, (N, 1, 32, 32), generator=g).float(), size=(H, H), mode="nearest")

@@ -2,6 +2,7 @@
 import sys, torch
 sys.path.insert(0, ".")
 from deepsee_amd import ops, lib as L
+from tools._plan import use_plan
 def timeit(fn, it=6):
     fn(); fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -19,7 +20,7 @@ for name, n, h, ci, co, k, s, p, ups in cases:
     x = torch.randn(n, h, h, ci, generator=g).cuda(); dy = torch.randn(n, geom.Ho, geom.Wo, co, generator=g).cuda()
     res = {}
     for mode, thr in (("f32", 0.0), ("f16x2", 1.0)):
-        ops.CONV_F16X2_MIN_FLOP = thr
+        use_plan(conv_f16x2_min_flop=thr)
         dw = ops.wgrad_raw(x, dy, geom, co, ci, k, k)
         res[mode] = (dw, timeit(lambda: ops.wgrad_raw(x, dy, geom, co, ci, k, k)))
     fl = ops._flops(geom)
