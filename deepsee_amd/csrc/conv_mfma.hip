@@ -1574,7 +1574,10 @@ int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t 
     // split == 3: the same with two-term fp16 splits (3 MFMA products), operand scales from max |dM|, max |V|
     // split == 5: V is the pre-split V2 of the forward pass (dsee_wino43_input_f16x2, bound DSEE_WINO_V_BOUND), amax_v = max |x|
     // split == 6: dM is pre-split as well (dsee_wino43_dout_f16x2, bound DSEE_WINO_DM_BOUND), amax_dm = max |dY|
-    int rc = split == 6   ? dsee_gemm_f16x2_tn_pqpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm,
+    // split == 7: 16-bit storage mode -- both operands packed one-term (dsee_wino43_dout_f16p / dsee_wino43_input_f16p)
+    int rc = split == 7   ? dsee_gemm_f16p_tn_pqpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm,
+                                                    DSEE_WINO_DM_BOUND, amax_v, DSEE_WINO_V_BOUND, st)
+             : split == 6 ? dsee_gemm_f16x2_tn_pqpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm,
                                                      DSEE_WINO_DM_BOUND, amax_v, DSEE_WINO_V_BOUND, st)
              : split == 5 ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36, T, Cout_s, Cin_s, Kpad, sper, amax_dm, amax_v,
                                                     DSEE_WINO_V_BOUND, st)
@@ -1621,7 +1624,9 @@ int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, s
   if (split) {
     DSEE_CHECK_ARG(rows % 128 == 0);
     const int sper = wino_sper(T / N, ld, rows, N), Kpad = dsee_conv_kpad(1, 1, ld);
-    int rc = split == 6   ? dsee_gemm_f16x2_tn_pqpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm,
+    int rc = split == 7   ? dsee_gemm_f16p_tn_pqpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm,
+                                                    DSEE_WINO_DM_BOUND, amax_v, DSEE_WINO_V_BOUND, st)
+             : split == 6 ? dsee_gemm_f16x2_tn_pqpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm,
                                                      DSEE_WINO_DM_BOUND, amax_v, DSEE_WINO_V_BOUND, st)
              : split == 5 ? dsee_gemm_f16x2_tn_qpre(dM, V, workspace, 36 * N, T / N, rows, ld, Kpad, sper, amax_dm, amax_v,
                                                     DSEE_WINO_V_BOUND, st)

@@ -150,3 +150,23 @@ __device__ __forceinline__ float dsee_amax_read(const float* amax) {
 __device__ __forceinline__ float dsee_absmax4(const f32x4& v) {
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
+
+// ---- packed one-term fp16 image of the 16-bit storage mode (gemm_bf16x3.hip): a lane holds 4 channels = 8 bytes per transform
+// position; the lanes of a pair (adjacent channel quads of one 32-channel slab) exchange halves across a PAIR of positions -- the
+// even lane writes 16 bytes of position xi0 (its own quad + the partner's), the odd lane 16 bytes of position xi0 + 1 -- so that
+// every store is 16 bytes and a (tile, slab, position) row is written whole.
+typedef unsigned dsee_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned dsee_pk2h(float a, float b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+}
+// o0 / o1 = this lane's 4 channels at positions xi0 / xi0 + 1 (already scaled); row_xi0 = the pair's 16-byte chunk in the row
+// of position xi0, pos_bytes = distance between the rows of consecutive positions
+__device__ __forceinline__ void dsee_store_pk_pair(unsigned char* row_xi0, size_t pos_bytes, bool odd, const f32x4& o0,
+                                                   const f32x4& o1) {
+  const unsigned a0 = dsee_pk2h(o0[0], o0[1]), a1 = dsee_pk2h(o0[2], o0[3]), b0 = dsee_pk2h(o1[0], o1[1]), b1 = dsee_pk2h(o1[2], o1[3]);
+  const unsigned s0 = odd ? a0 : b0, s1 = odd ? a1 : b1;      // what the partner stores: the even lane's xi0 + 1, the odd lane's xi0
+  const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
+  const dsee_u32x4 wv = odd ? (dsee_u32x4){r0, r1, b0, b1} : (dsee_u32x4){a0, a1, r0, r1};
+  __builtin_nontemporal_store(wv, reinterpret_cast<dsee_u32x4*>(row_xi0 + (odd ? pos_bytes : 0)));
+}

@@ -50,6 +50,7 @@ struct Gemm3Args {
   // pre-split fp16x2 A (NT form) / Q (TN form) operands: the producer scaled them with dsee_pow2_scale(bound * *amax) where
   // bound * max|x| >= max|operand| is known BEFORE the producer runs (dsee_wino43_input_f16x2: bound = 100)
   float a_bound, b_bound;
+  int k_real;   // packed one-term operands (PK): the reduction length in elements (K counts 16-k slabs of 64-byte rows, i.e. K = k_real / 2)
 };
 
 // force a value the compiler cannot prove wave-uniform into SGPRs (buffer resources / M0 must be scalar; without this
@@ -172,6 +173,24 @@ __device__ __forceinline__ void mfma_product(int q, const u32x4 (&af)[TERMS], co
 }
 template <int TERMS>
 constexpr int products() { return TERMS == 3 ? 6 : (TERMS == 2 ? 3 : 1); }
+
+// ---------------------------------------------------------------- packed one-term fp16 (PK): the 16-bit storage mode
+// BASELINE configs[2]'s 16-bit arithmetic with 16-bit STORAGE of the Winograd-domain operands: ONE scaled fp16 term per
+// element, written by the producers into the SAME 64-byte-row image the fp16x2 kernels stream -- a row holds 32 consecutive
+// k's of one term ([K/32][rows][32] fp16) where the two-term form holds 2 terms x 16 k's ([K/16][rows][2][16]).  The DMA
+// requests, the LDS image and the fragment reads of the pre-split kernels are unchanged; a "slab" now carries 32 k's and
+// the two 16-byte chunks a lane used to read as (term 0, term 1) are (k's 0-15, k's 16-31): two products a0*b0 + a1*b1
+// instead of three, half the bytes per element, K/32 slabs instead of K/16.
+template <bool PK>
+constexpr int products2() { return PK ? 2 : 3; }
+template <bool PK>
+__device__ __forceinline__ void mfma_product2(int q, const u32x4 (&af)[2], const u32x4 (&bf)[2], f32x16& acc) {
+  if constexpr (PK) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[q]), __builtin_bit_cast(f16x8, bf[q]), acc, 0, 0, 0);
+  } else {
+    mfma_product<2>(q, af, bf, acc);
+  }
+}
 
 // ---------------------------------------------------------------- pre-split operands, direct to LDS
 // FL > 0: two-level accumulation -- the MFMA chain runs over FL slabs into `acc`, which is then folded into `tot`
@@ -373,13 +392,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3g_ke
 // 3 x 8 bf16 -> the same 6r + c + (r>>4) slot layout the fragments are read from.  B (weights) stays pre-split.
 // APRE: the A operand arrives PRE-SPLIT from its producer (fp16x2 rows [K/16][M][2][16], dsee_wino43_input_f16x2) and
 // travels exactly like B -- LDS-DMA straight into a ring of three split images, no fp32 staging, no conversion pass.
-template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false, bool APRE = false>
+template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false, bool APRE = false, bool PK = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   static_assert(BM / 16 == 2 * NW, "two fp32 A instructions (16 rows each) per wave");
   static_assert(!APRE || (TERMS == 2 && NW == 8), "pre-split A: fp16x2, ping-pong form only");
+  static_assert(!PK || APRE, "packed one-term operands arrive pre-split");
   constexpr int SA = I::slots(BM), SB = I::slots(BN);
   constexpr int NB = (SB + 63) / 64;
   constexpr int NIB = (NB + NW - 1) / NW;                // B instructions per wave per slab (last maybe absent)
@@ -418,7 +438,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
   if constexpr (C16) {
     // the product leaves the kernel as fp16: |C| <= K max|A| max|B| is mapped below 2^15 (no overflow, ~2^8 of headroom
     // over typical values); the consumer multiplies by *cscale (the inverse, a power of two)
-    const float sm = 2.f * pow2_scale((float)a.K * dsee_amax_read(a.amax_a) * dsee_amax_read(a.amax_b));
+    const float sm = 2.f * pow2_scale((float)(PK ? a.k_real : a.K) * (APRE ? a.a_bound : 1.f) * dsee_amax_read(a.amax_a) *
+                                      dsee_amax_read(a.amax_b));
     oscale *= sm;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.cscale = 1.f / sm;
   }
@@ -611,6 +632,21 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
+        if constexpr (C16 && PK) {
+          // fp16 product, two columns per store: lanes (n, n + 1) exchange one value per row pair through DPP -- the even lane
+          // writes (row r: columns n, n + 1), the odd lane (row r + 1: columns n - 1, n) -- 8 dword stores per accumulator
+          // tile instead of 16 two-byte stores (N is a multiple of 128 here: no column tail)
+          const bool odd = (lane & 1) != 0;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const unsigned h0 = __builtin_bit_cast(unsigned short, (_Float16)(acc[i][j][r] * oscale));
+            const unsigned h1 = __builtin_bit_cast(unsigned short, (_Float16)(acc[i][j][r + 1] * oscale));
+            const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h0 : h1), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            const unsigned w = odd ? (got | (h1 << 16)) : (h0 | (got << 16));
+            const long row = mb + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
+            *reinterpret_cast<unsigned*>(reinterpret_cast<_Float16*>(cz) + row * a.ldc + (n & ~1)) = w;
+          }
+        } else
         if (n < a.N && (!(DSEE_GEMM_ABL & 16) || acc[i][j][0] == 12345.678f))
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -708,11 +744,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
             for (int p = 0; p < TERMS; ++p) acc[i][j][p] += __builtin_bit_cast(float, af[i][p][0] ^ bf[j][p][1]);
       } else {
 #pragma unroll
-        for (int q = 0; q < products<TERMS>(); ++q)   // product-major: 8 independent accumulators between reuses
+        for (int q = 0; q < (PK ? 2 : products<TERMS>()); ++q)   // product-major: 8 independent accumulators between reuses
 #pragma unroll
           for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) mfma_product<TERMS>(q, af[i], bf[j], acc[i][j]);
+            for (int i = 0; i < MT; ++i) {
+              if constexpr (PK) mfma_product2<true>(q, af[i], bf[j], acc[i][j]);
+              else mfma_product<TERMS>(q, af[i], bf[j], acc[i][j]);
+            }
       }
       __builtin_amdgcn_s_setprio(0);
       par ^= 1;
@@ -803,7 +842,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm3a_ke
 // Three raw stages (a slab is read during the iteration that requests the slab two ahead).
 // PPRE (with QPRE): P = dM2 pre-split by dsee_wino43_dout_f16x2 in the same image -- both operands then go global -> LDS ->
 // transpose read -> MFMA, the kernel converts nothing.
-template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false, bool PPRE = false>
+template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false, bool PPRE = false, bool PK = false>
 __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using I = Img<TERMS>;
@@ -811,16 +850,23 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   static_assert(BM == 32 * NW, "every wave owns 32 rows of the P tile");
   static_assert(!QPRE || (TERMS == 2 && BN % 32 == 0), "pre-split Q: fp16x2");
   static_assert(!PPRE || QPRE, "pre-split P comes with pre-split Q");
+  // PK: packed one-term operands (16-bit storage mode): a 64-byte row of the image holds 32 channels of ONE term, so a 32-column
+  // MFMA tile is one channel slab (1 KB per 16 tiles) instead of two, and a product is one MFMA
+  static_assert(!PK || (PPRE && TERMS == 2 && NW == 8), "packed one-term operands: both pre-split, ping-pong form");
+  constexpr int SCH = PK ? 32 : 16;                 // channels per slab of a pre-split image
+  constexpr int NF = PK ? 1 : TERMS;                // 16-byte fragment chunks per operand tile and slab
   constexpr int RB = BN / NW;                       // Q rows (channels) owned by a wave
   static_assert(BN % NW == 0 && RB % 4 == 0 && 2 * RB <= 64, "Q rows per wave");
   constexpr int QCH = RB / 4;                       // 16-byte chunks per tile row of a wave's Q piece
-  constexpr int QS = BN / 16;                       // QPRE: channel slabs of the tile = DMA instructions per slab and block
+  constexpr int QS = BN / SCH;                      // QPRE: channel slabs of the tile = DMA instructions per slab and block
   constexpr int QI = QPRE ? (QS + NW - 1) / NW : (16 * QCH + 63) / 64;   // Q DMA instructions per wave per slab
   constexpr int SA = I::slots(BM), SB = I::slots(BN);
   constexpr int IMGA = PPRE ? 0 : (SA * 16 + 255) / 256 * 256, IMGB = QPRE ? 0 : (SB * 16 + 255) / 256 * 256;
   // bytes of one stage of P (fp32: two stages; PPRE: raw split rows of BM/16 channel slabs, three stages), of one Q stage
   // (QPRE: raw split rows, three stages; else fp32, two stages)
-  constexpr int FA = PPRE ? (BM / 16) * 1024 : NW * 2048, FB = QPRE ? QS * 1024 : NW * QI * 1024;
+  constexpr int PI = PPRE ? (BM / SCH) / NW : 2;    // P DMA instructions per wave per slab
+  constexpr int TILEB = PK ? 1024 : 2048;           // bytes of a 32-column MFMA tile in a raw pre-split stage
+  constexpr int FA = PPRE ? (BM / SCH) * 1024 : NW * 2048, FB = QPRE ? QS * 1024 : NW * QI * 1024;
   constexpr int OFF_FB = (PPRE ? 3 : 2) * FA, OFF_IA = OFF_FB + (QPRE ? 3 : 2) * FB, OFF_IB = OFF_IA + 2 * IMGA;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -871,9 +917,9 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     if constexpr (PPRE) {
       // instruction jj of this wave: channel slab bm * (BM/16) + wave + NW * jj of dM2, the slab's 16 tile rows
       // (the tile's first slab goes into the 64-bit base: with 1 024 gamma/beta rows the slabs span more than 4 GB)
-      pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * (BM / 16) * a.a_group_bytes);
+      pa = uniform_ptr(a.A + z * a.a_z_bytes + bm * (BM / SCH) * a.a_group_bytes);
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
+      for (int jj = 0; jj < PI; ++jj)
         voffa[jj] = (unsigned)((unsigned long)(wave + NW * jj) * (unsigned long)a.a_group_bytes) + lane * 16;
       live_bytes_a = __builtin_amdgcn_readfirstlane(live ? (int)0xFFFFFFF0u : 0);
     } else {
@@ -899,7 +945,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
     __amdgpu_buffer_rsrc_t rb =
         __builtin_amdgcn_make_buffer_rsrc((void*)(pb + lk * a.b_slab_bytes), 0, live_bytes_b, 0x00020000);
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < PI; ++jj) {
       auto* dst = PPRE ? (__attribute__((address_space(3))) void*)(smem + qnxt * FA + (wave + NW * jj) * 1024)
                        : (__attribute__((address_space(3))) void*)(smem + fs * FA + wave * 2048 + jj * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, voffa[jj], 0, 0, 0);
@@ -980,13 +1026,14 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
   // everything but this wave's instructions of the youngest requested slab has landed
   auto wait_slab = [&]() {
     if (!QPRE || has_last_q)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI + QI) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + QI - 1) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI + QI - 1) : "memory");
   };
   // QPRE: this lane's part of a transpose read -- tile row 8 * (lane >> 5) + ((lane & 15) >> 2) (+ 4 for the second read) of
   // the slab, channel slab (lane >> 4) & 1 of the 32-column MFMA tile, channels 4 * (lane & 3) .. + 3 of it
-  const unsigned qfrag = (unsigned)(((lane >> 4) & 1) * 1024 + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (lane & 3) * 8);
+  // (PK: the two 16-channel halves of the tile are the two halves of one 64-byte row)
+  const unsigned qfrag = (unsigned)(((lane >> 4) & 1) * (PK ? 32 : 1024) + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (lane & 3) * 8);
   load_base();
   issue(0);
   issue(1);
@@ -1021,14 +1068,14 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int p = 0; p < TERMS; ++p) {
-          if constexpr (PPRE) af[i][p] = trf(sa_ + (wm * MT + i) * 2048 + qfrag + p * 32);
+        for (int p = 0; p < NF; ++p) {
+          if constexpr (PPRE) af[i][p] = trf(sa_ + (wm * MT + i) * TILEB + qfrag + p * 32);
           else af[i][p] = *reinterpret_cast<const u32x4*>(sa_ + fa + i * TSTEP + p * 32);
         }
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int p = 0; p < TERMS; ++p) bf[j][p] = trf(sb + (wn * NT + j) * 2048 + qfrag + p * 32);
+        for (int p = 0; p < NF; ++p) bf[j][p] = trf(sb + (wn * NT + j) * TILEB + qfrag + p * 32);
       __builtin_amdgcn_sched_barrier(0);
       issue(par);    // slab k+2 (fp32 P: into the stage this wave converted in its previous L interval)
       __builtin_amdgcn_sched_barrier(0);
@@ -1043,11 +1090,16 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm3t_kernel(Gemm3Args a) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int q = 0; q < products<TERMS>(); ++q)
+      for (int q = 0; q < (PK ? 1 : products<TERMS>()); ++q)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int i = 0; i < MT; ++i) mfma_product<TERMS>(q, af[i], bf[j], acc[i][j]);
+          for (int i = 0; i < MT; ++i) {
+            if constexpr (PK)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]),
+                                                                 __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
+            else mfma_product<TERMS>(q, af[i], bf[j], acc[i][j]);
+          }
       __builtin_amdgcn_s_setprio(0);
       qcur = qcur == 2 ? 0 : qcur + 1;
       ++ck;
@@ -1215,7 +1267,7 @@ int launch_gemm3(Gemm3Args a, int nz, hipStream_t st) {
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false, bool APRE = false>
+template <int WM, int WN, int MT, int NT, int TERMS, bool C16 = false, bool APRE = false, bool PK = false>
 int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -1225,36 +1277,36 @@ int launch_gemm3a(const Gemm3Args& a, hipStream_t st) {
                           : (size_t)(TERMS == 2 ? 3 : 2) * BM * 64 + 2 * IMG + (size_t)3 * NB * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS, C16, APRE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3a_kernel<WM, WN, MT, NT, TERMS, C16, APRE, PK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const long ntile = (a.M / BM) * ((a.N + BN - 1) / BN);
   const long slots = (long)gemm3_num_cus() * (WM * WN == 4 ? 2 : 1);
-  gemm3a_kernel<WM, WN, MT, NT, TERMS, C16, APRE><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
+  gemm3a_kernel<WM, WN, MT, NT, TERMS, C16, APRE, PK><<<(unsigned)(ntile < slots ? ntile : slots), WM * WN * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false, bool PPRE = false>
+template <int WM, int WN, int MT, int NT, int FL, int TERMS, bool QPRE = false, bool PPRE = false, bool PK = false>
 int launch_gemm3t(Gemm3Args a, int nz, hipStream_t st) {
   using I = Img<TERMS>;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NW = WM * WN;
   constexpr int QI = (16 * (BN / NW / 4) + 63) / 64;
   constexpr int IMGA = (I::slots(BM) * 16 + 255) / 256 * 256, IMGB = (I::slots(BN) * 16 + 255) / 256 * 256;
-  const size_t lds = PPRE ? (size_t)3 * (BM / 16 + BN / 16) * 1024
+  const size_t lds = PPRE ? (size_t)3 * (BM / 16 + BN / 16) * 1024 / (PK ? 2 : 1)
                      : QPRE ? (size_t)2 * NW * 2048 + (size_t)3 * (BN / 16) * 1024 + 2 * IMGA
                           : (size_t)2 * NW * 2048 + (size_t)2 * NW * QI * 1024 + 2 * IMGA + 2 * IMGB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE, PPRE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE, PPRE, PK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   a.nz = nz;
   const long ntile = (a.M / BM) * (a.N / BN) * nz;
   const long slots = gemm3_num_cus();
-  gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE, PPRE><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
+  gemm3t_kernel<WM, WN, MT, NT, FL, TERMS, QPRE, PPRE, PK><<<(unsigned)(ntile < slots ? ntile : slots), NW * 64, lds, st>>>(a);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1390,6 +1442,25 @@ int dsee_gemm_f16x2_pre(const void* A2, const void* B2, float* C, long M, int N,
   return launch_gemm3a<2, 4, 4, 2, 2, false, true>(a, st);
 }
 
+/* 16-bit storage mode (opt.precision = "fp16"; BASELINE configs[2]): the same GEMM on PACKED ONE-TERM operands -- A1
+ * [K/32][M][32] fp16 = dsee_wino43_input_f16p's output (scale dsee_pow2_scale(a_bound * *amax_a)), B1 [groups][K/32][b_rows][32]
+ * fp16 = dsee_wino43_weights[_table](split = 4) (scale of *amax_b) -- one MFMA product per multiply-add, fp32 accumulate, and the
+ * product written as scaled fp16 C16 [M][N] (power-of-two scale from the bound K a_bound max|x| max|B|; its inverse goes to
+ * *cscale for the consumer).  Same 64-byte-row image, LDS-DMA stream and tiles as dsee_gemm_f16x2_pre.  K % 32 == 0. */
+int dsee_gemm_f16p_pre(const void* A1, const void* B1, void* C16, long M, int N, int K, long rows_per_group, int b_rows,
+                       const float* amax_a, float a_bound, const float* amax_b, float* cscale, hipStream_t st) {
+  DSEE_CHECK_ARG(A1 && B1 && C16 && amax_a && amax_b && cscale && a_bound > 0.f && M > 0 && N > 0 && K > 0 && K % 32 == 0);
+  DSEE_CHECK_ARG(rows_per_group % 256 == 0 && M % rows_per_group == 0 && N % 128 == 0 && b_rows >= N);
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)A1; a.B = (const unsigned char*)B1; a.C = (float*)C16;
+  a.amax_a = amax_a; a.amax_b = amax_b; a.a_bound = a_bound; a.cscale = cscale;
+  a.M = M; a.N = N; a.K = K / 2; a.k_real = K; a.ldc = N; a.rows_per_group = rows_per_group;
+  a.a_slab_bytes = M * 64;
+  a.b_group_bytes = (long)b_rows * K * 2; a.b_slab_bytes = (long)b_rows * 64; a.nz = 1;
+  if (N % 256) return launch_gemm3a<2, 4, 4, 1, 2, true, true, true>(a, st);
+  return launch_gemm3a<2, 4, 4, 2, 2, true, true, true>(a, st);
+}
+
 /* dsee_gemm_bf16x3_tn with both operands left in fp32: P [groups*T][rows_p], Q [groups*T][rows_q] fp32 row-major (the
  * plain outputs of dsee_wino43_dout / dsee_wino43_input), transposed and split inside the kernel.
  * rows_p % 256 == 0 and rows_q == 160 or rows_q % 128 == 0; returns DSEE_EINVAL otherwise (use the pre-split form). */
@@ -1517,6 +1588,30 @@ int dsee_gemm_f16x2_tn_pqpre(const void* P2, const void* Q2, float* C, int group
   if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 2, true, true>(a, groups * splits, st);
   if (rows_q % 256 == 0) return launch_gemm3t<2, 4, 4, 2, 0, 2, true, true>(a, groups * splits, st);
   return launch_gemm3t<4, 2, 2, 2, 16, 2, true, true>(a, groups * splits, st);
+}
+
+/* 16-bit storage mode: the weight-gradient product on PACKED ONE-TERM operands -- P1 = dsee_wino43_dout_f16p's dM1
+ * [rows_p/32][groups*T][32] fp16 (scale of p_bound x *amax_dy), Q1 = dsee_wino43_input_f16p's V1 [rows_q/32][groups*T][32] --
+ * one MFMA product per multiply-add, fp32 accumulate, fp32 output.  rows_p % 256 == 0, rows_q == 160 or % 128 == 0. */
+int dsee_gemm_f16p_tn_pqpre(const void* P1, const void* Q1, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                            int splits, const float* amax_dy, float p_bound, const float* amax_x, float q_bound,
+                            hipStream_t st) {
+  DSEE_CHECK_ARG(P1 && Q1 && C && amax_dy && amax_x && p_bound > 0.f && q_bound > 0.f && groups > 0 && T % 16 == 0);
+  DSEE_CHECK_ARG(rows_p % 256 == 0 && splits > 0 && (T / 16) % splits == 0 && ldc >= rows_q);
+  DSEE_CHECK_ARG(rows_q == 160 || rows_q % 128 == 0);
+  DSEE_CHECK_ARG((long)8 * groups * T * 64 < 0xFFFFFFF0L);   // the 8 channel slabs of a 256-wide tile from one 64-bit base
+  Gemm3Args a = {};
+  a.A = (const unsigned char*)P1; a.B = (const unsigned char*)Q1; a.C = C;
+  a.amax_a = amax_dy; a.amax_b = amax_x; a.a_bound = p_bound; a.b_bound = q_bound;
+  const long nk = T / 16 / splits;
+  a.M = rows_p; a.N = rows_q; a.K = (int)(nk * 16); a.ldc = ldc; a.rows_per_group = rows_p;
+  a.c_z_elems = (long)rows_p * ldc;
+  a.a_slab_bytes = a.b_slab_bytes = 16 * 64;
+  a.a_z_bytes = a.b_z_bytes = nk * 1024;
+  a.a_group_bytes = a.b_group_bytes = (long)groups * T * 64;
+  if (rows_q == 160) return launch_gemm3t<8, 1, 1, 5, 16, 2, true, true, true>(a, groups * splits, st);
+  if (rows_q % 256 == 0) return launch_gemm3t<2, 4, 4, 2, 0, 2, true, true, true>(a, groups * splits, st);
+  return launch_gemm3t<4, 2, 2, 2, 16, 2, true, true, true>(a, groups * splits, st);
 }
 
 }  // extern "C"

@@ -409,6 +409,33 @@ __device__ __forceinline__ void store_ata_split(const f32x4 (&v)[4][4], unsigned
   }
 }
 
+// ... and into the PACKED ONE-TERM image dM1 [rows/32][36*T][32] fp16 of the 16-bit storage mode (one scaled fp16 term per
+// element; lane pairs exchange halves across pairs of positions, dsee_common.h)
+__device__ __forceinline__ void store_ata_pk(const f32x4 (&v)[4][4], unsigned char* __restrict__ dM1, long T, long t, int col,
+                                             float sc, int l) {
+  f32x4 tmp[6][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 c4[4], o[6];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c4[k] = v[k][j];
+    a6n(c4, o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
+  }
+  const bool odd = (l & 1) != 0;
+  const size_t slab = (size_t)36 * T * 64;
+  unsigned char* rowp = dM1 + (size_t)(col >> 5) * slab + (size_t)t * 64 + (((col & 31) >> 2) & ~1) * 8;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    f32x4 o[6];
+    a6n(tmp[k], o);
+#pragma unroll
+    for (int j = 0; j < 6; j += 2)
+      dsee_store_pk_pair(rowp + (size_t)(k * 6 + j) * T * 64, (size_t)T * 64, odd, o[j] * sc, o[j + 1] * sc);
+  }
+}
+
 // Pass 1 of the BN + modulate + LeakyReLU backward with the gamma/beta gradient written straight in the Winograd
 // domain: dM[xi][tile][packed gamma col] = (A (g*xhat) A^T)[xi], [packed beta col] = (A g A^T)[xi] -- the operand of the
 // weight / table gradient AND (adjoint form) of the embedding's data gradient; the [M][2C] tensor dgb and the separate
@@ -479,6 +506,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_kernel(
 // would scatter 64-byte rows: 2.66 vs 2.2 ms at N = 8, 256^2, C = 512).  A wave keeps its 64 channels for its whole loop
 // (gridDim.x * 4 is a multiple of C/64); the per-channel sums are folded over the wave's 4 tile lanes and written as
 // part[global wave][4][64], summed per channel group in wave order by norm_bwd_split_sums_kernel.
+template <bool PK>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_split_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -520,8 +548,13 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_split_kernel(
         acc[2] += gx[k][j];
         acc[3] += g;
       }
-    store_ata_split(gx, dM2, T, t, pcol, sc, l);
-    store_ata_split(gg, dM2, T, t, pcol + 32, sc, l);
+    if constexpr (PK) {
+      store_ata_pk(gx, dM2, T, t, pcol, sc, l);
+      store_ata_pk(gg, dM2, T, t, pcol + 32, sc, l);
+    } else {
+      store_ata_split(gx, dM2, T, t, pcol, sc, l);
+      store_ata_split(gg, dM2, T, t, pcol + 32, sc, l);
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -788,10 +821,10 @@ int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* 
   return DSEE_OK;
 }
 
-/* ... with dM written PRE-SPLIT: dM2 [rows/16][36*T][2][16] fp16 scaled by the power of two of bound x *amax_g, where
- * *amax_g >= max |dh| * max(1, max |xhat|) is known before the kernel runs (dsee_amax_product of the maxima the producers of dh
- * and of the forward pass wrote) and bound >= DSEE_WINO_DM_BOUND.  T % 16 == 0. */
-int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const float* x, const float* scale,
+}  // extern "C"
+
+template <bool PK>
+static int reduce_wino_split_launch(const float* dh, const float* h, const float* x, const float* scale,
                                         const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
                                         int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
                                         hipStream_t st) {
@@ -803,13 +836,37 @@ int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const f
   int blocks = wino_reduce_blocks(N, H, W, C) / m * m;
   if (blocks < m) blocks = m;
   DSEE_CHECK_ARG(blocks <= wino_reduce_blocks(N, H, W, C) || blocks == m);
-  norm_bwd_reduce_wino_split_kernel<<<blocks, 256, 0, st>>>(dh, h, x, scale, mean, invstd,
+  norm_bwd_reduce_wino_split_kernel<PK><<<blocks, 256, 0, st>>>(dh, h, x, scale, mean, invstd,
                                                             reinterpret_cast<unsigned char*>(dM2), workspace, N, H, W, C, slope,
                                                             amax_g, bound);
   DSEE_LAUNCH_CHECK();
   norm_bwd_split_sums_kernel<<<dim3(dsee_cdiv(C, 8), 4), 256, 0, st>>>(workspace, blocks * 4, C, sums);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
+}
+
+
+extern "C" {
+
+/* ... with dM written PRE-SPLIT: dM2 [rows/16][36*T][2][16] fp16 scaled by the power of two of bound x *amax_g, where
+ * *amax_g >= max |dh| * max(1, max |xhat|) is known before the kernel runs (dsee_amax_product of the maxima the producers of dh
+ * and of the forward pass wrote) and bound >= DSEE_WINO_DM_BOUND.  T % 16 == 0. */
+int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const float* x, const float* scale,
+                                        const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
+                                        int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
+                                        hipStream_t st) {
+  return reduce_wino_split_launch<false>(dh, h, x, scale, mean, invstd, dM2, rows, sums, N, H, W, C, slope, workspace, amax_g,
+                                         bound, st);
+}
+
+/* 16-bit storage mode: the same pass writing dM as the PACKED ONE-TERM operand dM1 [rows/32][36*T][32] fp16 (consumers:
+ * dsee_wino43_wgrad[_table] split = 7, dsee_gemm_f16p_pre) */
+int dsee_modulate_bwd_reduce_wino_f16p(const float* dh, const float* h, const float* x, const float* scale,
+                                       const float* mean, const float* invstd, void* dM1, int rows, float* sums, int N,
+                                       int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
+                                       hipStream_t st) {
+  return reduce_wino_split_launch<true>(dh, h, x, scale, mean, invstd, dM1, rows, sums, N, H, W, C, slope, workspace, amax_g,
+                                        bound, st);
 }
 
 /* out (64-line slot, zeroed by the caller) <- max(a) * max(floor_b, max(b)): the operand bound of a product of two tensors */

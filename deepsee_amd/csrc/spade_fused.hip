@@ -87,12 +87,17 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
   return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
 }
 
-template <int NP, bool WSCALE>
+// PK (16-bit storage mode, opt.precision = "fp16"): the operands are PACKED ONE-TERM images ([K/32][rows][32] fp16: the same
+// 64-byte rows holding 32 k's of one scaled fp16 term, gemm_bf16x3.hip) -- a piece is then 64 k's (its two "term" halves are
+// k's 0-31 and 32-63), a position NP = 2 (K = 128) or 3 (K = 160: the last piece half empty, fetched as zeros) pieces, and a
+// piece costs 2 MFMA products per block instead of 3.  Ring, fragment reads, fold and epilogue are unchanged.
+template <int NP, bool WSCALE, bool PK = false>
 __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int PIECE = 8192;                  // 32 k's of one operand: 64 rows x (2 terms x 4 octets x 16 B)
+  constexpr int PIECE = 8192;                  // 32 k's of one operand: 64 rows x (2 terms x 4 octets x 16 B)   [PK: 64 k's]
   constexpr int UREG = 2 * NP * PIECE;         // LDS: [2 NP pieces of U][2 NP pieces of V]; piece (par, k) in slot par * NP + k
-  static_assert(NP == 4 || NP == 5, "K = 128 or 160");
+  static_assert(PK ? (NP == 2 || NP == 3) : (NP == 4 || NP == 5), "K = 128 or 160");
+  constexpr bool HALF_LAST = PK && NP == 3;    // K = 160 = 2.5 pieces of 64 k's
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * POSB (>= 64 KB for the epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,11 +135,16 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 
   // ---- LDS-DMA: wave w fills rows 8w .. 8w+7 of every piece (64 slots); lane -> (row 8w + l/8, slot chunk l%8) fetches
   //      chunk cc = (l%8) ^ f(row) = 4 term + octet: bytes (2 term + octet%2) * 16 of the row in 16-k slab 2 piece + octet/2.
+  //      PK: chunk cc = 4 half + octet = k's 8 cc .. 8 cc + 7 of the 64-k piece: bytes (cc % 4) * 16 of the row in 32-k slab
+  //      2 piece + cc / 4.
   const int dr = 8 * wave + (lane >> 3);
   const int dcc = (lane & 7) ^ ((dr >> 1) & 7);
-  const unsigned dlo = (unsigned)(dr * 64 + (2 * (dcc >> 2) + (dcc & 1)) * 16);
-  const unsigned voffu = dlo + (unsigned)((dcc >> 1) & 1) * (unsigned)a.u_slab_bytes;
-  const unsigned voffv = dlo + (unsigned)((dcc >> 1) & 1) * (unsigned)a.v_slab_bytes;
+  const int dslab = PK ? (dcc >> 2) : ((dcc >> 1) & 1);   // which of the piece's two slabs this lane reads
+  const unsigned dlo = PK ? (unsigned)(dr * 64 + (dcc & 3) * 16) : (unsigned)(dr * 64 + (2 * (dcc >> 2) + (dcc & 1)) * 16);
+  const unsigned voffu = dlo + (unsigned)dslab * (unsigned)a.u_slab_bytes;
+  const unsigned voffv = dlo + (unsigned)dslab * (unsigned)a.v_slab_bytes;
+  // the half-empty last piece: its second slab does not exist -- out-of-range offsets make the buffer loads return zeros
+  const unsigned voffu_l = dslab ? 0xFFFFFFF0u : voffu, voffv_l = dslab ? 0xFFFFFFF0u : voffv;
   const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(a.U2), 0, (int)a.u_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(a.V2), 0, (int)a.v_bytes, 0x00020000);
   const unsigned PU = (unsigned)(a.G * a.u_group_bytes), PV = (unsigned)(a.T * 64);       // per position
@@ -143,11 +153,13 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   // piece pc of position pos (ring half par): one U and one V instruction per wave
   auto dma_u = [&](int par, int pc, unsigned opos) {
     unsigned char* dst = smem + (par * NP + pc) * PIECE + wave * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void*)dst, 16, voffu, opos + pc * QU, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void*)dst, 16,
+                                             (HALF_LAST && pc == NP - 1) ? voffu_l : voffu, opos + pc * QU, 0, 0);
   };
   auto dma_v = [&](int par, int pc, unsigned opos) {
     unsigned char* dst = smem + UREG + (par * NP + pc) * PIECE + wave * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)dst, 16, voffv, opos + pc * QV, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)dst, 16,
+                                             (HALF_LAST && pc == NP - 1) ? voffv_l : voffv, opos + pc * QV, 0, 0);
   };
 
   // ---- fragment addresses (bytes within a piece): row r, chunk 4 term + octet at slot 8r + (chunk ^ f(r)).
@@ -187,6 +199,11 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     if constexpr (DSEE_FUSED_ABL & 1) {
       pg[0] += (float)(g1[0] + v0[1]) + (float)(g0[2] + v1[3]);
       pb[1] += (float)(b1[0] + v0[1]) + (float)(b0[2] + v1[3]);
+    } else if constexpr (PK) {   // one term: the two chunk groups are k's 0-31 and 32-63 of the piece
+      pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, v0, pg, 0, 0, 0);
+      pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, v0, pb, 0, 0, 0);
+      pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, v1, pg, 0, 0, 0);
+      pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, v1, pb, 0, 0, 0);
     } else {
       pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, v0, pg, 0, 0, 0);
       pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, v0, pb, 0, 0, 0);
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   // ---- ring: 2 NP pieces (two positions), piece (pos, k) in slot (pos & 1) * NP + k.  A position is two stages (pieces
   //      [0, NA) and [NA, NP)), one barrier each; the requests of stage s + 3 are issued during stage s into the slots of
   //      stage s - 1 (dead: every wave consumed those fragments before it arrived at the barrier that opens s).
-  constexpr int NA = 2;
+  constexpr int NA = NP == 2 ? 1 : 2;
   auto issue_stage = [&](int pos, int half) {   // prologue only (run-time indices)
     for (int k = half ? NA : 0; k < (half ? NP : NA); ++k) {
       dma_u(pos & 1, k, base_u + pos * PU);
@@ -536,10 +553,12 @@ void dsee_fused_set_stamps(float* p) { g_fused_stamps = p; }
 
 /* The fused SPADE / SEAN normalisation forward (see the head of this file).  V2 = dsee_wino43_input_f16x2(cat, amax_cat,
  * v_bound), U2 = dsee_wino43_weights[_table](..., split = 2, amax_u); groups = images with per-image tables, else 1. */
-int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
-                         const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
-                         float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                         float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
+}  // extern "C"
+
+static int spade_fused_launch(bool packed, const void* V2, const void* U2, const float* amax_cat, float v_bound,
+                              const float* amax_u, const float* bias_packed, const float* x, const float* mean,
+                              const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C, int rows, int K,
+                              int groups, float add_one, float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
   DSEE_CHECK_ARG(V2 && U2 && amax_cat && amax_u && x && mean && invstd && out_h);
   DSEE_CHECK_ARG(rows == 2 * C && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && (K == 128 || K == 160));
   DSEE_CHECK_ARG(groups == 1 || groups == N);
@@ -562,8 +581,9 @@ int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, 
   a.T = T;
   a.v_slab_bytes = 36L * T * 64;
   a.u_slab_bytes = (long)rows * 64;
-  a.u_group_bytes = (long)(K / 16) * rows * 64;
-  const long vb = a.v_slab_bytes * (K / 16), ub = a.u_group_bytes * 36 * groups;
+  const int kslab = packed ? 32 : 16;          // k's per 64-byte-row slab of the operand images
+  a.u_group_bytes = (long)(K / kslab) * rows * 64;
+  const long vb = a.v_slab_bytes * (K / kslab), ub = a.u_group_bytes * 36 * groups;
   DSEE_CHECK_ARG(vb < 0xFFFFFFF0L && ub < 0xFFFFFFF0L);   // operand tensors are addressed through one buffer resource each
   a.v_bytes = (unsigned)vb;
   a.u_bytes = (unsigned)ub;
@@ -580,13 +600,13 @@ int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, 
   a.stamps = g_fused_stamps;
   const long ntile = (T / 64) * (rows / 64);
   DSEE_CHECK_ARG(ntile < 0x7FFFFFFF);
-  const int np = K / 32;
+  const int np = packed ? (K + 63) / 64 : K / 32;
   const size_t lds = (size_t)2 * np * 16384;   // ring of two positions: 2 * NP pieces of U and of V, 8 KB each
-#define DSEE_FUSED(NP, WS)                                                                                           \
+#define DSEE_FUSED(NP, WS, PKD)                                                                                      \
   do {                                                                                                               \
     static bool attr_done = false;                                                                                   \
     if (!attr_done) {                                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_fwd_kernel<NP, WS>),            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_fwd_kernel<NP, WS, PKD>),       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e != hipSuccess) {                                                                                         \
         dsee_set_error("hipFuncSetAttribute(%zu bytes of LDS): %s", lds, hipGetErrorString(e));                     \
@@ -594,16 +614,42 @@ int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, 
       }                                                                                                              \
       attr_done = true;                                                                                              \
     }                                                                                                                \
-    spade_fused_fwd_kernel<NP, WS><<<(int)ntile, 512, lds, st>>>(a);                                                 \
+    spade_fused_fwd_kernel<NP, WS, PKD><<<(int)ntile, 512, lds, st>>>(a);                                            \
   } while (0)
-  if (np == 5) {
-    if (out_scale) DSEE_FUSED(5, true); else DSEE_FUSED(5, false);
+  if (packed) {
+    if (np == 3) {
+      if (out_scale) DSEE_FUSED(3, true, true); else DSEE_FUSED(3, false, true);
+    } else {
+      if (out_scale) DSEE_FUSED(2, true, true); else DSEE_FUSED(2, false, true);
+    }
+  } else if (np == 5) {
+    if (out_scale) DSEE_FUSED(5, true, false); else DSEE_FUSED(5, false, false);
   } else {
-    if (out_scale) DSEE_FUSED(4, true); else DSEE_FUSED(4, false);
+    if (out_scale) DSEE_FUSED(4, true, false); else DSEE_FUSED(4, false, false);
   }
 #undef DSEE_FUSED
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
+}
+
+extern "C" {
+
+int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
+                         const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
+                         float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
+                         float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
+  return spade_fused_launch(false, V2, U2, amax_cat, v_bound, amax_u, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W,
+                            C, rows, K, groups, add_one, slope, amax_h, amax_xhat, st);
+}
+
+/* 16-bit storage mode: the same kernel on PACKED ONE-TERM operands -- V1 = dsee_wino43_input_f16p(cat) [K/32][36*T][32] fp16,
+ * U1 = dsee_wino43_weights[_table](split = 4) [36*groups][K/32][rows][32] -- one MFMA product per multiply-add. */
+int dsee_spade_fused_fwd_f16p(const void* V1, const void* U1, const float* amax_cat, float v_bound, const float* amax_u,
+                              const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
+                              float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
+                              float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
+  return spade_fused_launch(true, V1, U1, amax_cat, v_bound, amax_u, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W,
+                            C, rows, K, groups, add_one, slope, amax_h, amax_xhat, st);
 }
 
 }  // extern "C"

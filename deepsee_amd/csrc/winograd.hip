@@ -312,19 +312,44 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
 // WIDE (C % 64 == 0): a wave = 4 consecutive tiles x four slabs (64 channels), lane = (tile l >> 4, slab (l >> 2) & 3, quad
 // l & 3): the 16 lanes of a tile read 256 contiguous bytes of every pixel (64-byte runs cost the narrow form 20 % of its
 // bandwidth) and a store instruction still writes whole 64-byte rows, 256 bytes contiguous per slab.
-template <bool WIDE>
+// PK (16-bit storage mode, opt.precision = "fp16"): the same transform written as the PACKED ONE-TERM operand
+// V1 [C/32][36*T][32] fp16 -- the 64-byte row of the image holds 32 channels of one scaled fp16 term instead of 2 terms x 16
+// channels (gemm_bf16x3.hip, "packed one-term"): half the bytes per element, same row size, same consumers' DMA streams.
+// A lane holds 4 channels = 8 bytes per transform position; the lanes of a pair (adjacent channel quads) exchange halves
+// across PAIRS of positions -- the even lane writes 16 bytes of position 2j (its own quad + the partner's), the odd lane 16
+// bytes of position 2j + 1 -- so every store is 16 bytes and a (tile, 32-channel slab, position) row is written whole.
+// Lane mappings: WIDE (C % 64 == 0) as above, 4 tiles x 64 channels per wave; else (C % 32 == 0) 8 tiles x 32 channels.
+template <bool WIDE, bool PK>
+__device__ __forceinline__ void f16_lane_map(long w, int l, int nkb, int& kb, long& t) {
+  if constexpr (WIDE) {
+    kb = (int)(w % nkb) * 4 + ((l >> 2) & 3);
+    t = (w / nkb) * 4 + (l >> 4);
+  } else if constexpr (PK) {
+    kb = (int)(w % nkb) * 2 + ((l >> 2) & 1);
+    t = (w / nkb) * 8 + (l >> 3);
+  } else {
+    kb = (int)(w % nkb);
+    t = (w / nkb) * 16 + (l >> 2);
+  }
+}
+template <bool WIDE, bool PK>
+__device__ __forceinline__ int f16_nkb(int C) { return WIDE ? C >> 6 : (PK ? C >> 5 : C >> 4); }
+template <bool WIDE, bool PK>
+__device__ __forceinline__ long f16_waves(long T, int nkb) { return (WIDE ? T >> 2 : (PK ? T >> 3 : T >> 4)) * nkb; }
+template <bool WIDE, bool PK = false>
 __global__ __launch_bounds__(256) void wino43_input_f16x2_kernel(const float* __restrict__ x, unsigned char* __restrict__ V2,
                                                                  int N, int H, int W, int C,
                                                                  const float* __restrict__ amax, float bound) {
   const float sc = dsee_pow2_scale(bound * dsee_amax_read(amax));
-  const int nkb = WIDE ? C >> 6 : C >> 4, th = H / 4, tw = W / 4;
-  const long T = (long)N * th * tw, total = (WIDE ? T >> 2 : T >> 4) * nkb * 64;
+  const int nkb = f16_nkb<WIDE, PK>(C), th = H / 4, tw = W / 4;
+  const long T = (long)N * th * tw, total = f16_waves<WIDE, PK>(T, nkb) * 64;
   const size_t slab = (size_t)36 * T * 64;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long w = i >> 6;
     const int l = (int)(i & 63);
-    const int kb = WIDE ? (int)(w % nkb) * 4 + ((l >> 2) & 3) : (int)(w % nkb);
-    const long t = WIDE ? (w / nkb) * 4 + (l >> 4) : (w / nkb) * 16 + (l >> 2);
+    int kb;
+    long t;
+    f16_lane_map<WIDE, PK>(w, l, nkb, kb, t);
     const int q = kb * 4 + (l & 3);
     const int tx = (int)(t % tw);
     const long r = t / tw;
@@ -346,6 +371,18 @@ __global__ __launch_bounds__(256) void wino43_input_f16x2_kernel(const float* __
       for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
     }
     const bool odd = (l & 1) != 0;
+    if constexpr (PK) {
+      unsigned char* rowp = V2 + (size_t)(q >> 3) * slab + (size_t)t * 64 + ((q & 7) & ~1) * 8;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        f32x4 o[6];
+        bt6(tmp[k], o);
+#pragma unroll
+        for (int j = 0; j < 6; j += 2)
+          dsee_store_pk_pair(rowp + (size_t)(k * 6 + j) * T * 64, (size_t)T * 64, odd, o[j] * sc, o[j + 1] * sc);
+      }
+      continue;
+    }
     unsigned char* rowp = V2 + (size_t)kb * slab + (size_t)t * 64 + (odd ? 32 + ((l & 3) - 1) * 8 : (l & 3) * 8);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -394,7 +431,7 @@ __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
 // SUMS: bias / noise-weight gradients as in wino43_dout_kernel; a wave keeps its 16-channel slab for the whole loop
 // (gridDim.x * 4 is a multiple of C/16), reduces over its 16 tile lanes and writes part[global wave][3][16].
 struct DoutSums;
-template <bool SUMS, bool WIDE>
+template <bool SUMS, bool WIDE, bool PK = false>
 __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __restrict__ dy, unsigned char* __restrict__ dM2,
                                                                 int N, int H, int W, int C, const float* __restrict__ amax,
                                                                 float bound, float* __restrict__ part, int want_bias,
@@ -408,15 +445,16 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
       off1 += *epoch;
     }
   }
-  const int nkb = WIDE ? C >> 6 : C >> 4, C4 = C / 4, th = H / 4, tw = W / 4;   // channel groups of a wave (64 / 16 channels)
-  const long T = (long)N * th * tw, total = (WIDE ? T >> 2 : T >> 4) * nkb * 64;
+  const int nkb = f16_nkb<WIDE, PK>(C), C4 = C / 4, th = H / 4, tw = W / 4;   // channel groups of a wave (64 / 32 / 16 channels)
+  const long T = (long)N * th * tw, total = f16_waves<WIDE, PK>(T, nkb) * 64;
   const size_t slab = (size_t)36 * T * 64;
   f32x4 sb = {0.f, 0.f, 0.f, 0.f}, s0 = sb, s1 = sb;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long w = i >> 6;
     const int l = (int)(i & 63);
-    const int kb = WIDE ? (int)(w % nkb) * 4 + ((l >> 2) & 3) : (int)(w % nkb);
-    const long t = WIDE ? (w / nkb) * 4 + (l >> 4) : (w / nkb) * 16 + (l >> 2);
+    int kb;
+    long t;
+    f16_lane_map<WIDE, PK>(w, l, nkb, kb, t);
     const int q = kb * 4 + (l & 3);
     const int tx = (int)(t % tw);
     const long r = t / tw;
@@ -440,6 +478,18 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
       for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
     }
     const bool odd = (l & 1) != 0;
+    if constexpr (PK) {
+      unsigned char* rowp = dM2 + (size_t)(q >> 3) * slab + (size_t)t * 64 + ((q & 7) & ~1) * 8;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        f32x4 o[6];
+        a6(tmp[k], o);
+#pragma unroll
+        for (int j = 0; j < 6; j += 2)
+          dsee_store_pk_pair(rowp + (size_t)(k * 6 + j) * T * 64, (size_t)T * 64, odd, o[j] * sc, o[j + 1] * sc);
+      }
+      continue;
+    }
     unsigned char* rowp = dM2 + (size_t)kb * slab + (size_t)t * 64 + (odd ? 32 + ((l & 3) - 1) * 8 : (l & 3) * 8);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -469,7 +519,7 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
   if constexpr (SUMS) {
     // fold the tile lanes of the wave (WIDE: lane bits 4, 5; else bits 2..5); the low QL lanes then hold the sums of the
     // wave's channel quads; part[global wave][3][CW channels]
-    constexpr int QL = WIDE ? 16 : 4, CW = QL * 4;
+    constexpr int QL = WIDE ? 16 : (PK ? 8 : 4), CW = QL * 4;
 #pragma unroll
     for (int o = QL; o < 64; o <<= 1)
 #pragma unroll
@@ -951,7 +1001,10 @@ __global__ void wino43_weight_table_kernel(const float* __restrict__ w2a, const 
     ggt(g, u);
 #pragma unroll
     for (int xi = 0; xi < 36; ++xi) {
-      if (split == 3) {   // half-precision compute mode: [K/16][rows][16], one scaled fp16 term
+      if (split == 4) {   // 16-bit storage mode: packed one-term rows [K/32][rows][32] (Kpad % 32 == 0)
+        reinterpret_cast<_Float16*>(U)[((size_t)xi * N + n) * per + ((size_t)(k >> 5) * rows + row) * 32 + (k & 31)] =
+            (_Float16)(u[xi] * sc);
+      } else if (split == 3) {   // half-precision compute mode: [K/16][rows][16], one scaled fp16 term
         reinterpret_cast<_Float16*>(U)[((size_t)xi * N + n) * per + ((size_t)(k >> 4) * rows + row) * 16 + (k & 15)] =
             (_Float16)(u[xi] * sc);
       } else if (split == 2) {
@@ -1028,7 +1081,10 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
       u[5] = t2;
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        if (split == 3) {
+        if (split == 4) {
+          reinterpret_cast<_Float16*>(U)[(size_t)(a * 6 + b) * total + ((size_t)(k >> 5) * rows + row) * 32 + (k & 31)] =
+              (_Float16)(u[b] * sc);
+        } else if (split == 3) {
           reinterpret_cast<_Float16*>(U)[(size_t)(a * 6 + b) * total + ((size_t)(k >> 4) * rows + row) * 16 + (k & 15)] =
               (_Float16)(u[b] * sc);
         } else if (split == 2) {
@@ -1103,6 +1159,22 @@ int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C
   return DSEE_OK;
 }
 
+/* 16-bit storage mode: the same transform written as the PACKED ONE-TERM operand V1 [C/32][36*T][32] fp16 (one scaled fp16 term
+ * per element, 64-byte rows of 32 channels), scale dsee_pow2_scale(bound * *amax_x).  C % 32 == 0, T % 8 == 0. */
+int dsee_wino43_input_f16p(const float* x, void* V1, int N, int H, int W, int C, const float* amax_x, float bound,
+                           hipStream_t st) {
+  DSEE_CHECK_ARG(x && V1 && amax_x && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 100.f);
+  DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 8 == 0);
+  if (C % 64 == 0)
+    wino43_input_f16x2_kernel<true, true><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+        x, reinterpret_cast<unsigned char*>(V1), N, H, W, C, amax_x, bound);
+  else
+    wino43_input_f16x2_kernel<false, true><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+        x, reinterpret_cast<unsigned char*>(V1), N, H, W, C, amax_x, bound);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
 /* same transform, output as bf16x3-split rows for dsee_gemm_bf16x3: V3 [C/16][36*T][3][16] bf16 (C % 32 == 0) */
 int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C, hipStream_t st) {
   DSEE_CHECK_ARG(x && V3 && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 8 == 0);
@@ -1148,24 +1220,28 @@ size_t dsee_wino43_dout_f16x2_workspace(void) { return (size_t)DOUT_SUMS_GRID * 
  * 225, amax_dy >= max |dY| written by dY's producer) + optionally the channel sums of dsee_wino43_dout_sums.
  * workspace (dsee_wino43_dout_f16x2_workspace bytes) only when a sum is requested.  C % 16 == 0, T % 16 == 0,
  * 2048 % (C/16) == 0. */
-int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
-                           float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
-                           float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t st) {
-  DSEE_CHECK_ARG(dy && dM2 && amax_dy && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 225.f);
+}  // extern "C"
+
+namespace {
+template <bool PK>
+int dout_f16_launch(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
+                    float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0, float* dnoise1,
+                    uint64_t seed1, uint64_t offset1, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dM2 && amax_dy && C % (PK ? 32 : 16) == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 225.f);
   const long T = (long)N * (H / 4) * (W / 4);
   DSEE_CHECK_ARG(T % 16 == 0);
   const bool sums = dbias || dnoise0 || dnoise1, wide = C % 64 == 0;
-  const int cw = wide ? 64 : 16, nkb = C / cw;
+  const int cw = wide ? 64 : (PK ? 32 : 16), nkb = C / cw;
   const long blocks = (T / 16) * (C / 16) / 4 + 1;
   unsigned char* out = reinterpret_cast<unsigned char*>(dM2);
   if (!sums) {
     const int grid = (int)min(16384L, blocks);
     if (wide)
-      wino43_dout_f16x2_kernel<false, true><<<grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0, 0, 0,
-                                                                  0, 0, nullptr);
+      wino43_dout_f16x2_kernel<false, true, PK><<<grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0, 0,
+                                                                      0, 0, 0, nullptr);
     else
-      wino43_dout_f16x2_kernel<false, false><<<grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0, 0, 0,
-                                                                   0, 0, nullptr);
+      wino43_dout_f16x2_kernel<false, false, PK><<<grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, nullptr, 0, 0, 0,
+                                                                       0, 0, 0, 0, nullptr);
     DSEE_LAUNCH_CHECK();
     return DSEE_OK;
   }
@@ -1176,18 +1252,39 @@ int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int 
   if (grid < m) grid = m;
   DSEE_CHECK_ARG((grid * 4) % nkb == 0);
   if (wide)
-    wino43_dout_f16x2_kernel<true, true><<<(int)grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, workspace,
-                                                                    dbias != nullptr, dnoise0 != nullptr, dnoise1 != nullptr,
-                                                                    seed0, offset0, seed1, offset1, dsee_rng_epoch());
+    wino43_dout_f16x2_kernel<true, true, PK><<<(int)grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, workspace,
+                                                                        dbias != nullptr, dnoise0 != nullptr,
+                                                                        dnoise1 != nullptr, seed0, offset0, seed1, offset1,
+                                                                        dsee_rng_epoch());
   else
-    wino43_dout_f16x2_kernel<true, false><<<(int)grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, workspace,
-                                                                     dbias != nullptr, dnoise0 != nullptr, dnoise1 != nullptr,
-                                                                     seed0, offset0, seed1, offset1, dsee_rng_epoch());
+    wino43_dout_f16x2_kernel<true, false, PK><<<(int)grid, 256, 0, st>>>(dy, out, N, H, W, C, amax_dy, bound, workspace,
+                                                                         dbias != nullptr, dnoise0 != nullptr,
+                                                                         dnoise1 != nullptr, seed0, offset0, seed1, offset1,
+                                                                         dsee_rng_epoch());
   DSEE_LAUNCH_CHECK();
   dout_f16x2_sums_finalize_kernel<<<dim3(dsee_cdiv(C, 8), 3), 256, 0, st>>>(workspace, (int)grid * 4, C, cw, dbias, dnoise0,
                                                                            dnoise1);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
+                           float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
+                           float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t st) {
+  return dout_f16_launch<false>(dy, dM2, N, H, W, C, amax_dy, bound, workspace, dbias, dnoise0, seed0, offset0, dnoise1, seed1,
+                                offset1, st);
+}
+
+/* 16-bit storage mode: dM = A dY A^T as the PACKED ONE-TERM operand dM1 [C/32][36*T][32] fp16 (+ the same optional channel
+ * sums); workspace as dsee_wino43_dout_f16x2.  C % 32 == 0. */
+int dsee_wino43_dout_f16p(const float* dy, void* dM1, int N, int H, int W, int C, const float* amax_dy, float bound,
+                          float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
+                          float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t st) {
+  return dout_f16_launch<true>(dy, dM1, N, H, W, C, amax_dy, bound, workspace, dbias, dnoise0, seed0, offset0, dnoise1, seed1,
+                               offset1, st);
 }
 
 /* weight-gradient operands for dsee_gemm_bf16x3_tn: [36][T/16][C][3][16 tiles] bf16 (T % 16 == 0, C % 16 == 0) */
@@ -1229,6 +1326,27 @@ int dsee_wino43_output_stats(const float* M, const float* bias, const float* res
   return DSEE_OK;
 }
 
+/* dsee_wino43_output_stats on the scaled-fp16 product M16 of the 16-bit storage mode (dsee_gemm_f16p_pre; *mscale undoes its
+ * power-of-two scale) */
+int dsee_wino43_output_stats_f16(const void* M16, const float* bias, const float* residual, int residual_ld, float* y, int N,
+                                 int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
+                                 uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
+                                 uint64_t res_noise_offset, const float* mscale, float* stats_part, hipStream_t st) {
+  DSEE_CHECK_ARG(M16 && y && mscale && stats_part && C % 4 == 0 && H % 4 == 0 && W % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
+  DSEE_CHECK_ARG(act != DSEE_ACT_MASK);
+  DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
+  DSEE_CHECK_ARG(!res_noise_w || (residual && residual_ld == C));
+  DSEE_CHECK_ARG((long)N * (H / 4) * (W / 4) * C * 2 < 0xFFFFFFF0L);
+  const long items = (long)N * (H / 4) * (W / 4) * (C / 4);
+  const int grid = (int)min((long)DSEE_STATS_ROWS_MAX, (items + 255) / 256);
+  wino43_output_kernel<true, _Float16, true><<<grid, 256, 0, st>>>(reinterpret_cast<const _Float16*>(M16), bias, residual,
+                                                                   residual_ld, y, N, H, W, C, act, slope, noise_w, noise_seed,
+                                                                   noise_offset, res_noise_w, res_noise_seed, res_noise_offset,
+                                                                   mscale, dsee_rng_epoch(), stats_part);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
 /* dx [N][H][W][C] from dV [36][T][C] (see wino43_input_adjoint_kernel); mask [pixels][mask_ld] optional */
 int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
                               const float* dvscale, hipStream_t st) {
@@ -1249,6 +1367,16 @@ int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int
   DSEE_CHECK_ARG(dV && dx && amax_dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   wino43_input_adjoint_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dV, nullptr, 0, dx, N, H, W, C,
                                                                                           nullptr, amax_dx);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* ... and from the scaled-fp16 dV16 of the 16-bit storage mode (*dvscale undoes its power-of-two scale) */
+int dsee_wino43_input_adjoint_amax_f16(const void* dV16, float* dx, int N, int H, int W, int C, const float* dvscale,
+                                       float* amax_dx, hipStream_t st) {
+  DSEE_CHECK_ARG(dV16 && dx && dvscale && amax_dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
+  wino43_input_adjoint_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
+      reinterpret_cast<const _Float16*>(dV16), nullptr, 0, dx, N, H, W, C, dvscale, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -291,7 +291,8 @@ def _split_ok(k_s, r_s):
 
 
 def _split_kind(k_s, r_s):
-    """0: fp32 GEMM operands; 1: bf16x3; 2: fp16x2 (fp32 A operand split inside the GEMM kernel); 3: one fp16 term."""
+    """0: fp32 GEMM operands; 1: bf16x3; 2: fp16x2 (fp32 A operand split inside the GEMM kernel); 3: one fp16 term.
+    (4 = packed one-term operands written by their producers, the 16-bit storage mode: chosen per call by _pk_ok.)"""
     if not _split_ok(k_s, r_s):
         return 0
     af32 = P().gemm_af32 and k_s * 4 * 256 < 0x7FFFFFFF
@@ -367,20 +368,23 @@ def _wino_u(w, co, ci, transpose_flip, rows, kp, split):
     if pre is not None and (int(transpose_flip), int(split), rows, kp) in pre:
         return pre[(int(transpose_flip), int(split), rows, kp)]       # transformed with its whole network (SNGroup.wino_weights)
     amax = weight_amax(w) if split >= 2 else None
-    u = _i16(36 * rows * kp * {1: 3, 2: 2, 3: 1}[split]) if split else new(36, rows, kp)
+    u = _i16(36 * rows * kp * {1: 3, 2: 2, 3: 1, 4: 1}[split]) if split else new(36, rows, kp)
     L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split), amax)
     return u, amax
 
 
 def _gemm_bytes(t, k_s, r_s, groups, rows, split):
     """algorithmic HBM bytes of a Winograd-domain GEMM: A (fp32, or 6 B/element pre-split) + B + C (fp32)"""
+    if split == 4:
+        return 2.0 * 36 * t * k_s + 2.0 * groups * rows * k_s + 2.0 * 36 * t * r_s
     if split == 3:
         return 4.0 * 36 * t * k_s + 2.0 * groups * rows * k_s + 2.0 * 36 * t * r_s
     return 4.0 * 36 * t * k_s + (4.0 if split == 2 else 6.0) * groups * rows * k_s + 4.0 * 36 * t * r_s
 
 
 def _gemm_name(split):
-    return {1: "winograd_gemm_bf16x3", 2: "winograd_gemm_f16x2", 3: "winograd_gemm_f16_1term"}[split]
+    return {1: "winograd_gemm_bf16x3", 2: "winograd_gemm_f16x2", 3: "winograd_gemm_f16_1term",
+            4: "winograd_gemm_f16_1term_packed"}[split]
 
 
 FUSED_V_BOUND = 100.0       # |B^T d B| <= 100 max|d| for F(4x4,3x3): scale of a pre-split V from max |input|
@@ -393,6 +397,14 @@ def _presplit_ok(xc, t, t_g, r_s, k_s=0, keep=False):
             and (36 * t // 256) * (r_s // 256) >= 512 and (not keep or k_s == 160 or k_s % 128 == 0))
 
 
+def _pk_ok(xc, t_g, r_s, k_s):
+    """16-bit storage mode (plan.half): the layer takes the packed one-term kernels (dsee_wino43_input_f16p ->
+    dsee_gemm_f16p_pre -> fp16 product) when the input's maximum was written by its producer, every GEMM group is whole
+    256-row tiles, the output width whole 128-column tiles and the reduction whole 32-channel slabs."""
+    return (P().half and P().presplit_a and P().gemm_split and P().gemm_af32 and carried_amax(xc) is not None
+            and t_g % 256 == 0 and r_s % 128 == 0 and k_s % 32 == 0)
+
+
 def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=None, u_amax=None):
     """(M [36][t][r_s], mscale) = V(xc) x U: input transform of `nb` images + the 36 (x nb with per-image weights) GEMMs.
     mscale: None (M is fp32) or the device scalar that rescales the fp16 M of the half-precision mode.
@@ -400,9 +412,20 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
     tpi = (h // 4) * (wd // 4)
     t = nb * tpi
     groups, t_g = (36 * nb, tpi) if per_image else (36, t)
-    m = torch.empty(36, t, r_s, dtype=torch.float16, device="cuda") if split == 3 else new(36, t, r_s)
+    m = torch.empty(36, t, r_s, dtype=torch.float16, device="cuda") if split in (3, 4) else new(36, t, r_s)
     ms = None
-    if split == 3:
+    if split == 4:
+        # 16-bit storage: V leaves the transform as ONE scaled fp16 term per element (2 bytes), the GEMM streams it and the
+        # packed one-term weights without conversion and writes the product as scaled fp16
+        ax = xc.dsee_amax
+        v1, ms = _i16(36 * t * k_s), amax_slot()
+        L.call("wino43_input_f16p", xc, v1, nb, h, wd, k_s, ax, FUSED_V_BOUND)
+        with _timed("winograd_gemm_f16_1term_packed", 2.0 * 36 * t * k_s * r_s,
+                    2.0 * 36 * t * k_s + 2.0 * groups * rows * k_s + 2.0 * 36 * t * r_s):
+            L.call("gemm_f16p_pre", v1, u, m, 36 * t, r_s, k_s, t_g, rows, ax, FUSED_V_BOUND, u_amax, ms)
+        if keep is not None:
+            keep.append((v1, ax, "pk"))     # (packed one-term V, max |x|, marker): the weight gradient's Q operand as it is
+    elif split == 3:
         v, va, ms = new(36, t, k_s), amax_slot(), amax_slot()
         L.call("wino43_input", xc, v, nb, h, wd, k_s, va)
         with _timed(_gemm_name(3), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 3)):
@@ -459,9 +482,11 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
     r_s, k_s = (cin_s, cout_s) if transpose_flip else (cout_s, cin_s)   # GEMM output / reduction channels
     rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
     split = _split_kind(k_s, r_s)
+    nb = _wino_chunk(n, h, wd, max(r_s, k_s))
+    if split == 3 and nb == n and _pk_ok(x, n * (h // 4) * (wd // 4), r_s, k_s):
+        split = 4
     u, ua = _wino_u(w, co, ci, transpose_flip, rows, kp, split)
     y = new(n, h, wd, r_s)
-    nb = _wino_chunk(n, h, wd, max(r_s, k_s))
     for n0 in range(0, n, nb):
         xc = x if nb == n else x[n0:n0 + nb]
         if nb != n and carried_amax(x) is not None:
@@ -470,10 +495,14 @@ def _wino_conv(x, w, n, h, wd, cin_s, cout_s, transpose_flip, bias=None, res=Non
         nz = (None, 0, 0) if noise is None else (noise[0], noise[1].seed, noise[1].offset + n0 * h * wd * r_s // 4)
         rz = ((None, 0, 0) if res_noise is None else
               (res_noise[0], res_noise[1].seed, res_noise[1].offset + n0 * h * wd * r_s // 4))
-        if stats and P().producer_stats and nb == n and ms is None and act != L.ACT_MASK and _stats_rows_ok(r_s):
+        if stats and P().producer_stats and nb == n and (ms is None or split == 4) and act != L.ACT_MASK and _stats_rows_ok(r_s):
             rows = L.lib().dsee_stats_part_rows(C.c_long(nb * (h // 4) * (wd // 4) * (r_s // 4)))
             part = new(rows, 3, r_s)
-            L.call("wino43_output_stats", m, bias, res, res_ld or r_s, y, nb, h, wd, r_s, act, LRELU_SLOPE, *nz, *rz, part)
+            if ms is None:
+                L.call("wino43_output_stats", m, bias, res, res_ld or r_s, y, nb, h, wd, r_s, act, LRELU_SLOPE, *nz, *rz, part)
+            else:
+                L.call("wino43_output_stats_f16", m, bias, res, res_ld or r_s, y, nb, h, wd, r_s, act, LRELU_SLOPE, *nz, *rz,
+                       ms, part)
             y.dsee_stats_rows = (part, rows)
             continue
         L.call("wino43_output", m, bias, None if res is None else res[n0:n0 + nb], res_ld or r_s, y[n0:n0 + nb], nb, h, wd,
@@ -513,6 +542,21 @@ def _dout_sums_ok(n, nb, cout_s, mode):
 DM_BOUND = 225.0      # |A dY A^T| <= 225 max|dY| for F(4x4,3x3) (absolute row sums of A: 1, 4, 4, 15, 15, 1)
 
 
+def _is_pk(v):
+    """(tensor, amax, "pk"): a packed one-term operand of the 16-bit storage mode"""
+    return v is not None and len(v) == 3 and v[2] == "pk"
+
+
+def _wgrad_code(v, dm, mode):
+    """`split` argument of dsee_wino43_wgrad[_table] for the operand forms at hand"""
+    if _is_pk(v):
+        assert _is_pk(dm)
+        return 7
+    if len(v) == 3:
+        return 6 if len(dm) == 3 else 5
+    return _wgrad_split(mode)
+
+
 def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None, sums=None, pre_dm=False):
     """((V, amax_V), (dM, amax_dM)) of one image chunk for the Winograd-domain weight gradient: fp32 rows (modes 0, 2;
     `v` may be the (V, amax) the forward pass kept, `dm` the (A dY A^T, amax) its producer already wrote) or transposed
@@ -526,13 +570,28 @@ def _wino_wgrad_operands(xc, gc, nb, h, wd, cin_s, cout_s, mode, v=None, dm=None
         L.call("wino43_dout_split_t", gc, dm, nb, h, wd, cout_s)
         return (v, None), (dm, None)
     need = P().gemm_split and (P().gemm_f16x2 or P().half)   # maxima for the fp16 operand scales
+    ga = carried_amax(gc) if gc is not None else None
+    if _is_pk(v) and not _is_pk(dm) and not (dm is None and pre_dm and ga is not None):
+        v = None       # a packed one-term V needs a packed one-term dM (dsee_gemm_f16p_tn_pqpre): transform x again in fp32
     if v is not None and len(v) == 3:
         pass                                     # the forward's pre-split V2 (dsee_wino43_wgrad split = 5)
     elif v is None or (need and v[1] is None):
         v = (new(36, t, cin_s), amax_slot() if need else None)
         L.call("wino43_input", xc, v[0], nb, h, wd, cin_s, v[1])
-    ga = carried_amax(gc)
-    if dm is None and pre_dm and ga is not None and v is not None and len(v) == 3:
+    if dm is None and pre_dm and ga is not None and _is_pk(v):
+        # 16-bit storage: A dY A^T as ONE scaled fp16 term per element, for the same two consumers
+        dm1 = _i16(36 * t * cout_s)
+        n0, n1 = (sums.get("n0"), sums.get("n1")) if sums else (None, None)
+        if sums:
+            sums["dbias"] = new(cout_s) if sums.get("bias") else None
+            sums["dn0"], sums["dn1"] = (new(cout_s) if n0 is not None else None), (new(cout_s) if n1 is not None else None)
+        any_sum = bool(sums) and (sums["dbias"] is not None or n0 is not None or n1 is not None)
+        ws = scratch(L.lib().dsee_wino43_dout_f16x2_workspace(), "doutsums2") if any_sum else None
+        L.call("wino43_dout_f16p", gc, dm1, nb, h, wd, cout_s, ga, DM_BOUND, ws, sums["dbias"] if sums else None,
+               sums["dn0"] if sums else None, n0.seed if n0 is not None else 0, n0.offset if n0 is not None else 0,
+               sums["dn1"] if sums else None, n1.seed if n1 is not None else 0, n1.offset if n1 is not None else 0)
+        dm = (dm1, ga, "pk")
+    elif dm is None and pre_dm and ga is not None and v is not None and len(v) == 3:
         # dY's maximum is known (its producer wrote it): A dY A^T leaves the transform pre-split, for the weight gradient's
         # P operand and the adjoint data-gradient GEMM's A operand alike
         dm2 = _i16(36 * t * cout_s * 2)
@@ -570,11 +629,13 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
     """dx [nb,h,wd,r_s] of a 3x3 convolution from dm = (dM [36][t][k_s] = A dY A^T, amax): one grouped GEMM with the
     transposed forward weights u_t = (U^T [36][rows][k_s] split, amax) and the overlap-add of the patches B dV B^T."""
     t = nb * (h // 4) * (wd // 4)
-    split = _split_kind(k_s, r_s)          # (the kind u_t was built with)
-    dv = torch.empty(36, t, r_s, dtype=torch.float16, device="cuda") if split == 3 else new(36, t, r_s)
-    dvs = amax_slot() if split == 3 else None
+    split = 4 if _is_pk(dm) else _split_kind(k_s, r_s)          # (the kind u_t was built with)
+    dv = torch.empty(36, t, r_s, dtype=torch.float16, device="cuda") if split in (3, 4) else new(36, t, r_s)
+    dvs = amax_slot() if split in (3, 4) else None
     with _timed(_gemm_name(split), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, 36, rows, split)):
-        if len(dm) == 3:
+        if split == 4:
+            L.call("gemm_f16p_pre", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, dm[1], DM_BOUND, u_t[1], dvs)
+        elif len(dm) == 3:
             L.call("gemm_f16x2_pre", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, dm[1], DM_BOUND, u_t[1])
         elif split == 3:
             L.call("gemm_f16_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0, dm[1], u_t[1], 1, dvs)
@@ -586,6 +647,9 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
     if mask is None and dvs is None and P().presplit_dm:
         tag_amax(dx, amax_slot())      # (dx is the gradient w.r.t. a norm's output: bound of that norm's gamma/beta gradient)
         L.call("wino43_input_adjoint_amax", dv, dx, nb, h, wd, r_s, dx.dsee_amax)
+    elif mask is None and split == 4 and P().presplit_dm:
+        tag_amax(dx, amax_slot())
+        L.call("wino43_input_adjoint_amax_f16", dv, dx, nb, h, wd, r_s, dvs, dx.dsee_amax)
     else:
         L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s, dvs)
     return dx
@@ -603,22 +667,25 @@ def _wino_wgrad(x, g, n, h, wd, cin_s, cout_s, co, ci, v_fwd=None, w_for_dx=None
     total = None
     with_dx = w_for_dx is not None
     assert not with_dx or (mode != 1 and _adjoint_ok(cout_s, cin_s))
+    # 16-bit storage mode: the forward kept a packed one-term V -> A dY A^T packed one-term too (wgrad split 7, adjoint GEMM on
+    # dsee_gemm_f16p_pre), when dY's maximum is known
+    pk = (_is_pk(v_fwd) and P().presplit_dm and mode == 2 and nb == n and carried_amax(g) is not None and t % 256 == 0
+          and cout_s % 32 == 0 and (not with_dx or cin_s % 128 == 0))
     if with_dx:
         rows_t = L.wrows(cin_s)
-        u_t = _wino_u(w_for_dx, co, ci, 2, rows_t, L.kpad(1, 1, cout_s), _split_kind(cout_s, cin_s))
+        u_t = _wino_u(w_for_dx, co, ci, 2, rows_t, L.kpad(1, 1, cout_s), 4 if pk else _split_kind(cout_s, cin_s))
         dx = new(n, h, wd, cin_s) if nb != n else None
     # A dY A^T pre-split when the whole chain can take it: split V kept by the forward (-> wgrad split 6), and the adjoint GEMM
     # (if any) on the 256 x 256 pre-split-A kernel
-    pre_dm = (P().presplit_dm and mode == 2 and nb == n and _split_kind(cout_s, cin_s) == 2 and t % 256 == 0
-              and cout_s % 16 == 0 and (not with_dx or (cin_s % 256 == 0 and (36 * t // 256) * (cin_s // 256) >= 512)))
+    pre_dm = pk or (P().presplit_dm and mode == 2 and nb == n and _split_kind(cout_s, cin_s) == 2 and t % 256 == 0
+                    and cout_s % 16 == 0 and (not with_dx or (cin_s % 256 == 0 and (36 * t // 256) * (cin_s // 256) >= 512)))
     for n0 in range(0, n, nb):
         gc = g if nb == n else g[n0:n0 + nb]
         v, dm = _wino_wgrad_operands(x[n0:n0 + nb], gc, nb, h, wd, cin_s, cout_s, mode,
                                      v_fwd if (mode == 2 and nb == n) else None, sums=sums, pre_dm=pre_dm)
         dw = new(co, ci, 3, 3)
         with _timed(_wgrad_name(mode), 2.0 * 36 * t * cin_s * cout_s):
-            L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci,
-                   (6 if len(dm) == 3 else 5) if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
+            L.call("wino43_wgrad", v[0], dm[0], ws, nbytes, dw, t, cin_s, cout_s, co, ci, _wgrad_code(v, dm, mode), v[1], dm[1])
         total = dw if total is None else total.add_(dw)
         if with_dx:
             dxc = _wino_dgrad_from_dm(dm, u_t, nb, h, wd, cout_s, cin_s, rows_t)
@@ -677,7 +744,7 @@ class Conv2d(torch.autograd.Function):
         ctx.noise = noise_eps if noise_w is not None else None
         ctx.res_noise = res_noise_eps if res_noise_w is not None else None
         ctx.res_sink = res_sink
-        ctx.v_pre = bool(vkeep) and len(vkeep) == 3
+        ctx.v_kind = vkeep[2] if (vkeep and len(vkeep) == 3) else None     # True: fp16x2 pre-split, "pk": packed one-term
         ctx.save_for_backward(x, w, out if act != L.ACT_NONE else None, *(vkeep[:2] if vkeep else (None, None)))
         return out
 
@@ -687,7 +754,7 @@ class Conv2d(torch.autograd.Function):
         x, w, out, vk, vk_amax = ctx.saved_tensors
         w.dsee_amax, w.dsee_u = ctx.w_amax, ctx.w_u
         _bind_rng(ctx.noise, ctx.res_noise)
-        vkeep = ((vk, vk_amax, True) if ctx.v_pre else (vk, vk_amax)) if vk is not None else None
+        vkeep = ((vk, vk_amax, ctx.v_kind) if ctx.v_kind else (vk, vk_amax)) if vk is not None else None
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
@@ -960,22 +1027,23 @@ class SNGroup:
         w0 = self.layers[0].weight_orig
         co, ci = w0.shape[0], w0.shape[1]
         same = all(tuple(m.weight_orig.shape) == tuple(w0.shape) for m in self.layers) and tuple(w0.shape[2:]) == (3, 3)
-        if not (same and P().winograd and P().gemm_split and P().gemm_f16x2 and P().gemm_af32 and not P().half and ci % 32 == 0 and co % 128 == 0
+        if not (same and P().winograd and P().gemm_split and P().gemm_f16x2 and P().gemm_af32 and ci % 32 == 0 and co % 128 == 0
                 and ci % 128 == 0 and ci >= 128):
             return
         out, amax = self.last
         nl = len(self.layers)
         stride = self.slices[1][0] - self.slices[0][0] if nl > 1 else co * ci * 9
+        sp = 4 if P().half else 2              # 16-bit storage mode: packed one-term weights
         for flip in ((0, 2) if with_adjoint else (0,)):
             r_s, k_s = (ci, co) if flip else (co, ci)
             rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
-            per = 36 * rows * kp * 2            # int16 elements per layer (two fp16 terms)
+            per = 36 * rows * kp * (1 if sp == 4 else 2)     # int16 elements per layer (one / two fp16 terms)
             u = _i16(nl * per)
             with torch.no_grad():
-                L.call("wino43_weights_batch", out, u, nl, stride, per // 2, co, ci, flip, 2, amax)
+                L.call("wino43_weights_batch", out, u, nl, stride, per // 2, co, ci, flip, sp, amax)
             for i, m in enumerate(self.layers):
                 d = getattr(m._pre, "dsee_u", None) or {}
-                d[(flip, 2, rows, kp)] = (u[i * per:(i + 1) * per], amax[i])
+                d[(flip, sp, rows, kp)] = (u[i * per:(i + 1) * per], amax[i])
                 m._pre.dsee_u = d
 
 
@@ -1304,16 +1372,17 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     dgb = dm = None
     t = n * (h // 4) * (w // 4)
     dha = carried_amax(dh)
-    if as_dm and P().presplit_dm and P().presplit_gb and xhat_amax is not None and dha is not None and t % 256 == 0 and not P().half:
+    if as_dm and P().presplit_dm and P().presplit_gb and xhat_amax is not None and dha is not None and t % 256 == 0:
         # max |dh| (written by the kernel that produced dh) x max(1, max |xhat|) (written by the forward pass) bounds both halves
         # (g * xhat | g) of the gradient: dM leaves the reduce pass pre-split, for the table / embedding weight gradient's P
         # operand and the adjoint data-gradient GEMM's A operand
         ga = amax_slot()
         L.call("amax_product", dha, xhat_amax, 1.0, ga)
-        dm = (_i16(36 * t * rows * 2), ga, True)
+        pk = P().half      # 16-bit storage mode: one scaled fp16 term per element (dsee_modulate_bwd_reduce_wino_f16p)
+        dm = (_i16(36 * t * rows * (1 if pk else 2)), ga, "pk" if pk else True)
         ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
-        L.call("modulate_bwd_reduce_wino_f16x2", dh.contiguous(), out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c,
-               LRELU_SLOPE, ws, ga, DM_BOUND)
+        L.call("modulate_bwd_reduce_wino_f16p" if pk else "modulate_bwd_reduce_wino_f16x2", dh.contiguous(), out, x, scale, mean,
+               invstd, dm[0], rows, sums, n, h, w, c, LRELU_SLOPE, ws, ga, DM_BOUND)
     elif as_dm:
         dm = (new(36, t, rows), amax_slot() if (P().gemm_split and (P().gemm_f16x2 or P().half)) else None)
         ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
@@ -1388,9 +1457,15 @@ class SpadeNormAct(torch.autograd.Function):
 
 def _fused_norm_ok(n, h, w, c, rows, ld):
     tpi = (h // 4) * (w // 4)
-    return (P().fused_norm and P().gemm_split and P().gemm_f16x2 and P().gemm_af32 and not P().half and ld in (128, 160) and rows == 2 * c
+    return (P().fused_norm and P().gemm_split and P().gemm_f16x2 and P().gemm_af32 and ld in (128, 160) and rows == 2 * c
             and c % 32 == 0 and h % 4 == 0 and w % 4 == 0 and tpi % 64 == 0
             and 36 * n * tpi * ld * 4 < 0xFFFFFFF0 and 36 * n * rows * ld * 4 < 0xFFFFFFF0)
+
+
+def _norm_plan(plan):
+    """The plan a SPADE/SEAN norm runs under: in the 16-bit mode with plan.half_norms off the norm's own GEMMs stay on the
+    two-term kernels of the fp32 path (its output h still carries max |h|, so the convolution behind it runs one-term)."""
+    return plan.replace(half=False) if (plan.half and not plan.half_norms) else plan
 
 
 class SeanNormTable(torch.autograd.Function):
@@ -1404,10 +1479,10 @@ class SeanNormTable(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, *args):
-        ctx.plan = P()
+        ctx.plan = _norm_plan(P())
         n, h, w, c = x.shape
         # bench.py: the whole forward on SURVEY 8(d)'s algorithmic bytes (x twice, out, the 128-channel embedding, labels)
-        with _timed("norm_forward@%dx%d" % (h, w), 0.0, 4.0 * n * h * w * (3 * c + NHIDDEN) + n * h * w):
+        with _timed("norm_forward@%dx%d" % (h, w), 0.0, 4.0 * n * h * w * (3 * c + NHIDDEN) + n * h * w), ctx.plan.active():
             return SeanNormTable._forward(ctx, x, *args)
 
     @staticmethod
@@ -1459,14 +1534,16 @@ class SeanNormTable(torch.autograd.Function):
             kp = L.kpad(1, 1, ld)
             t = n * (h // 4) * (w // 4)
             ac = cat_amax if cat_amax is not None else tensor_amax(cat)
-            v2 = _i16(36 * t * ld * 2)
-            L.call("wino43_input_f16x2", cat, v2, n, h, w, ld, ac, FUSED_V_BOUND)
+            pk = P().half       # 16-bit storage mode: packed one-term operands, one MFMA product (dsee_spade_fused_fwd_f16p)
+            sp = 4 if pk else 2
+            v2 = _i16(36 * t * ld * (1 if pk else 2))
+            L.call("wino43_input_f16p" if pk else "wino43_input_f16x2", cat, v2, n, h, w, ld, ac, FUSED_V_BOUND)
             if has_t:
                 ua = weight_amax(w2a if has_a else None, tb)
-                u = _i16(36 * n * rows * kp * 2)
-                L.call("wino43_weights_table", w2a if has_a else None, tb, u, n, rows, ca, 2, ua)
+                u = _i16(36 * n * rows * kp * (1 if pk else 2))
+                L.call("wino43_weights_table", w2a if has_a else None, tb, u, n, rows, ca, sp, ua)
             else:
-                u, ua = _wino_u(w2a, rows, ca, False, rows, kp, 2)
+                u, ua = _wino_u(w2a, rows, ca, False, rows, kp, sp)
             if PROFILE is not None:
                 global PROFILE_OPERAND_GB
                 PROFILE_OPERAND_GB += (t // 64) * (rows // 64) * 36 * 2 * 64 * ld * 4.0 / 1e9
@@ -1474,7 +1551,7 @@ class SeanNormTable(torch.autograd.Function):
                         4.0 * 36 * t * ld + 4.0 * n * h * w * c * (3 if need_scale else 2)):
                 hm = amax_slot()     # max |h|: the convolution that consumes h writes its V pre-split with this bound
                 xm = amax_slot() if need_scale else None     # max |xhat|: bounds the backward pass's gamma/beta gradient
-                L.call("spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
+                L.call("spade_fused_fwd_f16p" if pk else "spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
                        scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE,
                        hm, xm)
                 tag_amax(out, hm)
@@ -1482,7 +1559,7 @@ class SeanNormTable(torch.autograd.Function):
             keep = None
             if P().keep_v and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
                 if P().presplit_a:
-                    keep = [(v2, ac, True)]     # the weight / table gradient reads the split V the kernel above consumed
+                    keep = [(v2, ac, "pk" if pk else True)]     # the weight / table gradient reads the split V the kernel above consumed
                 else:
                     # ... or an fp32 V of its own as its Q operand
                     vq = (new(36, t, ld), amax_slot())
@@ -1518,7 +1595,7 @@ class SeanNormTable(torch.autograd.Function):
         ctx.geom, ctx.labels, ctx.shift, ctx.has_a, ctx.has_t, ctx.rows = geom, labels, shift, has_a, has_t, rows
         ctx.cat_ups = cat_ups
         vcat = keep[0] if (nb and keep) else (None, None)
-        ctx.v_pre = len(vcat) == 3
+        ctx.v_kind = vcat[2] if len(vcat) == 3 else None
         ctx.w_amax = getattr(w2a, "dsee_amax", None) if has_a else None
         ctx.save_for_backward(x, cat, w2a if has_a else None, out, scale, mean, invstd, *vcat[:2], actv_low)
         return out
@@ -1529,7 +1606,7 @@ class SeanNormTable(torch.autograd.Function):
         x, cat, w2a, out, scale, mean, invstd, vc, vc_amax, actv_low = ctx.saved_tensors
         if w2a is not None:
             w2a.dsee_amax = ctx.w_amax     # (an upper bound: the slot also holds max |style table|)
-        vcat = ((vc, vc_amax, True) if ctx.v_pre else (vc, vc_amax)) if vc is not None else None
+        vcat = ((vc, vc_amax, ctx.v_kind) if ctx.v_kind else (vc, vc_amax)) if vc is not None else None
         geom, lab, shift, rows = ctx.geom, ctx.labels, ctx.shift, ctx.rows
         n, h, w, c = x.shape
         ld = cat.shape[3]
@@ -1556,7 +1633,8 @@ class SeanNormTable(torch.autograd.Function):
             tpi, ca = (h // 4) * (w // 4), (NHIDDEN if ctx.has_a else 0)
             if fused_d:
                 rows_t = L.wrows(NHIDDEN)
-                u_t = _wino_u(w2a, rows, NHIDDEN, 2, rows_t, L.kpad(1, 1, rows), _split_kind(rows, NHIDDEN))
+                u_t = _wino_u(w2a, rows, NHIDDEN, 2, rows_t, L.kpad(1, 1, rows),
+                              4 if _is_pk(dm_all) else _split_kind(rows, NHIDDEN))
                 dactv_fused[0] = new(n, h, w, NHIDDEN) if nb != n else None
             if ctx.has_t:
                 nbytes = L.lib().dsee_wino43_wgrad_table_workspace(C.c_long(nb * tpi), nb, ca, rows)
@@ -1572,10 +1650,10 @@ class SeanNormTable(torch.autograd.Function):
                 with _timed(_wgrad_name(mode), 2.0 * 36 * nb * tpi * ld * rows):
                     if ctx.has_t:
                         L.call("wino43_wgrad_table", v[0], dm[0], wsw, nbytes, dwc, dtable[n0:n0 + nb], nb * tpi, nb, ca,
-                               rows, lab.nc, (6 if len(dm) == 3 else 5) if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
+                               rows, lab.nc, _wgrad_code(v, dm, mode), v[1], dm[1])
                     else:
                         L.call("wino43_wgrad", v[0], dm[0], wsw, nbytes, dwc, nb * tpi, ld, rows, rows, NHIDDEN,
-                               (6 if len(dm) == 3 else 5) if len(v) == 3 else _wgrad_split(mode), v[1], dm[1])
+                               _wgrad_code(v, dm, mode), v[1], dm[1])
                 if dwc is not None:
                     dw2a = dwc if dw2a is None else dw2a.add_(dwc)
                 if fused_d:

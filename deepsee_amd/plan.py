@@ -41,6 +41,10 @@ class KernelPlan:
     # optimizer stay fp32.  fp16 and not bf16 because the F(4x4,3x3) transforms amplify operand rounding ~10x (per-layer
     # error 2.6 % with bf16 operands, 0.33 % with scaled fp16; a direct bf16 convolution: 0.24 %).
     half: bool = False
+    # ... and in that mode the gamma/beta convolution of the SPADE/SEAN norms (K = 128 / 160 -> 1024 rows) as well; False keeps
+    # the norms on the two-term fp16x2 kernels of the fp32 path (fused forward, pre-split gradient) while the 512 -> 512
+    # convolutions run one-term
+    half_norms: bool = True
     # A operand of a forward Winograd GEMM written pre-split by the input transform (False: fp32 V, split inside the GEMM)
     presplit_a: bool = True
     # A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)

@@ -158,6 +158,39 @@ int dsee_gemm_f16x2_tn_qpre(const float* P, const void* Q2, float* C, int groups
 int dsee_gemm_f16x2_tn_pqpre(const void* P2, const void* Q2, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                              int splits, const float* amax_dy, float p_bound, const float* amax_x, float q_bound,
                              hipStream_t stream);
+/* ---- 16-bit STORAGE mode (round 4; opt.precision = "fp16", BASELINE.json configs[2]'s 16-bit arithmetic for the layers of
+ * architecture.py:98,122 and normalization.py:107-120,167-213): the Winograd-domain operands are written by their producers as
+ * ONE scaled fp16 term per element in the "packed one-term" image -- [K/32][rows][32] fp16, i.e. the 64-byte rows of the
+ * fp16x2 image holding 32 k's of one term instead of 2 terms x 16 k's -- so every pre-split kernel streams them through the
+ * same LDS-DMA path with half the bytes and one MFMA product per multiply-add (fp32 accumulate); the products M / dV leave
+ * the GEMM as scaled fp16.  Producers: dsee_wino43_input_f16p, dsee_wino43_dout_f16p, dsee_modulate_bwd_reduce_wino_f16p,
+ * dsee_wino43_weights[_table] (split = 4).  fp32 everywhere else (activations, statistics, master weights, Adam). */
+int dsee_gemm_f16p_pre(const void* A1, const void* B1, void* C16, long M, int N, int K, long rows_per_group, int b_rows,
+                       const float* amax_a, float a_bound, const float* amax_b, float* cscale, hipStream_t stream);
+int dsee_gemm_f16p_tn_pqpre(const void* P1, const void* Q1, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
+                            int splits, const float* amax_dy, float p_bound, const float* amax_x, float q_bound,
+                            hipStream_t stream);
+int dsee_modulate_bwd_reduce_wino_f16p(const float* dh, const float* h, const float* x, const float* scale,
+                                       const float* mean, const float* invstd, void* dM1, int rows, float* sums, int N,
+                                       int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
+                                       hipStream_t stream);
+int dsee_spade_fused_fwd_f16p(const void* V1, const void* U1, const float* amax_cat, float v_bound, const float* amax_u,
+                              const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
+                              float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
+                              float slope, float* amax_h, float* amax_xhat, hipStream_t stream);
+int dsee_wino43_input_f16p(const float* x, void* V1, int N, int H, int W, int C, const float* amax_x, float bound,
+                           hipStream_t stream);
+int dsee_wino43_dout_f16p(const float* dy, void* dM1, int N, int H, int W, int C, const float* amax_dy, float bound,
+                          float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
+                          float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t stream);
+/* output / adjoint-input transforms of the scaled-fp16 products (mscale / dvscale = the GEMM's *cscale) that also emit the
+ * BatchNorm statistics rows / max |dx| their fp32 counterparts emit */
+int dsee_wino43_output_stats_f16(const void* M16, const float* bias, const float* residual, int residual_ld, float* y, int N,
+                                 int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
+                                 uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
+                                 uint64_t res_noise_offset, const float* mscale, float* stats_part, hipStream_t stream);
+int dsee_wino43_input_adjoint_amax_f16(const void* dV16, float* dx, int N, int H, int W, int C, const float* dvscale,
+                                       float* amax_dx, hipStream_t stream);
 /* Evaluation metrics on the device: per image PSNR, SSIM and RMSE of `fake` against `real`, both fp32 NHWC
  * [N][H][W][Cs] in [-1, 1] (channels 0..2 used).  Replaces MetricsEvaluator.collect_samples' per-sample CPU loop
  * (evaluator/evaluation.py:88-137: util/util.py:72-103 tensor2im quantisation, evaluator/calculate_PSNR_SSIM.py:71-79

@@ -601,74 +601,105 @@ def test_two_gpu_rccl_data_parallel(sync_bn):
 
 
 def test_half_mode_tracks_fp32():
-    """BASELINE configs[2]'s 16-bit arithmetic (opt.precision = 'fp16': Winograd-domain GEMMs on one-term scaled-fp16
-    operands, products stored as scaled fp16, fp32 master weights / statistics / Adam) against the fp32 HIP path as SURVEY
-    8(d) prescribes: generated image within 3e-2 after the first step; the losses of the first two iterations within 5 %
-    of the fp32 run, and the trajectories keep overlapping over 6 iterations (two fp32 runs that differ by one rounding
-    drift apart at the same rate: beta1 = 0 Adam steps by lr * sign(g), so later iterations are only held to a factor 1.5)."""
+    """BASELINE configs[2]'s 16-bit mode (opt.precision = 'fp16': every Winograd-domain GEMM on ONE scaled fp16 term per operand
+    element, stored as such -- packed one-term V / dM / weights, fp16 products M / dV -- fp32 master weights / statistics /
+    Adam) against the fp32 HIP path as SURVEY 8(d) prescribes: generated image within 3e-2 after the first step, the losses of
+    the first two iterations within 5 % of the fp32 run, and the loss trajectories overlapping over 50 iterations (two fp32
+    runs that differ by one rounding drift apart at the same rate -- beta1 = 0 Adam steps by lr * sign(g) -- so later
+    iterations are compared as window means, and the last window against a YARDSTICK: a second fp32-class run of the same
+    model on the exact 3-term bf16 split instead of the two-term fp16 split, i.e. how far two fp32 trajectories of this GAN
+    on a fixed batch of 2 drift apart from rounding alone).  Both norm variants of the mode run: the gamma/beta path
+    one-term (plan.half_norms, default) and two-term."""
     from deepsee_amd import ops
     from deepsee_amd.managers import TrainerManager
     from deepsee_amd.options import make_opt
     over = dict(batchSize=2, seed=11)
     batch = O.synthetic_batch(O.make_opt(batchSize=2), 2, seed=5)
+    iters = 50
     runs = {}
-    try:
-        for prec in ("fp32", "fp16"):
-            tm = TrainerManager(make_opt(precision=prec, **over))
-            assert tm.sr_model.plan.half == (prec == "fp16")
-            traj, fake0 = [], None
-            for it in range(6):
-                tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
-                if it == 0:
-                    fake0 = tm.get_latest_generated().detach().cpu()
-                tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
-                traj.append({k: float(v.detach()) for k, v in tm.get_latest_losses().items()})
-            torch.cuda.synchronize()
-            runs[prec] = (fake0, traj)
-            del tm
-    finally:
-        pass     # (the precision is the model's own plan: nothing process-wide to restore)
-    dev = rel(runs["fp16"][0], runs["fp32"][0])
-    print("fp16 mode vs fp32: |fake| deviation %.2e; losses at iteration 6: %s vs %s" % (dev, runs["fp16"][1][-1], runs["fp32"][1][-1]))
-    assert dev < 3e-2, dev
-    for it, (a, b) in enumerate(zip(runs["fp16"][1], runs["fp32"][1])):
-        for k in a:
-            assert a[k] == a[k] and abs(a[k]) < 1e4, (it, k, a[k])
-            tol = 0.05 if it < 2 else 0.5
-            assert abs(a[k] - b[k]) <= tol * abs(b[k]) + 0.05, (it, k, a[k], b[k])
+    for name, kw in (("fp32", dict(precision="fp32")), ("fp16", dict(precision="fp16")),
+                     ("fp32/bf16x3", dict(precision="fp32", kernel_plan=dict(gemm_f16x2=False))),
+                     ("fp16/two-term norms", dict(precision="fp16", kernel_plan=dict(half_norms=False)))):
+        tm = TrainerManager(make_opt(**kw, **over))
+        assert tm.sr_model.plan.half == name.startswith("fp16")
+        ops.PROFILE = prof = {}
+        traj, fake0 = [], None
+        for it in range(iters if name != "fp16/two-term norms" else 6):
+            tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
+            if it == 0:
+                fake0 = tm.get_latest_generated().detach().cpu()
+                ops.PROFILE = None
+            tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
+            traj.append({k: float(v.detach()) for k, v in tm.get_latest_losses().items()})
+        torch.cuda.synchronize()
+        runs[name] = (fake0, traj, sorted(prof))
+        del tm
+    # the 16-bit mode really runs the packed one-term kernels (a silent fall-back to fp32 operands would pass the bounds too)
+    assert "winograd_gemm_f16_1term_packed" in runs["fp16"][2] and "winograd_gemm_f16x2" not in runs["fp16"][2], runs["fp16"][2]
+    assert "winograd_gemm_f16_1term_packed" in runs["fp16/two-term norms"][2]
+    ref = runs["fp32"]
+    for name in ("fp16", "fp16/two-term norms"):
+        dev = rel(runs[name][0], ref[0])
+        print("%s vs fp32: |fake| deviation %.2e" % (name, dev))
+        assert dev < 3e-2, (name, dev)
+        for it, (a, b) in enumerate(zip(runs[name][1], ref[1])):
+            for k in a:
+                assert a[k] == a[k] and abs(a[k]) < 1e4, (name, it, k, a[k])
+                if it < 2:
+                    assert abs(a[k] - b[k]) <= 0.05 * abs(b[k]) + 0.05, (name, it, k, a[k], b[k])
+    rows = []
+    for lo, hi in ((0, 10), (10, 30), (30, 50)):
+        for k in ref[1][0]:
+            ma = sum(d[k] for d in runs["fp16"][1][lo:hi]) / (hi - lo)
+            mb = sum(d[k] for d in ref[1][lo:hi]) / (hi - lo)
+            my = sum(d[k] for d in runs["fp32/bf16x3"][1][lo:hi]) / (hi - lo)
+            rows.append((lo, hi, k, ma, mb, my))
+    print("\n".join("iterations %2d-%2d  %-8s fp16 %9.4f   fp32 %9.4f   fp32 on the exact bf16x3 split %9.4f" % r for r in rows))
+    for lo, hi, k, ma, mb, my in rows:
+        tol = 0.3 * abs(mb) + 0.15
+        if lo >= 30:       # chaotic regime of the two-image GAN: no further than 3x what fp32 rounding alone does
+            tol = max(tol, 3.0 * abs(my - mb))
+        assert abs(ma - mb) <= tol, (lo, hi, k, ma, mb, my)
 
 
-def test_half_mode_vs_oracle():
-    """The 16-bit compute mode against the CPU ORACLE (not only against the fp32 HIP path): one G step of BASELINE
-    configs[1]'s geometry at bs = 1 on identical weights, inputs, noise and branch decisions; generated image within SURVEY
-    8(d)'s 3e-2, generator losses within 5 %."""
+@pytest.mark.parametrize("bs", [1, 8])
+def test_half_mode_vs_oracle(bs):
+    """The 16-bit mode against the CPU ORACLE (not only against the fp32 HIP path): one G step of BASELINE configs[1]'s
+    geometry on identical weights, inputs, noise and branch decisions -- at bs = 1 and at the benchmark's bs = 8 (the oracle
+    needs ~60 GB of host memory there; skipped below 90 GB): generated image within SURVEY 8(d)'s 3e-2, generator losses
+    within 5 %."""
+    import os
     from deepsee_amd import networks as N, ops
     from deepsee_amd.managers import TrainerManager
     from deepsee_amd.options import make_opt
-    over = dict(batchSize=1)
+    if bs > 1:
+        try:
+            ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9
+        except (ValueError, OSError):
+            ram_gb = 0.0
+        if ram_gb < 90:
+            pytest.skip("the fp32 oracle at bs = 8 needs ~60 GB of host memory (%.0f GB here)" % ram_gb)
+    over = dict(batchSize=bs)
     oopt = O.make_opt(**over)
     states = O.recipe_state(oopt, gain=1.0)
-    batch = O.synthetic_batch(oopt, 1, seed=31)
+    batch = O.synthetic_batch(oopt, bs, seed=31)
     ctl = O.RecordingCtl()
     orc = O.Oracle(oopt, states, ctl)
     orc.create_optimizers()
     random.seed(31)
     torch.manual_seed(31)
     gl, fake = orc.run_generator_one_step({k: v.clone() for k, v in batch.items()})
-    try:
-        tm = TrainerManager(make_opt(precision="fp16", **over))
-        assert tm.sr_model.plan.half
-        tm.sr_model.load_states(states)
-        tm.sr_model.noise = N.ReplayNoise(ctl.tape)
-        tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
-        torch.cuda.synchronize()
-        hfake = tm.get_latest_generated().detach().cpu()
-        hgl = {k: float(v) for k, v in tm.g_losses.items()}
-    finally:
-        pass     # (the precision is the model's own plan: nothing process-wide to restore)
+    tm = TrainerManager(make_opt(precision="fp16", **over))
+    assert tm.sr_model.plan.half and tm.sr_model.plan.half_norms
+    tm.sr_model.load_states(states)
+    tm.sr_model.noise = N.ReplayNoise(ctl.tape)
+    tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
+    torch.cuda.synchronize()
+    hfake = tm.get_latest_generated().detach().cpu()
+    hgl = {k: float(v) for k, v in tm.g_losses.items()}
     dev = rel(hfake, fake.detach())
-    print("fp16 mode vs the CPU oracle: |fake - oracle| / |oracle| = %.2e, losses %s vs %s"
-          % (dev, {k: round(v, 4) for k, v in hgl.items()}, {k: round(float(v.detach()), 4) for k, v in gl.items()}))
+    print("fp16 mode vs the CPU oracle at bs = %d: |fake - oracle| / |oracle| = %.2e, losses %s vs %s"
+          % (bs, dev, {k: round(v, 4) for k, v in hgl.items()}, {k: round(float(v.detach()), 4) for k, v in gl.items()}))
     assert dev < 3e-2, dev
     for k, v in gl.items():
         assert abs(hgl[k] - float(v.detach())) <= 0.05 * abs(float(v.detach())) + 1e-3, (k, hgl[k], float(v.detach()))
