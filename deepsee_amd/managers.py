@@ -61,7 +61,9 @@ class TrainerManager(BaseManager):
     the variant to replay is known before it runs.  The first occurrence of a variant runs eagerly (it also sizes every
     workspace), the second is captured, later ones replay.  All graphs share one memory pool: a replay invalidates the
     activations of the previous one, which is why losses / the generated image are copied out after every replay.
-    Data-parallel runs capture everything up to the backward pass and keep the all-reduce + Adam eager."""
+    Data-parallel runs capture the chunked RCCL all-reduce and the per-chunk Adam launches as well (opt.dp_graph_collectives,
+    default on: collectives are capturable, the graph then is the whole step and a rank's host does one launch per half step);
+    with the option off everything up to the backward pass is replayed and the all-reduce + Adam run eagerly behind it."""
 
     def __init__(self, opt):
         super().__init__(opt, create_model=True)
@@ -72,6 +74,7 @@ class TrainerManager(BaseManager):
         self.logs = {}
         self.g_losses, self.d_losses = {}, {}
         self.use_graphs = bool(getattr(opt, "hip_graphs", False))
+        self.dp_in_graph = bool(getattr(opt, "dp_graph_collectives", True))
         self._graphs, self._seen, self._static, self._pool = {}, {}, {}, None
         self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0}
 
@@ -184,13 +187,14 @@ class TrainerManager(BaseManager):
             ops.begin_capture()
             # thread-local capture mode: RCCL's watchdog thread (event queries, in a data-parallel run) must not
             # invalidate a capture in progress on this thread
+            eager_opt = multi and not self.dp_in_graph       # all-reduce + Adam outside the graph
             with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
-                losses, generated = step_fn(sd, pinned=pinned, opt_step=not multi)
+                losses, generated = step_fn(sd, pinned=pinned, opt_step=not eager_opt)
             ops.begin_capture()                   # (pools created on the capture stream belong to the graph)
             noise.step, noise.offset = state      # the capture ran the Python side once; the replay below is the real step
             # tensors the forward leaves in model.logs live in the shared graph pool as well: copied out after every replay
             logged = {k: v for k, v in model.logs.items() if isinstance(v, torch.Tensor)} if which == "G" else {}
-            rec = {"graph": g, "losses": losses, "generated": generated, "pinned": pinned,
+            rec = {"graph": g, "losses": losses, "generated": generated, "pinned": pinned, "eager_opt": eager_opt,
                    "grads": [p.grad for p in optim.params], "full": model.last_encoded_style_is_full,
                    "noisy": model.last_encoded_style_is_noisy,
                    "out_losses": {k: torch.empty_like(v) for k, v in losses.items()},
@@ -204,7 +208,7 @@ class TrainerManager(BaseManager):
         noise.step += 1
         model.last_encoded_style_is_full, model.last_encoded_style_is_noisy = rec["full"], rec["noisy"]
         rec["graph"].replay()
-        if multi:
+        if rec["eager_opt"]:
             for p, g in zip(optim.params, rec["grads"]):   # the gradient tensors this graph writes (static addresses)
                 p.grad = g
             optim.step(clip=self.opt.gradient_clip)

@@ -165,7 +165,9 @@ class FlatAdam:
         ptrs = np.array([0 if g is None else g.data_ptr() for g in grads], dtype=np.int64)
         self.touched = (ptrs != 0).astype(np.int32)
         if capturing:
-            assert pinned is not None and not multi, "graph capture: caller-owned staging buffer, single rank"
+            # (data parallel: the chunked all-reduce below is captured too -- RCCL collectives are capturable; the graph then
+            # holds forward + backward + gather + every chunk's all-reduce / Adam pair and a rank's host does ONE launch)
+            assert pinned is not None, "graph capture: caller-owned staging buffer"
             pinned.copy_(torch.from_numpy(ptrs))
             self._ptr_dev.copy_(pinned, non_blocking=True)
         else:
