@@ -451,6 +451,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        tm.release_graphs()          # (the graphs hold captured RCCL operations: gone before their communicator)
         dist.destroy_process_group()
 
 

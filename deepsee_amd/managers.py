@@ -61,9 +61,10 @@ class TrainerManager(BaseManager):
     the variant to replay is known before it runs.  The first occurrence of a variant runs eagerly (it also sizes every
     workspace), the second is captured, later ones replay.  All graphs share one memory pool: a replay invalidates the
     activations of the previous one, which is why losses / the generated image are copied out after every replay.
-    Data-parallel runs capture the chunked RCCL all-reduce and the per-chunk Adam launches as well (opt.dp_graph_collectives,
-    default on: collectives are capturable, the graph then is the whole step and a rank's host does one launch per half step);
-    with the option off everything up to the backward pass is replayed and the all-reduce + Adam run eagerly behind it."""
+    Data-parallel runs replay everything up to the backward pass + gradient gather and issue the chunked all-reduce + per-chunk
+    Adam eagerly behind it (~12 launches per half step).  opt.dp_graph_collectives captures those as well (the graph is then
+    the whole step, bit-identical results) but is OFF by default: capturing RCCL operations aborts intermittently inside the
+    HIP runtime on this stack (tests/test_gpu_model.py::test_dp_collectives_captured_inside_the_graph_world1)."""
 
     def __init__(self, opt):
         super().__init__(opt, create_model=True)
@@ -74,7 +75,7 @@ class TrainerManager(BaseManager):
         self.logs = {}
         self.g_losses, self.d_losses = {}, {}
         self.use_graphs = bool(getattr(opt, "hip_graphs", False))
-        self.dp_in_graph = bool(getattr(opt, "dp_graph_collectives", True))
+        self.dp_in_graph = bool(getattr(opt, "dp_graph_collectives", False))
         self._graphs, self._seen, self._static, self._pool = {}, {}, {}, None
         self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0}
 
@@ -222,6 +223,20 @@ class TrainerManager(BaseManager):
                 rec["out_logs"][k].dsee_layout = v.dsee_layout
             model.logs[k] = rec["out_logs"][k]
         return rec["out_losses"], rec["out_generated"]
+
+    def release_graphs(self):
+        """Drop every captured graph (and its static buffers).  Call it BEFORE torch.distributed.destroy_process_group() in a
+        data-parallel run: with opt.dp_graph_collectives the graphs hold captured RCCL operations, and destroying them after
+        their communicator is gone can abort the process at exit."""
+        if self._graphs:
+            torch.cuda.synchronize()
+        self._graphs.clear()
+        self._seen.clear()
+        self._static.clear()
+        import gc
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     def get_latest_losses(self):
         return {**self.g_losses, **self.d_losses}

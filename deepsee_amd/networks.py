@@ -571,6 +571,7 @@ class VGG19Taps(nn.Module):
             idx += 2
         for p in self.parameters():
             p.requires_grad = False
+            p.dsee_frozen = True     # ops._frozen_cache: packed weights and their maxima are built once, not per forward
 
     def forward(self, x):
         feats, idx = [], 0

@@ -188,20 +188,48 @@ def rng_fill(shape, seed, offset, normal=True):
 
 
 # ------------------------------------------------------------------------------------ convolution
+def _frozen_cache(w, key, build):
+    """Weight-derived tensors of a FROZEN parameter (the VGG19 taps: requires_grad False, never stepped) are built once and
+    kept on the parameter, keyed by its version: 13 layers x 2 passes x (pack + max |w|) launches per step otherwise."""
+    # (opt-in by the owner -- networks.VGG19Taps marks its parameters `dsee_frozen`: "requires_grad is False" alone also holds for
+    # the discriminator's weights during the generator step, and the fused Adam kernel does not bump tensor versions)
+    if not getattr(w, "dsee_frozen", False) or w.requires_grad:
+        return build()
+    cache = w.__dict__.setdefault("_dsee_frozen", {})
+    if cache.get("version") != w._version or cache.get("ptr") != w.data_ptr():
+        cache.clear()
+        cache["version"], cache["ptr"] = w._version, w.data_ptr()
+    if key not in cache:
+        if torch.cuda.is_current_stream_capturing():
+            return build()       # (a tensor allocated inside a capture lives in the graph's pool: not cacheable)
+        cache[key] = build()
+    return cache[key]
+
+
 def _pack_fwd(w, cin_s, korder):
-    co, ci, kh, kw = w.shape
-    wp = new(L.wrows(L.pad4(co)), L.kpad(kh, kw, cin_s))
-    L.call("pack_weight_fwd", w, None, None, wp, co, ci, kh, kw, cin_s, korder)
-    wp.dsee_amax = getattr(w, "dsee_amax", None)     # (a permutation + zero padding of w: same maximum)
-    return wp
+    def build():
+        co, ci, kh, kw = w.shape
+        wp = new(L.wrows(L.pad4(co)), L.kpad(kh, kw, cin_s))
+        L.call("pack_weight_fwd", w, None, None, wp, co, ci, kh, kw, cin_s, korder)
+        wp.dsee_amax = getattr(w, "dsee_amax", None)     # (a permutation + zero padding of w: same maximum)
+        if wp.dsee_amax is None and getattr(w, "dsee_frozen", False):
+            wp.dsee_amax = torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=wp.device)
+            L.call("absmax", wp, wp.numel(), wp.dsee_amax)
+        return wp
+    return _frozen_cache(w, ("fwd", cin_s, korder), build)
 
 
 def _pack_dgrad(w, cout_s, korder):
-    co, ci, kh, kw = w.shape
-    wp = new(L.wrows(L.pad4(ci)), L.kpad(kh, kw, cout_s))
-    L.call("pack_weight_dgrad", w, None, None, wp, co, ci, kh, kw, cout_s, korder)
-    wp.dsee_amax = getattr(w, "dsee_amax", None)
-    return wp
+    def build():
+        co, ci, kh, kw = w.shape
+        wp = new(L.wrows(L.pad4(ci)), L.kpad(kh, kw, cout_s))
+        L.call("pack_weight_dgrad", w, None, None, wp, co, ci, kh, kw, cout_s, korder)
+        wp.dsee_amax = getattr(w, "dsee_amax", None)
+        if wp.dsee_amax is None and getattr(w, "dsee_frozen", False):
+            wp.dsee_amax = torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=wp.device)
+            L.call("absmax", wp, wp.numel(), wp.dsee_amax)
+        return wp
+    return _frozen_cache(w, ("dgrad", cout_s, korder), build)
 
 
 def tensor_amax(t, cache=None):
@@ -367,10 +395,16 @@ def _wino_u(w, co, ci, transpose_flip, rows, kp, split):
     pre = getattr(w, "dsee_u", None)
     if pre is not None and (int(transpose_flip), int(split), rows, kp) in pre:
         return pre[(int(transpose_flip), int(split), rows, kp)]       # transformed with its whole network (SNGroup.wino_weights)
-    amax = weight_amax(w) if split >= 2 else None
-    u = _i16(36 * rows * kp * {1: 3, 2: 2, 3: 1, 4: 1}[split]) if split else new(36, rows, kp)
-    L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split), amax)
-    return u, amax
+    def build():
+        if split >= 2 and getattr(w, "dsee_frozen", False):
+            amax = torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=w.device)     # (kept with the cached U: not a pool slot)
+            L.call("absmax", w, w.numel(), amax)
+        else:
+            amax = weight_amax(w) if split >= 2 else None
+        u = _i16(36 * rows * kp * {1: 3, 2: 2, 3: 1, 4: 1}[split]) if split else new(36, rows, kp)
+        L.call("wino43_weights", w, u, co, ci, int(transpose_flip), int(split), amax)
+        return u, amax
+    return _frozen_cache(w, ("u", int(transpose_flip), int(split), rows, kp), build)
 
 
 def _gemm_bytes(t, k_s, r_s, groups, rows, split):
@@ -1308,7 +1342,9 @@ class TableLayout(torch.autograd.Function):
 def style_table_packed(style, wst, rows, amax=None):
     """T[n][tap][row][r(32)] = sum_s wst[tap*rows + row][s] * style[n][r][s]: one GEMM on parameter-sized operands
     (rocBLAS through torch.matmul, see _style_gemm) + the layout kernel.  `amax`: slot that receives max |T| (on top of
-    what it holds: max |w2a| from SeanPack) -- the operand bound of the gamma/beta GEMM's weights."""
+    what it holds: max |w2a| from SeanPack) -- the operand bound of the gamma/beta GEMM's weights.
+    (Round 4 tried hand-written VALU kernels for this 152 x 128 x 9216 product and its two gradients: 34 / 71 / 225 us against
+    20 / 30 / 20 us for the library -- profiles/r04_notes.md -- and kept the library call.)"""
     n, nc, s = style.shape
     t = TableLayout.apply(_style_gemm(style.reshape(n * nc, s), wst), n, nc, rows, amax)
     t.dsee_amax = amax

