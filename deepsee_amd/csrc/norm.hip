@@ -368,18 +368,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // The same 36 values written into the PRE-SPLIT fp16x2 image dM2 [rows/16][36*T][2][16] (winograd.hip:
 // wino43_dout_f16x2_kernel): the four lanes of a 16-column slab (consecutive channel quads, same tile) exchange halves so
 // that every lane stores 16 contiguous bytes of the 64-byte row (term 0 | term 1).  `l` = lane, col = packed column.
-__device__ __forceinline__ void store_ata_split(const f32x4 (&v)[4][4], unsigned char* __restrict__ dM2, long T, long t,
-                                                int col, float sc, int l) {
-  f32x4 tmp[6][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    f32x4 c4[4], o[6];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c4[k] = v[k][j];
-    a6n(c4, o);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
-  }
+// (`tmp` = A v, the column half of A v A^T, formed by the caller: the reduce kernel builds it column by column while its loads
+// arrive, so that g * xhat itself never has to be held -- 330 -> <= 256 registers, two waves per SIMD instead of one)
+__device__ __forceinline__ void store_ata_rows_split(const f32x4 (&tmp)[6][4], unsigned char* __restrict__ dM2, long T, long t,
+                                                     int col, float sc, int l) {
   const bool odd = (l & 1) != 0;
   const size_t slab = (size_t)36 * T * 64;
   unsigned char* rowp = dM2 + (size_t)(col >> 4) * slab + (size_t)t * 64 + (odd ? 32 + ((l & 3) - 1) * 8 : (l & 3) * 8);
@@ -411,18 +403,8 @@ __device__ __forceinline__ void store_ata_split(const f32x4 (&v)[4][4], unsigned
 
 // ... and into the PACKED ONE-TERM image dM1 [rows/32][36*T][32] fp16 of the 16-bit storage mode (one scaled fp16 term per
 // element; lane pairs exchange halves across pairs of positions, dsee_common.h)
-__device__ __forceinline__ void store_ata_pk(const f32x4 (&v)[4][4], unsigned char* __restrict__ dM1, long T, long t, int col,
-                                             float sc, int l) {
-  f32x4 tmp[6][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    f32x4 c4[4], o[6];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c4[k] = v[k][j];
-    a6n(c4, o);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) tmp[k][j] = o[k];
-  }
+__device__ __forceinline__ void store_ata_rows_pk(const f32x4 (&tmp)[6][4], unsigned char* __restrict__ dM1, long T, long t,
+                                                  int col, float sc, int l) {
   const bool odd = (l & 1) != 0;
   const size_t slab = (size_t)36 * T * 64;
   unsigned char* rowp = dM1 + (size_t)(col >> 5) * slab + (size_t)t * 64 + (((col & 31) >> 2) & ~1) * 8;
@@ -507,7 +489,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_kernel(
 // (gridDim.x * 4 is a multiple of C/64); the per-channel sums are folded over the wave's 4 tile lanes and written as
 // part[global wave][4][64], summed per channel group in wave order by norm_bwd_split_sums_kernel.
 template <bool PK>
-__global__ __launch_bounds__(256) void norm_bwd_reduce_wino_split_kernel(
+__global__ __launch_bounds__(256, 2) void norm_bwd_reduce_wino_split_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
     unsigned char* __restrict__ dM2, float* __restrict__ part, int N, int H, int W, int C, float slope,
@@ -525,15 +507,18 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_split_kernel(
   for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long t = ((i >> 6) / ncg) * 4 + (l >> 4);
-    const int tx = (int)(t % tw);
+    const int tx_ = (int)(t % tw);
     const long r = t / tw;
     const int ty = (int)(r % th), n = (int)(r / th);
-    f32x4 gg[4][4], gx[4][4];
+    // column j of the tile at a time: g is kept (its own transform follows), g * xhat goes straight into the column half of
+    // its transform
+    f32x4 gg[4][4], tx[6][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 4; ++j) {
+      f32x4 cx[4], o6[6];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const size_t o = (((size_t)n * H + ty * 4 + k) * W + tx * 4 + j) * C + c0;
+      for (int k = 0; k < 4; ++k) {
+        const size_t o = (((size_t)n * H + ty * 4 + k) * W + tx_ * 4 + j) * C + c0;
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
         const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
@@ -542,19 +527,34 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_split_kernel(
         for (int e = 0; e < 4; ++e) g[e] = dv[e] * (yv[e] > 0.f ? 1.f : slope);
         const f32x4 d = g * *reinterpret_cast<const f32x4*>(scale + o);
         gg[k][j] = g;
-        gx[k][j] = g * xh;
+        cx[k] = g * xh;
         acc[0] += d;
         acc[1] += d * xh;
-        acc[2] += gx[k][j];
+        acc[2] += cx[k];
         acc[3] += g;
+        if (k == 1) __builtin_amdgcn_sched_barrier(0);   // (8 loads per scheduling group: see below)
       }
-    if constexpr (PK) {
-      store_ata_pk(gx, dM2, T, t, pcol, sc, l);
-      store_ata_pk(gg, dM2, T, t, pcol + 32, sc, l);
-    } else {
-      store_ata_split(gx, dM2, T, t, pcol, sc, l);
-      store_ata_split(gg, dM2, T, t, pcol + 32, sc, l);
+      a6n(cx, o6);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tx[k][j] = o6[k];
+      // (keeps the 16 loads of the next column from being hoisted above this column's arithmetic: with all 64 in flight per
+      // thread the kernel needs > 256 registers; two waves per SIMD x 16 loads cover the HBM latency as well)
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (PK) store_ata_rows_pk(tx, dM2, T, t, pcol, sc, l);
+    else store_ata_rows_split(tx, dM2, T, t, pcol, sc, l);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 c4[4], o6[6];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c4[k] = gg[k][j];
+      a6n(c4, o6);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tx[k][j] = o6[k];
+    }
+    if constexpr (PK) store_ata_rows_pk(tx, dM2, T, t, pcol + 32, sc, l);
+    else store_ata_rows_split(tx, dM2, T, t, pcol + 32, sc, l);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)

@@ -35,4 +35,4 @@ for nm in dir(ops):
 step(); torch.cuda.synchronize()
 rows = sorted(((sum(s.elapsed_time(e) for s, e in v), len(v), k) for k, v in recs.items()), reverse=True)
 print("total %.1f ms" % sum(r[0] for r in rows))
-for ms, n, k in rows[:40]: print("%7.2f ms  x%-3d %s" % (ms, n, k))
+for ms, n, k in rows[:int(sys.argv[1]) if len(sys.argv) > 1 else 40]: print("%7.2f ms  x%-3d %s" % (ms, n, k))
