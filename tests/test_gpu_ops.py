@@ -325,6 +325,25 @@ def test_rng_statistics():
     assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3
     z2 = ops.rng_fill((1 << 20,), 1234, 0, normal=True)
     assert torch.equal(z, z2)
+    # higher moments, lag correlations within and across the float4 counters, independence of neighbouring seeds / offsets on
+    # 4 M draws (round 4 also tried Philox4x32-7, the smallest Crush-resistant round count: no measurable gain, kept at 10)
+    z = ops.rng_fill((1 << 22,), 99, 12345, normal=True).double()
+    n = z.numel()
+    assert abs(float((z ** 3).mean())) < 8e-3 and abs(float((z ** 4).mean()) - 3.0) < 2e-2      # skewness 0, kurtosis 3
+    for lag in (1, 2, 3, 4, 5, 8, 64, 1 << 10):
+        assert abs(float((z[:-lag] * z[lag:]).mean())) < 3e-3, lag                                # sigma = 1 / sqrt(n) = 5e-4
+    z4 = z.view(-1, 4)
+    assert float((z4.T @ z4 / z4.shape[0] - torch.eye(4, dtype=torch.float64, device=z4.device)).abs().max()) < 4e-3   # the 4 lanes of a counter
+    other = ops.rng_fill((1 << 22,), 100, 12345, normal=True).double()
+    shifted = ops.rng_fill((1 << 22,), 99, 12345 + (1 << 20), normal=True).double()
+    assert abs(float((z * other).mean())) < 3e-3 and abs(float((z * shifted).mean())) < 3e-3
+    a = ops.rng_fill((64,), 7, 10, normal=True)
+    b = ops.rng_fill((64,), 7, 11, normal=True)
+    assert torch.equal(a[4:], b[:-4])                                           # stream (seed, offset + 1) = the same stream shifted
+    u = ops.rng_fill((1 << 22,), 5, 0, normal=False).double()
+    assert abs(float(u.var()) - 1.0 / 12) < 5e-4 and abs(float((u[:-1] * u[1:]).mean()) - 0.25) < 1e-3
+    hist = torch.histc(u.float(), bins=64, min=0.0, max=1.0)
+    assert float((hist - n / 64).abs().max()) < 6 * (n / 64) ** 0.5             # 64 equiprobable bins within 6 sigma
 
 
 def test_loss_backward_honours_the_upstream_gradient():
