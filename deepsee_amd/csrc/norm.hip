@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_reduce_wino_split_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
     const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
     unsigned char* __restrict__ dM2, float* __restrict__ part, int N, int H, int W, int C, float slope,
-    const float* __restrict__ amax, float bound) {
+    const float* __restrict__ amax, float bound, const unsigned* __restrict__ mask) {
+  // mask (optional): the sign bits of y written by the fused forward ([C/32][pixel] words) -- y itself is then not read
   const float sc = dsee_pow2_scale(bound * dsee_amax_read(amax));
   const int ncg = C >> 6, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = (T >> 2) * ncg * 64;
@@ -518,13 +519,20 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_reduce_wino_split_kernel(
       f32x4 cx[4], o6[6];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const size_t o = (((size_t)n * H + ty * 4 + k) * W + tx_ * 4 + j) * C + c0;
+        const size_t px = ((size_t)n * H + ty * 4 + k) * W + tx_ * 4 + j, o = px * C + c0;
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
         f32x4 g;
+        if (mask) {
+          // ([C/32][N*H*W] words, bit 8 * (c & 3) + ((c & 31) >> 2): the layout the forward kernel's lanes vote in)
+          const unsigned bits = mask[(size_t)(c0 >> 5) * ((size_t)N * H * W) + px] >> ((c0 & 31) >> 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = dv[e] * (yv[e] > 0.f ? 1.f : slope);
+          for (int e = 0; e < 4; ++e) g[e] = dv[e] * ((bits >> (8 * e)) & 1u ? 1.f : slope);
+        } else {
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = dv[e] * (yv[e] > 0.f ? 1.f : slope);
+        }
         const f32x4 d = g * *reinterpret_cast<const f32x4*>(scale + o);
         gg[k][j] = g;
         cx[k] = g * xh;
@@ -623,7 +631,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ add, float* __restrict__ dx,
                                                              long total4, int C, long group_elems, int groups,
                                                              float inv_count, int act, float slope,
-                                                             float* __restrict__ amax = nullptr) {
+                                                             float* __restrict__ amax = nullptr,
+                                                             const unsigned* __restrict__ mask = nullptr) {
+  // mask (MODE 1, LeakyReLU): sign bits of y ([C/32][pixel] words); y is then not read
   float vmax = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 4;
@@ -635,11 +645,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + sc);
     const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + (size_t)groups * C + sc);
     const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + e);
-    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e);
     const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + e) - mu) * is;
     f32x4 d;
+    if (mask) {
+      const unsigned bits = mask[(size_t)(c >> 5) * (total4 * 4 / C) + e / C] >> ((c & 31) >> 2);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = dv[k] * dsee_act_grad_from_out(yv[k], act, slope);
+      for (int k = 0; k < 4; ++k) d[k] = dv[k] * ((bits >> (8 * k)) & 1u ? 1.f : slope);
+    } else {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = dv[k] * dsee_act_grad_from_out(yv[k], act, slope);
+    }
     if constexpr (MODE == 1) d = d * *reinterpret_cast<const f32x4*>(scale + e);
     f32x4 r = is * (d - s0 * inv_count - xh * (s1 * inv_count));
     if (add) r += *reinterpret_cast<const f32x4*>(add + e);
@@ -827,8 +843,8 @@ template <bool PK>
 static int reduce_wino_split_launch(const float* dh, const float* h, const float* x, const float* scale,
                                         const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
                                         int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
-                                        hipStream_t st) {
-  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && dM2 && sums && workspace && amax_g && bound >= 225.f);
+                                        const uint32_t* sign_mask, hipStream_t st) {
+  DSEE_CHECK_ARG(dh && (h || sign_mask) && x && scale && mean && invstd && dM2 && sums && workspace && amax_g && bound >= 225.f);
   DSEE_CHECK_ARG(C % 64 == 0 && C <= 1024 && 256 % (C / 4) == 0 && rows == 2 * C && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 16 == 0);
   // a grid whose wave count is a multiple of the C/64 channel groups (every wave keeps its channels)
@@ -838,7 +854,7 @@ static int reduce_wino_split_launch(const float* dh, const float* h, const float
   DSEE_CHECK_ARG(blocks <= wino_reduce_blocks(N, H, W, C) || blocks == m);
   norm_bwd_reduce_wino_split_kernel<PK><<<blocks, 256, 0, st>>>(dh, h, x, scale, mean, invstd,
                                                             reinterpret_cast<unsigned char*>(dM2), workspace, N, H, W, C, slope,
-                                                            amax_g, bound);
+                                                            amax_g, bound, sign_mask);
   DSEE_LAUNCH_CHECK();
   norm_bwd_split_sums_kernel<<<dim3(dsee_cdiv(C, 8), 4), 256, 0, st>>>(workspace, blocks * 4, C, sums);
   DSEE_LAUNCH_CHECK();
@@ -854,9 +870,9 @@ extern "C" {
 int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const float* x, const float* scale,
                                         const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
                                         int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
-                                        hipStream_t st) {
+                                        const uint32_t* sign_mask, hipStream_t st) {
   return reduce_wino_split_launch<false>(dh, h, x, scale, mean, invstd, dM2, rows, sums, N, H, W, C, slope, workspace, amax_g,
-                                         bound, st);
+                                         bound, sign_mask, st);
 }
 
 /* 16-bit storage mode: the same pass writing dM as the PACKED ONE-TERM operand dM1 [rows/32][36*T][32] fp16 (consumers:
@@ -864,9 +880,9 @@ int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const f
 int dsee_modulate_bwd_reduce_wino_f16p(const float* dh, const float* h, const float* x, const float* scale,
                                        const float* mean, const float* invstd, void* dM1, int rows, float* sums, int N,
                                        int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
-                                       hipStream_t st) {
+                                       const uint32_t* sign_mask, hipStream_t st) {
   return reduce_wino_split_launch<true>(dh, h, x, scale, mean, invstd, dM1, rows, sums, N, H, W, C, slope, workspace, amax_g,
-                                        bound, st);
+                                        bound, sign_mask, st);
 }
 
 /* out (64-line slot, zeroed by the caller) <- max(a) * max(floor_b, max(b)): the operand bound of a product of two tensors */
@@ -892,11 +908,13 @@ int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, con
  * of this norm, whose A dY A^T transform is then written pre-split with the scale known in advance (dsee_wino43_dout_f16x2) */
 int dsee_modulate_bwd_apply_amax(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                                  const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
-                                 float inv_count, float slope, float* amax_dx, hipStream_t st) {
-  DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && sums && dx && amax_dx && C % 4 == 0 && inv_count > 0.f);
+                                 float inv_count, float slope, float* amax_dx, const uint32_t* sign_mask, hipStream_t st) {
+  DSEE_CHECK_ARG(dh && (h || sign_mask) && x && scale && mean && invstd && sums && dx && amax_dx && C % 4 == 0 && inv_count > 0.f);
+  DSEE_CHECK_ARG(!sign_mask || C % 32 == 0);
   const long total4 = (long)N * HW * C / 4;
   norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
-                                                             (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope, amax_dx);
+                                                             (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope, amax_dx,
+                                                             sign_mask);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

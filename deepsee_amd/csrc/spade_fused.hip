@@ -36,7 +36,8 @@
 #include "dsee_common.h"
 
 // Measurement builds only (tools/exp/build_fused_abl.sh): bit 1 no MFMAs, 2 no fragment reads, 4 no fold / Y update,
-// 8 no look-ahead LDS-DMA, 16 no epilogue, 32 cycle stamps, 64 all look-ahead requests read the same (cache-hot) piece.  The shipped library is built without the macro.
+// 8 no look-ahead LDS-DMA, 16 no epilogue, 32 cycle stamps, 64 all look-ahead requests read the same (cache-hot) piece,
+// 128 no sign-mask code.  The shipped library is built without the macro.
 #ifndef DSEE_FUSED_ABL
 #define DSEE_FUSED_ABL 0
 #endif
@@ -59,6 +60,9 @@ struct FusedArgs {
   float* amax_h;   // optional: max |out| (64-line form) -- the operand bound of the convolution that consumes h
   float* amax_xhat;   // optional: max |xhat| -- with max |dh| the bound of the backward pass's gamma/beta gradient
   float* scale;              // may be NULL
+  int cshift;                // log2(4 C) when a sign mask is written (C a power of two then)
+  unsigned* mask;            // optional: sign bits of h, [C/32][pixel] words, bit 8 (c & 3) + ((c & 31) >> 2): what the backward
+                             // pass needs of h (the LeakyReLU branch) in 1/32 of the bytes
   long T;                    // tiles of the whole batch
   long v_slab_bytes, u_slab_bytes, u_group_bytes;
   unsigned v_bytes, u_bytes; // sizes of the two operand tensors (< 4 GB)
@@ -427,7 +431,9 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the surplus look-ahead requests write LDS too)
   const int chunk_r = tid & 7;                            // read phase: channel quad of the 32-channel group
   const int cq = rg * 32 + chunk_r * 4;
-  size_t xoff[4];
+  // BYTE offsets of this lane's 4 items (pixel row k = 0) into x / h / scale, 32 bits (the host checks the tensor is < 4 GB):
+  // half the registers of 64-bit element offsets, and a load / store is `global_* v, v_off, s[base]`
+  unsigned boff[4];
   f32x4 xr[4][4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -435,15 +441,19 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     const int tl = px >> 2, j = px & 3;
     const int tin = (int)(t0 + tl - (long)n * a.tpi);
     const int ty = tin / a.tw, tx = tin - ty * a.tw;
-    xoff[it] = (((size_t)n * a.H + ty * 4) * a.W + tx * 4 + j) * a.C + cq;
+    boff[it] = ((unsigned)((n * a.H + ty * 4) * a.W + tx * 4 + j) * (unsigned)a.C + (unsigned)cq) * 4u;
   }
-  const size_t rowstride = (size_t)a.W * a.C;
+  const unsigned np = (unsigned)(a.T * 16);               // pixels of the tensor
+  const unsigned rowbytes = (unsigned)(a.W * a.C) * 4u;
+  const char* const xb = reinterpret_cast<const char*>(a.x);
+  char* const ob = reinterpret_cast<char*>(a.out);
+  char* const sb = reinterpret_cast<char*>(a.scale);
   if constexpr (!(DSEE_FUSED_ABL & 16)) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int it = 0; it < 4; ++it)
-        xr[k][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + xoff[it] + k * rowstride));
+        xr[k][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (boff[it] + k * rowbytes)));
   }
   __builtin_amdgcn_sched_barrier(0);
   {
@@ -491,17 +501,37 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     for (int it = 0; it < 4; ++it) {
       const int px = it * 64 + (tid >> 3);
       const int tl = px >> 2;
-      const size_t off = xoff[it] + k * rowstride;
+      // (opaque to the optimiser: otherwise the 16 offsets are formed before the main loop and carried through it -- 45 more
+      // spilled registers, the kernel 8 % slower)
+      unsigned off = boff[it];
+      asm volatile("" : "+v"(off));
+      off += k * rowbytes;
       const int ch = (chunk_r ^ (tl & 7)) * 4;
       const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + px * 32 + ch);
       const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + px * 32 + ch);
       const f32x4 xh = (xr[k][it] - mu) * is;
       const f32x4 sc = gv * oscale + bg + a.add_one;
-      if constexpr (WSCALE) __builtin_nontemporal_store(sc, reinterpret_cast<f32x4*>(a.scale + off));
+      if constexpr (WSCALE) __builtin_nontemporal_store(sc, reinterpret_cast<f32x4*>(sb + off));
       f32x4 v = (xh * sc + bb) + bv * oscale;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + off));
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ob + off));
+      if constexpr (WSCALE && !(DSEE_FUSED_ABL & 128)) {
+        // The LeakyReLU branch as bits for the backward pass (training only, like `scale`).  v_cmp leaves the 64 lanes' answers
+        // in an SGPR pair, so no lane exchange is needed: lane l = 8 * pixel + channel quad, byte `pixel` of ballot e holds
+        // element e of the pixel's 8 quads.  Word of (pixel, 32-channel group): bit 8 * (c & 3) + ((c & 31) >> 2).
+        // (Computed unconditionally -- a branch on a.mask here costs 45 spilled registers -- and stored by one lane of 8.)
+        const int pl = (tid >> 3) & 7;
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned long long b = __builtin_amdgcn_ballot_w64(v[e] > 0.f);
+          const unsigned half = (pl & 4) ? (unsigned)(b >> 32) : (unsigned)b;
+          m |= __builtin_amdgcn_ubfe(half, 8 * (pl & 3), 8) << (8 * e);
+        }
+        // ([C/32][N*H*W] words: the 8 pixels of a wave are 32 contiguous bytes, the 64 of the block's pass 256)
+        if (chunk_r == 0 && a.mask) a.mask[rg * np + (off >> a.cshift)] = m;      // (off >> cshift = the pixel: C = 2^(cshift - 2))
+      }
       hmax = fmaxf(hmax, dsee_absmax4(v));
       xmax = fmaxf(xmax, dsee_absmax4(xh));
     }
@@ -558,7 +588,8 @@ void dsee_fused_set_stamps(float* p) { g_fused_stamps = p; }
 static int spade_fused_launch(bool packed, const void* V2, const void* U2, const float* amax_cat, float v_bound,
                               const float* amax_u, const float* bias_packed, const float* x, const float* mean,
                               const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C, int rows, int K,
-                              int groups, float add_one, float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
+                              int groups, float add_one, float slope, float* amax_h, float* amax_xhat, unsigned* sign_mask,
+                              hipStream_t st) {
   DSEE_CHECK_ARG(V2 && U2 && amax_cat && amax_u && x && mean && invstd && out_h);
   DSEE_CHECK_ARG(rows == 2 * C && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && (K == 128 || K == 160));
   DSEE_CHECK_ARG(groups == 1 || groups == N);
@@ -576,6 +607,12 @@ static int spade_fused_launch(bool packed, const void* V2, const void* U2, const
   a.invstd = invstd;
   a.out = out_h;
   a.scale = out_scale;
+  a.mask = sign_mask;
+  a.cshift = 0;
+  while ((4 << a.cshift) < 4 * C) ++a.cshift;
+  a.cshift += 2;
+  DSEE_CHECK_ARG(!sign_mask || (C & (C - 1)) == 0);             // (the mask index is formed by a shift)
+  DSEE_CHECK_ARG((long)N * H * W * C < (1L << 30));             // (32-bit byte offsets into x / h / scale)
   a.amax_h = amax_h;
   a.amax_xhat = amax_xhat;
   a.T = T;
@@ -637,9 +674,9 @@ extern "C" {
 int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
                          const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                          float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                         float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
+                         float slope, float* amax_h, float* amax_xhat, uint32_t* sign_mask, hipStream_t st) {
   return spade_fused_launch(false, V2, U2, amax_cat, v_bound, amax_u, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W,
-                            C, rows, K, groups, add_one, slope, amax_h, amax_xhat, st);
+                            C, rows, K, groups, add_one, slope, amax_h, amax_xhat, sign_mask, st);
 }
 
 /* 16-bit storage mode: the same kernel on PACKED ONE-TERM operands -- V1 = dsee_wino43_input_f16p(cat) [K/32][36*T][32] fp16,
@@ -647,9 +684,9 @@ int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, 
 int dsee_spade_fused_fwd_f16p(const void* V1, const void* U1, const float* amax_cat, float v_bound, const float* amax_u,
                               const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                               float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                              float slope, float* amax_h, float* amax_xhat, hipStream_t st) {
+                              float slope, float* amax_h, float* amax_xhat, uint32_t* sign_mask, hipStream_t st) {
   return spade_fused_launch(true, V1, U1, amax_cat, v_bound, amax_u, bias_packed, x, mean, invstd, out_h, out_scale, N, H, W,
-                            C, rows, K, groups, add_one, slope, amax_h, amax_xhat, st);
+                            C, rows, K, groups, add_one, slope, amax_h, amax_xhat, sign_mask, st);
 }
 
 }  // extern "C"

@@ -1398,10 +1398,11 @@ def bn_stats(x, running_mean, running_var, training):
     return mean, invstd, cfg
 
 
-def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=None, xhat_amax=None):
+def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=None, xhat_amax=None, mask=None):
     """Backward of BN + modulate + LeakyReLU: (dx, dgb, col_sums [2][C], dM).  With SyncBN (`cfg`) the two per-channel
     sums of the BN backward are all-reduced over the ranks between the reduce and the apply pass.  `as_dm`: the
-    gamma/beta gradient leaves the reduce pass as dM = A (g*xhat | g) A^T [36][T][rows] (dgb is None)."""
+    gamma/beta gradient leaves the reduce pass as dM = A (g*xhat | g) A^T [36][T][rows] (dgb is None).  `mask`: the LeakyReLU
+    branch of `out` as bits (written by the fused forward); the passes that take it do not read `out`."""
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
     sums = new(4, c)
@@ -1417,8 +1418,9 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
         pk = P().half      # 16-bit storage mode: one scaled fp16 term per element (dsee_modulate_bwd_reduce_wino_f16p)
         dm = (_i16(36 * t * rows * (1 if pk else 2)), ga, "pk" if pk else True)
         ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
-        L.call("modulate_bwd_reduce_wino_f16p" if pk else "modulate_bwd_reduce_wino_f16x2", dh.contiguous(), out, x, scale, mean,
-               invstd, dm[0], rows, sums, n, h, w, c, LRELU_SLOPE, ws, ga, DM_BOUND)
+        L.call("modulate_bwd_reduce_wino_f16p" if pk else "modulate_bwd_reduce_wino_f16x2", dh.contiguous(),
+               None if mask is not None else out, x, scale, mean, invstd, dm[0], rows, sums, n, h, w, c, LRELU_SLOPE, ws, ga,
+               DM_BOUND, mask)
     elif as_dm:
         dm = (new(36, t, rows), amax_slot() if (P().gemm_split and (P().gemm_f16x2 or P().half)) else None)
         ws = scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, w, c), "norm")
@@ -1435,8 +1437,9 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
         parallel.allreduce_sums(sums[0:2], cfg.world, cfg.group)
         count *= cfg.world
     da = amax_slot()             # max |dx|: dx is the output gradient of the convolution in front of this norm
-    L.call("modulate_bwd_apply_amax", dh.contiguous(), out, x, scale, mean, invstd, sums, add, dx, n, h * w, c, 1.0 / count,
-           LRELU_SLOPE, da)      # dx += add: the gradient of the other consumer of x (the resblock shortcut)
+    # dx += add: the gradient of the other consumer of x (the resblock shortcut)
+    L.call("modulate_bwd_apply_amax", dh.contiguous(), None if mask is not None else out, x, scale, mean, invstd, sums, add, dx,
+           n, h * w, c, 1.0 / count, LRELU_SLOPE, da, mask)
     tag_amax(dx, da)
     return dx, dgb, sums[2:4], dm
 
@@ -1587,11 +1590,15 @@ class SeanNormTable(torch.autograd.Function):
                         4.0 * 36 * t * ld + 4.0 * n * h * w * c * (3 if need_scale else 2)):
                 hm = amax_slot()     # max |h|: the convolution that consumes h writes its V pre-split with this bound
                 xm = amax_slot() if need_scale else None     # max |xhat|: bounds the backward pass's gamma/beta gradient
+                # the LeakyReLU branch of h as bits: all the backward pass needs of h (1/32 of its bytes, read twice)
+                smask = (torch.empty(n * h * w * (c // 32), dtype=torch.int32, device=x.device)
+                         if (need_scale and P().sign_mask) else None)
                 L.call("spade_fused_fwd_f16p" if pk else "spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
                        scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE,
-                       hm, xm)
+                       hm, xm, smask)
                 tag_amax(out, hm)
                 ctx.xhat_amax = xm
+                ctx.sign_mask = smask
             keep = None
             if P().keep_v and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
                 if P().presplit_a:
@@ -1661,7 +1668,8 @@ class SeanNormTable(torch.autograd.Function):
         # adjoint GEMM takes 256-row tiles)
         pre_ok = vcat is not None and len(vcat) == 3 and _wgrad_mode(ld, rows) == 2 and (not ctx.has_a or fused_d)
         dx, dgb, cs, dm_all = modulate_bwd(dh, out, x, scale, mean, invstd, rows, ctx.sync, as_dm, add,
-                                           getattr(ctx, "xhat_amax", None) if pre_ok else None)
+                                           getattr(ctx, "xhat_amax", None) if pre_ok else None,
+                                           getattr(ctx, "sign_mask", None))
 
         def wino_wgrad():
             dw2a = dtable = None

@@ -69,8 +69,9 @@ class KernelPlan:
     fuse_dm: bool = True
     # the fused SPADE / SEAN forward (dsee_spade_fused_fwd; False: GEMM + wino43_output_modulate)
     fused_norm: bool = True
-    # norm backward in one pass behind the producer of dh (False: reduce pass + apply pass)
-    fused_norm_bwd: bool = True
+    # the fused forward also writes the LeakyReLU branch of h as a bit mask ([pixel][C/32] words) and the two passes of the norm
+    # backward read it instead of h (False: they read h, 32x the bytes, for its sign)
+    sign_mask: bool = True
     # direct (non-Winograd) convolutions with at least this much work run their MFMAs on fp16x2-split operands; 0 disables
     conv_f16x2_min_flop: float = 1e9
     # SyncBN-over-RCCL (ops.SyncBNConfig) or None for north_star's sync-free BatchNorm

@@ -173,11 +173,13 @@ int dsee_gemm_f16p_tn_pqpre(const void* P1, const void* Q1, float* C, int groups
 int dsee_modulate_bwd_reduce_wino_f16p(const float* dh, const float* h, const float* x, const float* scale,
                                        const float* mean, const float* invstd, void* dM1, int rows, float* sums, int N,
                                        int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
-                                       hipStream_t stream);
+                                       const uint32_t* sign_mask,
+        hipStream_t stream);
 int dsee_spade_fused_fwd_f16p(const void* V1, const void* U1, const float* amax_cat, float v_bound, const float* amax_u,
                               const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                               float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                              float slope, float* amax_h, float* amax_xhat, hipStream_t stream);
+                              float slope, float* amax_h, float* amax_xhat, uint32_t* sign_mask,
+                              hipStream_t stream);
 int dsee_wino43_input_f16p(const float* x, void* V1, int N, int H, int W, int C, const float* amax_x, float bound,
                            hipStream_t stream);
 int dsee_wino43_dout_f16p(const float* dy, void* dM1, int N, int H, int W, int C, const float* amax_dy, float bound,
@@ -236,10 +238,15 @@ int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, in
 #define DSEE_WINO_V_BOUND 100.0f   /* |B^T d B| <= 100 max|d| for the F(4x4,3x3) input transform */
 int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C, const float* amax_x, float bound,
                             hipStream_t stream);
+/* sign_mask (round 4; optional, here and in dsee_modulate_bwd_reduce_wino_f16x2 / _f16p / dsee_modulate_bwd_apply_amax): the
+ * LeakyReLU branch of h as bits -- [C/32][N*H*W] words, bit 8 * (c % 4) + (c % 32) / 4 = (h[pixel][c] > 0): the order the
+ * forward kernel's lanes vote in, the layout its blocks (64 tiles x 32 channels) write whole lines of -- written by the fused
+ * forward; the two backward passes then read 1/32 of the bytes of h (which is all they ever needed of it: `h` may be NULL there). */
 int dsee_spade_fused_fwd(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
                          const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                          float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
-                         float slope, float* amax_h, float* amax_xhat, hipStream_t stream);
+                         float slope, float* amax_h, float* amax_xhat, uint32_t* sign_mask,
+                         hipStream_t stream);
 size_t dsee_wino43_wgrad_table_workspace(long T, int N, int ca, int rows);
 int dsee_wino43_wgrad_table(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw2a,
                             float* dtable, long T, int N, int ca, int rows, int L, int split, const float* amax_v,
@@ -414,7 +421,8 @@ int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* 
 int dsee_modulate_bwd_reduce_wino_f16x2(const float* dh, const float* h, const float* x, const float* scale,
                                         const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
                                         int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
-                                        hipStream_t stream);
+                                        const uint32_t* sign_mask,
+        hipStream_t stream);
 int dsee_amax_product(const float* a, const float* b, float floor_b, float* out, hipStream_t stream);
 int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int W, int C, float* amax_dx, hipStream_t stream);
 int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
@@ -423,7 +431,8 @@ int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, con
 /* ... also writing max |dx| (64-line form): the operand bound of dsee_wino43_dout_f16x2 for the convolution in front of the norm */
 int dsee_modulate_bwd_apply_amax(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                                  const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
-                                 float inv_count, float slope, float* amax_dx, hipStream_t stream);
+                                 float inv_count, float slope, float* amax_dx, const uint32_t* sign_mask,
+        hipStream_t stream);
 
 /* ------------------------------------------------------------------ label-map kernels (uint8 [N][H][W])
  * mlp_shared = ReLU(conv3x3(one-hot)) (normalization.py:98-101) as a 9-tap gather-sum of weight columns. */

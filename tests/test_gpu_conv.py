@@ -502,6 +502,15 @@ def test_dout_transform_pre_split_with_channel_sums(n, h, c):
         assert rel(got.cpu(), want.cpu()) < 1e-5
 
 
+def _sign_words(out):
+    """The LeakyReLU branch of an NHWC tensor as the fused forward writes it: [C/32][pixel] words, bit 8 * (c % 4) + (c % 32) // 4
+    = (out > 0)."""
+    n, h, w, c = out.shape
+    bits = (out > 0).reshape(n * h * w, c // 32, 8, 4).transpose(2, 3).reshape(n * h * w, c // 32, 32).to(torch.int64)
+    words = (bits << torch.arange(32, device=out.device)).sum(2)
+    return (words - ((words >> 31) << 32)).to(torch.int32).t().reshape(-1)    # (two's complement into int32)
+
+
 @pytest.mark.parametrize("n,h,c", [(2, 32, 64), (1, 64, 128), (4, 32, 512)])
 def test_norm_backward_reduce_writes_pre_split_gradient(n, h, c):
     """dsee_modulate_bwd_reduce_wino_f16x2: the gamma/beta gradient A (g*xhat | g) A^T leaves the norm backward's reduce pass
@@ -523,7 +532,8 @@ def test_norm_backward_reduce_writes_pre_split_gradient(n, h, c):
     ga = ops.amax_slot()
     L.call("amax_product", a_dh, a_xh, 1.0, ga)
     dm2, sums = ops._i16(36 * t * rows * 2), ops.new(4, c)
-    L.call("modulate_bwd_reduce_wino_f16x2", dh, out, x, scale, mean, invstd, dm2, rows, sums, n, h, h, c, 0.2, ws, ga, 225.0)
+    L.call("modulate_bwd_reduce_wino_f16x2", dh, out, x, scale, mean, invstd, dm2, rows, sums, n, h, h, c, 0.2, ws, ga, 225.0,
+           None)
     torch.cuda.synchronize()
     bound = 225.0 * float(ga.max())
     want = float(dh.abs().max()) * max(1.0, float(((x - mean) * invstd).abs().max()))
@@ -535,11 +545,26 @@ def test_norm_backward_reduce_writes_pre_split_gradient(n, h, c):
     assert rel(sums.cpu(), sums_ref.cpu()) < 1e-5          # (same sums, folded in a different fixed order)
     # 16-bit storage mode: the same pass writing the packed one-term image (one scaled fp16 term per element)
     dm1, sums1 = ops._i16(36 * t * rows), ops.new(4, c)
-    L.call("modulate_bwd_reduce_wino_f16p", dh, out, x, scale, mean, invstd, dm1, rows, sums1, n, h, h, c, 0.2, ws, ga, 225.0)
+    L.call("modulate_bwd_reduce_wino_f16p", dh, out, x, scale, mean, invstd, dm1, rows, sums1, n, h, h, c, 0.2, ws, ga, 225.0,
+           None)
     torch.cuda.synchronize()
     dec1 = dm1.view(torch.float16).view(rows // 32, 36 * t, 32).permute(1, 0, 2).reshape(36, t, rows).float() / _pow2_scale(bound)
     assert float((dec1 - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max())
     assert torch.equal(sums1, sums)
+    # the LeakyReLU branch from the fused forward's bit mask instead of `out` (h = NULL): the same bits out of both passes
+    mask = _sign_words(out)
+    for name, want_dm, width in (("modulate_bwd_reduce_wino_f16x2", dm2, 2), ("modulate_bwd_reduce_wino_f16p", dm1, 1)):
+        dmm, sm = ops._i16(36 * t * rows * width), ops.new(4, c)
+        L.call(name, dh, None, x, scale, mean, invstd, dmm, rows, sm, n, h, h, c, 0.2, ws, ga, 225.0, mask)
+        torch.cuda.synchronize()
+        assert torch.equal(dmm, want_dm) and torch.equal(sm, sums)
+    dx0, dx1, da0, da1 = torch.empty_like(x), torch.empty_like(x), ops.amax_slot(), ops.amax_slot()
+    L.call("modulate_bwd_apply_amax", dh, out, x, scale, mean, invstd, sums, None, dx0, n, h * h, c, 1.0 / (n * h * h), 0.2, da0,
+           None)
+    L.call("modulate_bwd_apply_amax", dh, None, x, scale, mean, invstd, sums, None, dx1, n, h * h, c, 1.0 / (n * h * h), 0.2, da1,
+           mask)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1) and torch.equal(da0, da1) and float(dx0.abs().max()) > 0
 
 
 def test_f16x2_special_values():
@@ -694,9 +719,12 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale, packed):
         L.call("selftest_lds_poison", sink)
         out.fill_(float("nan"))
         hm, xm = ops.amax_slot(), ops.amax_slot()
+        mask = torch.full((n * h * h * (c // 32),), 0x5a5a5a5a, dtype=torch.int32, device="cuda") if with_scale else None
         L.call("spade_fused_fwd_f16p" if packed else "spade_fused_fwd", v2, u, ac, 100.0, ua, b2.cuda(), xd, mean.cuda(),
-               invstd.cuda(), out, sc, n, h, h, c, rows, K, n if per_image else 1, add_one, 0.2, hm, xm)
+               invstd.cuda(), out, sc, n, h, h, c, rows, K, n if per_image else 1, add_one, 0.2, hm, xm, mask)
         torch.cuda.synchronize()
+        if mask is not None:            # the LeakyReLU branch of h for the backward pass, one bit per element
+            assert torch.equal(mask, _sign_words(out))
         assert float(hm.max()) == float(out.abs().max())      # the maximum the consumer's operand scale is built from
         xh_max = float((((xd - mean.cuda()) * invstd.cuda()).abs()).max())
         assert abs(float(xm.max()) - xh_max) <= 1e-5 * xh_max
@@ -778,7 +806,7 @@ def test_small_channel_keeps_its_precision_in_the_fused_spade_kernel():
     u, ua = ops._wino_u(w2a.cuda(), rows, ca, False, rows, K, 2)
     out = torch.empty_like(xd)
     L.call("spade_fused_fwd", v2, u, ac, ops.FUSED_V_BOUND, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), out, None, n, h, h,
-           c, rows, K, 1, 1.0, 0.2, None, None)
+           c, rows, K, 1, 1.0, 0.2, None, None, None)
     torch.cuda.synchronize()
     got = out.cpu().double().permute(0, 3, 1, 2)
     e5, e_all = rel(got[:, 5], ref[:, 5]), rel(got, ref)

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepsee_amd import ops, lib as L
 
-def bench(n, h, c, ld, per_image, reps=5, scale=True):
+def bench(n, h, c, ld, per_image, reps=20, scale=True, mask=False):
     rows = 2 * c
     g = torch.Generator(device="cuda").manual_seed(1)
     cat = torch.rand(n, h, h, ld, device="cuda", generator=g)
@@ -24,19 +24,22 @@ def bench(n, h, c, ld, per_image, reps=5, scale=True):
     else:
         u, ua = ops._wino_u(w2a, rows, 128, False, rows, ld, 2)
     out, sc = torch.empty_like(x), torch.empty_like(x)
+    mk = torch.empty(n * h * h * (c // 32), dtype=torch.int32, device="cuda") if mask else None
     ts = []
     for i in range(reps + 2):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         L.call("spade_fused_fwd", v2, u, ac, 100.0, ua, b2, x, mean, invstd, out, sc if scale else None, n, h, h, c, rows, ld,
-               n if per_image else 1, 1.0, 0.2, None, None)
+               n if per_image else 1, 1.0, 0.2, None, None, mk)
         e.record()
         torch.cuda.synchronize()
         ts.append(s.elapsed_time(e))
-    return min(ts[2:])
+    return sorted(ts[2:])[reps // 2]
 
 if __name__ == "__main__":
     tag = os.environ.get("DSEE_LIB", "shipped")
+    bench(8, 256, 512, 160, True, reps=5)       # (clocks / caches warm before the first reported number)
     for (n, h, c, ld, pi) in [(8, 256, 512, 160, True), (8, 256, 512, 128, False), (8, 128, 512, 160, True)]:
-        print("%s: N=%d %dx%d C=%d K=%d per_image=%d: %.3f ms (scale written), %.3f ms (no scale)" % (
-            tag, n, h, h, c, ld, pi, bench(n, h, c, ld, pi), bench(n, h, c, ld, pi, scale=False)), flush=True)
+        print("%s: N=%d %dx%d C=%d K=%d per_image=%d: %.3f ms (scale + sign mask written), %.3f ms (scale written), %.3f ms (neither)" % (
+            tag, n, h, h, c, ld, pi, bench(n, h, c, ld, pi, mask="DSEE_LIB" not in os.environ or "fabl" in tag or "fvar" in tag), bench(n, h, c, ld, pi),
+            bench(n, h, c, ld, pi, scale=False)), flush=True)
