@@ -26,6 +26,7 @@ DEFAULTS = dict(
     sync_bn_clamp=True,      # ... with the reference DP branch's clamp(var, eps) (batchnorm.py:145) instead of var + eps
     preprocess_mode="resize_and_crop", no_flip=False,
     hip_graphs=False,        # capture the G and the D step as hipGraphs (one per encoder-branch variant) and replay them
+    dp_comm="torch",         # data parallel collectives: "torch" (torch.distributed, backend nccl = RCCL) | "capi" (dsee_comm_*)
     dp_graph_collectives=False,  # data parallel + hip_graphs: ALSO capture the chunked RCCL all-reduce and per-chunk Adam (off:
                                  # capturing RCCL operations aborts intermittently in the HIP runtime on ROCm 7.0.2 / RCCL 2.26.6)
     precision="fp32",        # "fp16": one-term scaled-fp16 matrix-core GEMMs + fp16 Winograd-domain products (BASELINE configs[2])

@@ -590,6 +590,30 @@ int dsee_adam_step_range(float* param, const float* grad, float* exp_avg, float*
                          const dsee_adam_tensor* tensors, const int* block_tensor, int first_block, int nblocks,
                          float beta1, float beta2, float eps, float grad_scale, float clip, hipStream_t stream);
 
+/* ---- RCCL behind the ABI: the collectives of the data-parallel path for a host without torch.distributed ----------------
+ * The reference's only parallelism is torch.nn.DataParallel with SyncBN callbacks (managers/base_manager.py:15-23,
+ * sync_batchnorm/replicate.py:50-94: per-iteration parameter broadcast + gradient reduce to GPU 0; batchnorm.py:105-145 +
+ * comm.py:46-133: the master's ReduceAddCoalesced / Broadcast of BN sums through Python queues).  Here: one process per GPU,
+ * parameters stay resident, and a step exchanges (1) the flat gradient -- dsee_comm_allreduce_sum per chunk, each followed
+ * by that chunk's dsee_adam_step_range with grad_scale = 1/world --, (2) once, the start state -- dsee_comm_broadcast --,
+ * and only with SyncBN on (3) [2][C] statistics rows -- dsee_comm_allgather feeding dsee_norm_stats_merge, and
+ * dsee_comm_allreduce_sum of the BN backward's two sums.
+ *
+ * Bootstrap: rank 0 calls dsee_comm_unique_id and ships the DSEE_COMM_ID_BYTES to the other ranks over any channel the host
+ * has (a file, a socket, its own RPC); every rank then calls dsee_comm_init with ITS HIP device current.  RCCL is resolved
+ * with dlopen at the first dsee_comm_* call (DSEE_RCCL_LIB, else librccl.so.1): the library has no link-time dependency on
+ * it.  Collectives are enqueued on `stream` (capturable into a hipGraph) and are in place. */
+#define DSEE_COMM_ID_BYTES 128
+int dsee_comm_unique_id(void* id_out);
+int dsee_comm_init(void** comm_out, const void* id, int world, int rank);
+int dsee_comm_world(const void* comm);
+int dsee_comm_rank(const void* comm);
+int dsee_comm_allreduce_sum(void* comm, float* buf, long n, hipStream_t stream);
+int dsee_comm_broadcast(void* comm, void* buf, long nbytes, int root, hipStream_t stream);
+/* recv [world][nbytes_per_rank] in rank order (a fixed order: dsee_norm_stats_merge then folds bit-identically on every rank) */
+int dsee_comm_allgather(void* comm, const void* send, void* recv, long nbytes_per_rank, hipStream_t stream);
+int dsee_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

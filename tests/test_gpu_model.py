@@ -491,23 +491,27 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
     assert float((plain[1] - dp[1]).abs().mean()) <= 2e-5
 
 
-def _rccl_world1_steps(in_graph, port, q=None):
+def _rccl_world1_steps(in_graph, port, q=None, dp_comm="torch", sync_bn=False):
     """8 G+D iterations of a small model on a forced 1-rank RCCL group with hipGraphs on; returns (losses, G params, D params,
-    graph stats).  `in_graph`: opt.dp_graph_collectives."""
+    graph stats).  `in_graph`: opt.dp_graph_collectives.  `dp_comm` = "capi": the collectives through dsee_comm_* of the C ABI,
+    with no torch.distributed process group at all."""
     import torch.distributed as dist
     from deepsee_amd import parallel
     from deepsee_amd.managers import TrainerManager
     from deepsee_amd.options import make_opt
     over = dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8)
     batch = O.synthetic_batch(O.make_opt(**over), 2, seed=17)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    if dp_comm == "torch":
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     tm = None
     try:
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
-            tm = TrainerManager(make_opt(seed=5, hip_graphs=True, dp_graph_collectives=in_graph, **over))
+            tm = TrainerManager(make_opt(seed=5, hip_graphs=True, dp_graph_collectives=in_graph, dp_comm=dp_comm,
+                                         sync_bn=sync_bn, sync_bn_clamp=False, **over))
         parallel.attach(tm, 1, chunk_mb=0.25, force=True)
+        assert (tm.dp_comm is not None) == (dp_comm == "capi")
         assert tm.use_graphs and tm.dp_in_graph == in_graph and tm.optimizer_G.reduce_hook.active
         assert len(tm.optimizer_G.chunk_ranges(tm.optimizer_G.reduce_hook.chunk_elems)) > 4
         out = []
@@ -521,7 +525,10 @@ def _rccl_world1_steps(in_graph, port, q=None):
     finally:
         if tm is not None:
             tm.release_graphs()       # captured RCCL operations must not outlive their communicator
-        dist.destroy_process_group()
+            if tm.dp_comm is not None:
+                tm.dp_comm.close()
+        if dp_comm == "torch":
+            dist.destroy_process_group()
     if q is not None:     # (plain bytes: tensors in a multiprocessing queue are shared-memory handles that die with the child)
         q.put((res[0], res[1].numpy().tobytes(), res[2].numpy().tobytes(), res[3]))
     return res
@@ -593,7 +600,34 @@ def test_dp_collectives_captured_inside_the_graph_world1():
     assert a[1] == b[1] and a[2] == b[2] and len(a[1]) > 1000      # the flat G / D parameter buffers, byte for byte
 
 
-def _two_gpu_worker(rank, world, port, sync_bn, q):
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_data_parallel_through_the_c_abi_communicator_world1(sync_bn):
+    """opt.dp_comm = "capi": the gradient all-reduce (per chunk, on the communicator's side stream, each chunk followed by its
+    Adam launch), the start-state broadcast and -- with opt.sync_bn -- the SyncBN statistics all-gather / sum all-reduce go
+    through dsee_comm_* of include/deepsee_hip.h (RCCL resolved with dlopen inside libdeepsee_hip.so), with NO torch.distributed
+    process group.  On a 1-rank communicator every collective is the identity, so the run must equal, byte for byte, the same
+    schedule over torch.distributed's 1-rank RCCL group.  (Child processes: one RCCL bootstrap each.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for dp_comm in ("torch", "capi"):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_world1_steps, args=(False, _free_port(), q, dp_comm, sync_bn))
+        p.start()
+        try:
+            res[dp_comm] = q.get(timeout=300)
+        except Exception:
+            res[dp_comm] = None
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+        assert res[dp_comm] is not None, "the %s child died (exit code %s)" % (dp_comm, p.exitcode)
+    a, b = res["capi"], res["torch"]
+    assert a[0] == b[0]
+    assert a[1] == b[1] and a[2] == b[2] and len(a[1]) > 1000
+
+
+def _two_gpu_worker(rank, world, port, sync_bn, q, dp_comm="torch"):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -604,7 +638,7 @@ def _two_gpu_worker(rank, world, port, sync_bn, q):
     from deepsee_amd.options import make_opt
     parallel.init_distributed(backend="nccl")
     over = dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8, add_noise=False, noisy_style_scale=0.0)
-    tm = TrainerManager(make_opt(seed=3, sync_bn=sync_bn, sync_bn_clamp=False, **over))
+    tm = TrainerManager(make_opt(seed=3, sync_bn=sync_bn, sync_bn_clamp=False, dp_comm=dp_comm, **over))
     parallel.attach(tm, world, chunk_mb=0.25)
     full = O.synthetic_batch(O.make_opt(**dict(over, batchSize=2 * world)), 2 * world, seed=91)
     shard = {k: v[2 * rank:2 * rank + 2].clone() for k, v in full.items()}
@@ -616,16 +650,20 @@ def _two_gpu_worker(rank, world, port, sync_bn, q):
            {k: float(v) for k, v in tm.get_latest_losses().items()}))
     import torch.distributed as dist
     dist.barrier()
+    if tm.dp_comm is not None:
+        tm.dp_comm.close()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("dp_comm", ["torch", "capi"])
 @pytest.mark.parametrize("sync_bn", [False, True])
-def test_two_gpu_rccl_data_parallel(sync_bn):
+def test_two_gpu_rccl_data_parallel(sync_bn, dp_comm):
     """Needs TWO MI355X (skipped otherwise): 2 ranks over RCCL, 3 G+D iterations on different batch shards.  Parameters
     and per-tensor step counts must be BIT-IDENTICAL on both ranks (chunked asynchronous all-reduce + per-chunk Adam on
     two streams, flags in the first chunk's header, identical branch coins); with opt.sync_bn the run must also track a
     single process that trains on the concatenated batch (the reference DataParallel semantics: global BN statistics,
-    gradient = mean over the global batch)."""
+    gradient = mean over the global batch).  dp_comm = "capi": the same exchanges through dsee_comm_* of the C ABI (torch.distributed
+    then only carries the communicator's 128-byte id)."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the data-parallel path on one GPU: test_data_parallel_path_on_one_gpu_nccl_world1)")
     import socket
@@ -637,7 +675,7 @@ def test_two_gpu_rccl_data_parallel(sync_bn):
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_gpu_worker, args=(r, 2, port, sync_bn, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_gpu_worker, args=(r, 2, port, sync_bn, q, dp_comm)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])

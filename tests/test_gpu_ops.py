@@ -704,3 +704,46 @@ def test_psnr_ssim_rmse_kernel_matches_reference_numbers():
         assert res["n_samples"] == 2 and abs(res["ssim/mean"] - float(want[:, 1].mean())) <= 1e-9
         rows = open(os.path.join(d, "metrics.csv")).read().strip().splitlines()
         assert rows[0] == "split,ID,PSNR,SSIM,RMSE" and rows[1].startswith("val,7394,") and rows[2].startswith("val,12,")
+
+
+def _capi_comm_child(q):
+    import ctypes as C
+    from deepsee_amd import lib as L, parallel
+    ident = parallel.CapiComm.unique_id()
+    assert len(ident) == 128 and any(ident)
+    comm = parallel.CapiComm(1, 0, ident)
+    assert L.lib().dsee_comm_world(comm.handle) == 1 and L.lib().dsee_comm_rank(comm.handle) == 0
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(100003, device="cuda", generator=g)
+    want = x.clone()
+    comm.all_reduce_sum_(x)                                   # sum over one rank
+    y = torch.arange(77, device="cuda", dtype=torch.int64)
+    comm.broadcast_(y, 0)
+    rows = comm.all_gather(torch.stack([want[:64], want[64:128]]))
+    torch.cuda.synchronize()
+    ok = (torch.equal(x, want) and torch.equal(y.cpu(), torch.arange(77)) and tuple(rows.shape) == (1, 2, 64)
+          and torch.equal(rows[0, 1], want[64:128]))
+    # argument checks come back as error codes with a message, not as crashes
+    rc = L.lib().dsee_comm_broadcast(comm.handle, C.c_void_p(x.data_ptr()), 16, 3, None)
+    msg = L.lib().dsee_last_error().decode()
+    comm.close()
+    q.put((ok, rc, msg))
+
+
+def test_rccl_communicator_behind_the_c_abi_world1():
+    """dsee_comm_* (include/deepsee_hip.h): RCCL resolved with dlopen inside libdeepsee_hip.so -- unique id, init on the current
+    device, in-place sum all-reduce / broadcast / all-gather on the caller's stream, destroy.  One rank (every collective is the
+    identity); the 2-rank exchange is test_two_gpu_rccl_data_parallel's business.  In a child process: its own RCCL bootstrap."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_capi_comm_child, args=(q,))
+    p.start()
+    try:
+        ok, rc, msg = q.get(timeout=240)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert ok
+    assert rc != 0 and "root" in msg
