@@ -1078,7 +1078,7 @@ __global__ void wino43_wgrad_finalize_kernel(const float* __restrict__ slab, flo
         } else {
           for (int j = 0; j < sper; ++j) v += slab[((size_t)(xi * sper + j) * rows + co) * Kpad + ci];
         }
-        u[xi / 6][xi % 6] = v;
+        u[xi / 6][xi % 6] = v * dsee_dm_posr(xi);   // (dM = f_i f_j (A dY A^T)[i][j], dsee_common.h: undone here, exactly)
       }
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
@@ -1139,6 +1139,8 @@ __global__ void wino43_wgrad_table_finalize_kernel(const float* __restrict__ sla
         }
         acc[xi] += v;
       }
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] *= dsee_dm_posr(xi);   // (dM = f_i f_j (A dY A^T)[i][j], dsee_common.h)
     float t[3][6], dg[9];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {

@@ -169,4 +169,16 @@ __device__ __forceinline__ void dsee_store_pk_pair(unsigned char* row_xi0, size_
   const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
   const dsee_u32x4 wv = odd ? (dsee_u32x4){r0, r1, b0, b1} : (dsee_u32x4){a0, a1, r0, r1};
   __builtin_nontemporal_store(wv, reinterpret_cast<dsee_u32x4*>(row_xi0 + (odd ? pos_bytes : 0)));
+
 }
+
+// Row factors of the PRE-SPLIT dM = A dY A^T images (round 4).  The rows of A have absolute sums (1, 4, 4, 15, 15, 1), so the 36
+// positions of dM range over gains 1 ... 225 and one power-of-two scale per tensor leaves the low-gain positions (the corners,
+// which carry most of a 3x3 weight gradient's outer taps) 7.8 bits short.  The producers therefore write
+// dM'[i][j] = f_i f_j dM[i][j] with f = (1, 1/4, 1/4, 1/16, 1/16, 1) -- exact power-of-two factors, |dM'| <= max |dY| at every
+// position (DSEE_WINO_DM_BOUND = 1) -- and the two consumers of the GEMM results undo them in fp32, again exactly: the weight
+// gradient's G^T dU G stage and the data gradient's adjoint input transform multiply position (i, j) by r_i r_j, r = 1 / f.
+__host__ __device__ constexpr float dsee_dm_rowf(int i) { return (i == 0 || i == 5) ? 1.f : (i < 3 ? 0.25f : 0.0625f); }
+__host__ __device__ constexpr float dsee_dm_rowr(int i) { return (i == 0 || i == 5) ? 1.f : (i < 3 ? 4.f : 16.f); }
+__host__ __device__ constexpr float dsee_dm_posf(int xi) { return dsee_dm_rowf(xi / 6) * dsee_dm_rowf(xi % 6); }
+__host__ __device__ constexpr float dsee_dm_posr(int xi) { return dsee_dm_rowr(xi / 6) * dsee_dm_rowr(xi % 6); }

@@ -356,8 +356,9 @@ __device__ __forceinline__ float store_ata(const f32x4 (&v)[4][4], float* __rest
     a6n(tmp[k], o);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * ld + col) = o[j];
-      vmax = fmaxf(vmax, dsee_absmax4(o[j]));
+      const f32x4 of = o[j] * dsee_dm_posf(k * 6 + j);      // (every dM carries the row factors of dsee_common.h)
+      *reinterpret_cast<f32x4*>(dM + ((size_t)(k * 6 + j) * T + t) * ld + col) = of;
+      vmax = fmaxf(vmax, dsee_absmax4(of));
     }
   }
   return vmax;
@@ -384,7 +385,7 @@ __device__ __forceinline__ void store_ata_rows_split(const f32x4 (&tmp)[6][4], u
       _Float16 h0[4], h1[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float x = o[j][e] * sc;
+        const float x = o[j][e] * (sc * dsee_dm_posf(k * 6 + j));      // (row factors: dsee_common.h)
         h0[e] = (_Float16)x;
         h1[e] = (_Float16)(x - (float)h0[e]);
       }
@@ -414,7 +415,8 @@ __device__ __forceinline__ void store_ata_rows_pk(const f32x4 (&tmp)[6][4], unsi
     a6n(tmp[k], o);
 #pragma unroll
     for (int j = 0; j < 6; j += 2)
-      dsee_store_pk_pair(rowp + (size_t)(k * 6 + j) * T * 64, (size_t)T * 64, odd, o[j] * sc, o[j + 1] * sc);
+      dsee_store_pk_pair(rowp + (size_t)(k * 6 + j) * T * 64, (size_t)T * 64, odd, o[j] * (sc * dsee_dm_posf(k * 6 + j)),
+                         o[j + 1] * (sc * dsee_dm_posf(k * 6 + j + 1)));      // (row factors: dsee_common.h)
   }
 }
 
@@ -844,7 +846,7 @@ static int reduce_wino_split_launch(const float* dh, const float* h, const float
                                         const float* mean, const float* invstd, void* dM2, int rows, float* sums, int N,
                                         int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
                                         const uint32_t* sign_mask, hipStream_t st) {
-  DSEE_CHECK_ARG(dh && (h || sign_mask) && x && scale && mean && invstd && dM2 && sums && workspace && amax_g && bound >= 225.f);
+  DSEE_CHECK_ARG(dh && (h || sign_mask) && x && scale && mean && invstd && dM2 && sums && workspace && amax_g && bound >= DSEE_WINO_DM_BOUND);
   DSEE_CHECK_ARG(C % 64 == 0 && C <= 1024 && 256 % (C / 4) == 0 && rows == 2 * C && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 16 == 0);
   // a grid whose wave count is a multiple of the C/64 channel groups (every wave keeps its channels)

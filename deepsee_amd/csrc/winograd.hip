@@ -425,8 +425,9 @@ __device__ __forceinline__ void a6(const f32x4 (&d)[4], f32x4 (&o)[6]) {
 
 // dM[xi][t][c] = (A dY A^T)[xi] per 4x4 tile of the output gradient (adjoint of the output transform)
 // dM = A dY A^T written as the pre-split fp16x2 operand (same image as wino43_input_f16x2_kernel: dM2 [C/16][36*T][2][16] fp16,
-// scaled by dsee_pow2_scale(bound * max|dY|); |A dY A^T| <= 225 max|dY| -- the absolute row sums of A are 1,4,4,15,15,1 -- so
-// the scale is fixed by the maximum the producer of dY wrote).  Both consumers take it as it is: the adjoint data-gradient
+// scaled by dsee_pow2_scale(bound * max|dY|) and by the row factors f_i f_j of dsee_common.h -- the absolute row sums of A are
+// 1,4,4,15,15,1, those of diag(f) A are <= 1, so |f_i f_j (A dY A^T)[i][j]| <= max|dY| at every position and the scale is fixed by
+// the maximum the producer of dY wrote).  Both consumers take it as it is: the adjoint data-gradient
 // GEMM as its A operand (dsee_gemm_f16x2_pre), the weight-gradient TN GEMM as its P operand through LDS transpose reads.
 // SUMS: bias / noise-weight gradients as in wino43_dout_kernel; a wave keeps its 16-channel slab for the whole loop
 // (gridDim.x * 4 is a multiple of C/16), reduces over its 16 tile lanes and writes part[global wave][3][16].
@@ -486,7 +487,8 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
         a6(tmp[k], o);
 #pragma unroll
         for (int j = 0; j < 6; j += 2)
-          dsee_store_pk_pair(rowp + (size_t)(k * 6 + j) * T * 64, (size_t)T * 64, odd, o[j] * sc, o[j + 1] * sc);
+          dsee_store_pk_pair(rowp + (size_t)(k * 6 + j) * T * 64, (size_t)T * 64, odd, o[j] * (sc * dsee_dm_posf(k * 6 + j)),
+                             o[j + 1] * (sc * dsee_dm_posf(k * 6 + j + 1)));      // (row factors: dsee_common.h)
       }
       continue;
     }
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
         _Float16 h0[4], h1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = o[j][e] * sc;
+          const float v = o[j][e] * (sc * dsee_dm_posf(k * 6 + j));      // (row factors: dsee_common.h)
           h0[e] = (_Float16)v;
           h1[e] = (_Float16)(v - (float)h0[e]);
         }
@@ -622,11 +624,12 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
       a6(tmp[k], o);
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
+        const f32x4 of = o[j] * dsee_dm_posf(k * 6 + j);      // (every dM carries the row factors of dsee_common.h)
         if constexpr (OUT == OUT_SPLIT_T)
-          emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, o[j]);
+          emit_split_t(tbuf[threadIdx.x >> 6], lbuf[threadIdx.x >> 6], reinterpret_cast<unsigned short*>(dM), k * 6 + j, T, C, (int)(i & 63), tg, kb * 16, of);
         else {
-          st4b(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4, o[j]);
-          vmax = fmaxf(vmax, dsee_absmax4(o[j]));
+          st4b(dM + ((size_t)(k * 6 + j) * T + t) * C + q * 4, of);
+          vmax = fmaxf(vmax, dsee_absmax4(of));
         }
       }
     }
@@ -852,6 +855,8 @@ __device__ __forceinline__ void b6(const f32x4 (&v)[6], f32x4 (&o)[6]) {
 // dV row / column 5 is needed) + the first patch row / column of the tiles below / right (B's row 0 = 4 e0) + 4 corner
 // scalars.  64 instead of 36 loads per thread, the 28 extra ones from rows of the same planes its neighbours just read.
 // mask != NULL: dx = mask > 0 ? dx : 0 (ReLU backward of the SPADE embedding, DSEE_ACT_MASK of the conv epilogues).
+// dV = dM' U^T with dM' = f_i f_j dM[i][j] (every dM carries the row factors of dsee_common.h): each position is multiplied by
+// r_i r_j as it is loaded (exact powers of two).
 template <typename TM>
 __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const TM* __restrict__ dV,
                                                                    const float* __restrict__ mask, int mask_ld,
@@ -868,7 +873,10 @@ __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const TM* __r
     const int tx = (int)(t % tw);
     const long r = t / tw;
     const int ty = (int)(r % th), n = (int)(r / th);
-    auto at = [&](int xi, long tt) { return ldm4(dV + ((size_t)xi * T + tt) * C + q * 4); };
+    auto at = [&](int xi, long tt) {
+      const f32x4 v = ldm4(dV + ((size_t)xi * T + tt) * C + q * 4);
+      return v * dsee_dm_posr(xi);
+    };
     // own patch: tmp[a][s] = (B dV)[a][s], then P[a][b] = sum_s tmp[a][s] B[b][s]
     f32x4 tmp[6][6];
 #pragma unroll
@@ -1217,7 +1225,7 @@ int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C
 size_t dsee_wino43_dout_f16x2_workspace(void) { return (size_t)DOUT_SUMS_GRID * 4 * 3 * 64 * sizeof(float); }
 
 /* dM = A dY A^T as the pre-split fp16x2 operand dM2 [C/16][36*T][2][16] (scale dsee_pow2_scale(bound * *amax_dy), bound >=
- * 225, amax_dy >= max |dY| written by dY's producer) + optionally the channel sums of dsee_wino43_dout_sums.
+ * DSEE_WINO_DM_BOUND, amax_dy >= max |dY| written by dY's producer; positions carry the row factors of dsee_common.h) + optionally the channel sums of dsee_wino43_dout_sums.
  * workspace (dsee_wino43_dout_f16x2_workspace bytes) only when a sum is requested.  C % 16 == 0, T % 16 == 0,
  * 2048 % (C/16) == 0. */
 }  // extern "C"
@@ -1227,7 +1235,7 @@ template <bool PK>
 int dout_f16_launch(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
                     float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0, float* dnoise1,
                     uint64_t seed1, uint64_t offset1, hipStream_t st) {
-  DSEE_CHECK_ARG(dy && dM2 && amax_dy && C % (PK ? 32 : 16) == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 225.f);
+  DSEE_CHECK_ARG(dy && dM2 && amax_dy && C % (PK ? 32 : 16) == 0 && H % 4 == 0 && W % 4 == 0 && bound >= DSEE_WINO_DM_BOUND);
   const long T = (long)N * (H / 4) * (W / 4);
   DSEE_CHECK_ARG(T % 16 == 0);
   const bool sums = dbias || dnoise0 || dnoise1, wide = C % 64 == 0;
@@ -1353,11 +1361,9 @@ int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, f
   DSEE_CHECK_ARG(dV && dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(!mask || (mask_ld >= C && mask_ld % 4 == 0));
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
-  if (dvscale)
-    wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const _Float16*>(dV), mask, mask_ld, dx, N, H, W, C,
-                                                      dvscale);
-  else
-    wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, mask, mask_ld, dx, N, H, W, C, nullptr);
+  const _Float16* dVh = reinterpret_cast<const _Float16*>(dV);
+  if (dvscale) wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dVh, mask, mask_ld, dx, N, H, W, C, dvscale);
+  else wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, mask, mask_ld, dx, N, H, W, C, nullptr);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1365,8 +1371,8 @@ int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, f
 /* dsee_wino43_input_adjoint (fp32 dV) that also writes max |dx| (64-line form) */
 int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int W, int C, float* amax_dx, hipStream_t st) {
   DSEE_CHECK_ARG(dV && dx && amax_dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_input_adjoint_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dV, nullptr, 0, dx, N, H, W, C,
-                                                                                          nullptr, amax_dx);
+  const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
+  wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, nullptr, 0, dx, N, H, W, C, nullptr, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1375,8 +1381,9 @@ int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int
 int dsee_wino43_input_adjoint_amax_f16(const void* dV16, float* dx, int N, int H, int W, int C, const float* dvscale,
                                        float* amax_dx, hipStream_t st) {
   DSEE_CHECK_ARG(dV16 && dx && dvscale && amax_dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
-  wino43_input_adjoint_kernel<<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
-      reinterpret_cast<const _Float16*>(dV16), nullptr, 0, dx, N, H, W, C, dvscale, amax_dx);
+  const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
+  const _Float16* dVh = reinterpret_cast<const _Float16*>(dV16);
+  wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dVh, nullptr, 0, dx, N, H, W, C, dvscale, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

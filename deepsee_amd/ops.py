@@ -573,7 +573,10 @@ def _dout_sums_ok(n, nb, cout_s, mode):
     return P().dout_sums and nb == n and mode != 1 and cout_s // 4 <= 256 and 256 % (cout_s // 4) == 0
 
 
-DM_BOUND = 225.0      # |A dY A^T| <= 225 max|dY| for F(4x4,3x3) (absolute row sums of A: 1, 4, 4, 15, 15, 1)
+# Every dM holds f_i f_j (A dY A^T)[i][j], f = (1, 1/4, 1/4, 1/16, 1/16, 1) (include/deepsee_hip.h, "ROW FACTORS": the absolute row
+# sums of A are 1, 4, 4, 15, 15, 1), bounded by max|dY| at every position; the consumers of the GEMM results (weight-gradient
+# finalize, adjoint input transform) undo the factors
+DM_BOUND = 1.0
 
 
 def _is_pk(v):

@@ -257,11 +257,18 @@ int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, flo
  * weights (architecture.py:111-112 noise_middle, :127,133-134 noise_skip; normalization.py:289-304) with eps_k the Philox
  * stream (seed_k, offset_k) dsee_wino43_output drew in the forward pass.  Replaces the separate dsee_channel_dot /
  * dsee_channel_dot_rng passes over dY.  Any of the three outputs may be NULL (not all); 256 % (C/4) == 0. */
-/* ... and written PRE-SPLIT (round 3): dM2 [C/16][36*T][2][16] fp16 with the scale power-of-two scale of bound x *amax_dy, bound
- * >= DSEE_WINO_DM_BOUND (|A dY A^T| <= 225 max|dY|), amax_dy = max |dY| written by dY's producer (dsee_modulate_bwd_apply,
- * dsee_sumpool).  Consumers: dsee_gemm_f16x2_pre (adjoint data gradient) and dsee_wino43_wgrad(split = 6).  The three channel
+/* ... and written PRE-SPLIT (round 3): dM2 [C/16][36*T][2][16] fp16 with the power-of-two scale of bound x *amax_dy, bound
+ * >= DSEE_WINO_DM_BOUND, amax_dy = max |dY| written by dY's producer (dsee_modulate_bwd_apply, dsee_sumpool).
+ * ROW FACTORS (round 4): EVERY dM this library writes (dsee_wino43_dout[_sums / _split_t / _f16x2 / _f16p],
+ * dsee_modulate_bwd_reduce_wino[_f16x2 / _f16p]) holds f_i f_j (A dY A^T)[i][j] with f = (1, 1/4, 1/4, 1/16, 1/16, 1): the
+ * absolute row sums of A are (1, 4, 4, 15, 15, 1), so the 36 positions would otherwise span gains 1 ... 225 under the ONE
+ * power-of-two scale a split operand has, and the low-gain positions -- the corners, which carry the outer taps of a 3x3 weight
+ * gradient -- would lose 7.8 bits; with the factors |dM'| <= max |dY| at every position (bound 1).  The factors are exact powers
+ * of two and are undone, in fp32, by the consumers of the GEMM results: dsee_wino43_wgrad[_table] in their G^T dU G stage,
+ * dsee_wino43_input_adjoint* as they load dV = dM' U^T.
+ * Consumers: dsee_gemm_f16x2_pre (adjoint data gradient) and dsee_wino43_wgrad(split = 6).  The three channel
  * sums of dsee_wino43_dout_sums are optional (workspace: dsee_wino43_dout_f16x2_workspace() bytes when any is requested). */
-#define DSEE_WINO_DM_BOUND 225.0f
+#define DSEE_WINO_DM_BOUND 1.0f   /* |f_i f_j (A dY A^T)[i][j]| <= max|dY| */
 size_t dsee_wino43_dout_f16x2_workspace(void);
 int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
                            float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
