@@ -182,3 +182,19 @@ __host__ __device__ constexpr float dsee_dm_rowf(int i) { return (i == 0 || i ==
 __host__ __device__ constexpr float dsee_dm_rowr(int i) { return (i == 0 || i == 5) ? 1.f : (i < 3 ? 4.f : 16.f); }
 __host__ __device__ constexpr float dsee_dm_posf(int xi) { return dsee_dm_rowf(xi / 6) * dsee_dm_rowf(xi % 6); }
 __host__ __device__ constexpr float dsee_dm_posr(int xi) { return dsee_dm_rowr(xi / 6) * dsee_dm_rowr(xi % 6); }
+
+// Index arithmetic of the NHWC walkers.  The ISA has no integer divide: a 64-bit division by a run-time value compiles to ~150
+// instructions with branches, and three of them per float4 item (n, h, w, channel quad) left up_noise / sumpool instruction-bound
+// at ~2 TB/s.  Item counts fit 32 bits (the hosts check), and a 32-bit unsigned division is ~20 instructions.
+struct dsee_nhwq {
+  int n, h, w, q;
+};
+__device__ __forceinline__ dsee_nhwq dsee_split_nhwq(unsigned i, unsigned C4, unsigned W, unsigned H) {
+  dsee_nhwq r;
+  const unsigned t = i / C4, u = t / W, n = u / H;
+  r.q = (int)(i - t * C4);
+  r.w = (int)(t - u * W);
+  r.h = (int)(u - n * H);
+  r.n = (int)n;
+  return r;
+}

@@ -20,12 +20,9 @@ __global__ __launch_bounds__(256) void up_noise_fwd_kernel(const float* __restri
   const long total4 = (long)N * H * W * C / 4;
   const int C4 = C / 4, h0 = H >> ups, w0 = W >> ups;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    long t = i / C4;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H), n = (int)(t / H);
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * h0 + (h >> ups)) * w0 + (w >> ups)) * C + q * 4);
+    const dsee_nhwq p = dsee_split_nhwq((unsigned)i, C4, W, H);
+    const int q = p.q;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)p.n * h0 + (p.h >> ups)) * w0 + (p.w >> ups)) * C + q * 4);
     if (eps) v += *reinterpret_cast<const f32x4*>(nw + q * 4) * *reinterpret_cast<const f32x4*>(eps + i * 4);
     *reinterpret_cast<f32x4*>(y + i * 4) = v;
   }
@@ -38,15 +35,11 @@ __global__ __launch_bounds__(256) void sumpool_kernel(const float* __restrict__ 
   const int h0 = H >> ups, w0 = W >> ups, C4 = C / 4, f = 1 << ups;
   const long total4 = (long)N * h0 * w0 * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    long t = i / C4;
-    const int w = (int)(t % w0);
-    t /= w0;
-    const int h = (int)(t % h0), n = (int)(t / h0);
+    const dsee_nhwq p = dsee_split_nhwq((unsigned)i, C4, w0, h0);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < f; ++a)
       for (int b = 0; b < f; ++b)
-        v += *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + h * f + a) * W + w * f + b) * C + q * 4);
+        v += *reinterpret_cast<const f32x4*>(dy + (((size_t)p.n * H + p.h * f + a) * W + p.w * f + b) * C + p.q * 4);
     *reinterpret_cast<f32x4*>(dx + i * 4) = v;
     vmax = fmaxf(vmax, dsee_absmax4(v));
   }
@@ -405,12 +398,9 @@ __global__ __launch_bounds__(256) void up_noise_rng_fwd_kernel(const float* __re
   const long total4 = (long)N * H * W * C / 4;
   const int C4 = C / 4, h0 = H >> ups, w0 = W >> ups;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    long t = i / C4;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H), n = (int)(t / H);
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * h0 + (h >> ups)) * w0 + (w >> ups)) * C + q * 4);
+    const dsee_nhwq p = dsee_split_nhwq((unsigned)i, C4, W, H);
+    const int q = p.q;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)p.n * h0 + (p.h >> ups)) * w0 + (p.w >> ups)) * C + q * 4);
     v += *reinterpret_cast<const f32x4*>(nw + q * 4) * philox_normal4(seed, offset + (uint64_t)i);
     *reinterpret_cast<f32x4*>(y + i * 4) = v;
     if constexpr (STATS) sa.add(v);
@@ -450,6 +440,7 @@ extern "C" {
 int dsee_upsample_noise_rng_fwd(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
                                 uint64_t seed, uint64_t offset, hipStream_t st) {
   DSEE_CHECK_ARG(x && y && noise_w && C % 4 == 0);
+  DSEE_CHECK_ARG((long)N * H * W * C / 4 < (1L << 32));      // (32-bit item index: dsee_split_nhwq)
   up_noise_rng_fwd_kernel<false><<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset,
                                                                                  dsee_rng_epoch(), nullptr);
   DSEE_LAUNCH_CHECK();
@@ -462,6 +453,7 @@ int dsee_upsample_noise_rng_fwd(const float* x, const float* noise_w, float* y, 
 int dsee_upsample_noise_rng_fwd_stats(const float* x, const float* noise_w, float* y, int N, int H, int W, int C, int ups,
                                       uint64_t seed, uint64_t offset, float* stats_part, hipStream_t st) {
   DSEE_CHECK_ARG(x && y && noise_w && stats_part && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
+  DSEE_CHECK_ARG((long)N * H * W * C / 4 < (1L << 32));      // (32-bit item index: dsee_split_nhwq)
   const long items = (long)N * H * W * C / 4;
   const int grid = (int)min((long)DSEE_STATS_ROWS_MAX, (items + 255) / 256);
   up_noise_rng_fwd_kernel<true><<<grid, 256, 0, st>>>(x, noise_w, y, N, H, W, C, ups, seed, offset, dsee_rng_epoch(),
@@ -487,6 +479,7 @@ int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* works
 int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise_w, float* y, int N, int H, int W, int C,
                             int ups, hipStream_t st) {
   DSEE_CHECK_ARG(x && y && C % 4 == 0 && (eps == nullptr || noise_w != nullptr));
+  DSEE_CHECK_ARG((long)N * H * W * C / 4 < (1L << 32));      // (32-bit item index: dsee_split_nhwq)
   up_noise_fwd_kernel<<<egrid((long)N * H * W * C / 4), 256, 0, st>>>(x, eps, noise_w, y, N, H, W, C, ups);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
@@ -494,6 +487,7 @@ int dsee_upsample_noise_fwd(const float* x, const float* eps, const float* noise
 
 int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dx && C % 4 == 0 && ups >= 1);
+  DSEE_CHECK_ARG((long)N * H * W * C / 4 < (1L << 32));      // (32-bit item index: dsee_split_nhwq)
   sumpool_kernel<<<egrid((long)N * (H >> ups) * (W >> ups) * C / 4), 256, 0, st>>>(dy, dx, N, H, W, C, ups);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
@@ -502,6 +496,7 @@ int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups
 /* dsee_sumpool that also writes max |dx| (64-line form): dx is the output gradient of the previous block's conv_1 */
 int dsee_sumpool_amax(const float* dy, float* dx, int N, int H, int W, int C, int ups, float* amax_dx, hipStream_t st) {
   DSEE_CHECK_ARG(dy && dx && amax_dx && C % 4 == 0 && ups >= 1);
+  DSEE_CHECK_ARG((long)N * H * W * C / 4 < (1L << 32));      // (32-bit item index: dsee_split_nhwq)
   sumpool_kernel<<<egrid((long)N * (H >> ups) * (W >> ups) * C / 4), 256, 0, st>>>(dy, dx, N, H, W, C, ups, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;

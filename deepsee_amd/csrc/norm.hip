@@ -253,8 +253,9 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
                                                            long total4, int C, long group_elems, int act, float slope) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 4;
-    const int c = (int)(e % C);
-    const int grp = (int)(e / group_elems);
+    const unsigned px = (unsigned)i / ((unsigned)C >> 2);       // (32-bit divisions: dsee_common.h)
+    const int c = (int)((unsigned)i - px * ((unsigned)C >> 2)) * 4;
+    const int grp = (int)(px / (unsigned)(group_elems / C));
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)grp * C + c);
     const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)grp * C + c);
@@ -441,10 +442,10 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_wino_kernel(
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long t = i / C4;  // (i % C4 == q: gridDim.x * 256 is a multiple of C4)
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    // (32-bit divisions: item counts fit, the ISA has no integer divide -- dsee_common.h)
+    const long t = (long)((unsigned)i / (unsigned)C4);  // (i % C4 == q: gridDim.x * 256 is a multiple of C4)
+    const unsigned r_ = (unsigned)t / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)((unsigned)t - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     f32x4 gg[4][4], gx[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -509,10 +510,10 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_reduce_wino_split_kernel(
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long t = ((i >> 6) / ncg) * 4 + (l >> 4);
-    const int tx_ = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    // (32-bit divisions: item counts fit, the ISA has no integer divide -- dsee_common.h)
+    const long t = (long)(((unsigned)(i >> 6) / (unsigned)ncg) * 4 + (l >> 4));
+    const unsigned r_ = (unsigned)t / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx_ = (int)((unsigned)t - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     // column j of the tile at a time: g is kept (its own transform follows), g * xhat goes straight into the column half of
     // its transform
     f32x4 gg[4][4], tx[6][4];
@@ -637,10 +638,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const unsigned* __restrict__ mask = nullptr) {
   // mask (MODE 1, LeakyReLU): sign bits of y ([C/32][pixel] words); y is then not read
   float vmax = 0.f;
+  // (32-bit index arithmetic: item counts fit 32 bits -- the hosts check -- and a 64-bit division is ~150 instructions here)
+  const unsigned C4 = (unsigned)C >> 2, gpx = (unsigned)(group_elems / C), npx = (unsigned)(total4 / C4);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 4;
-    const int c = (int)(e % C);
-    const int grp = (int)(e / group_elems);
+    const unsigned px = (unsigned)i / C4;
+    const int c = (int)((unsigned)i - px * C4) * 4;
+    const int grp = groups == 1 ? 0 : (int)(px / gpx);
     const size_t sc = (size_t)grp * C + c;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + sc);
     const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + sc);
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + e) - mu) * is;
     f32x4 d;
     if (mask) {
-      const unsigned bits = mask[(size_t)(c >> 5) * (total4 * 4 / C) + e / C] >> ((c & 31) >> 2);
+      const unsigned bits = mask[(size_t)(c >> 5) * npx + px] >> ((c & 31) >> 2);
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = dv[k] * ((bits >> (8 * k)) & 1u ? 1.f : slope);
     } else {
@@ -780,6 +784,7 @@ int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const flo
   sums_finalize_kernel<<<dsee_cdiv((long)2 * g.groups * C, 8), 256, 0, st>>>(workspace, sums, 2, g);
   DSEE_LAUNCH_CHECK();
   const long total4 = (long)N * HW * C / 4;
+  DSEE_CHECK_ARG(total4 < (1L << 32));
   norm_bwd_apply_kernel<0><<<grid_for(total4), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, sums, nullptr, dx, total4,
                                                              C, (long)(N / groups) * HW * C, g.groups,
                                                              1.0f / (float)g.P, act, slope);
@@ -900,6 +905,7 @@ int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, con
                             float inv_count, float slope, hipStream_t st) {
   DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && sums && dx && C % 4 == 0 && inv_count > 0.f);
   const long total4 = (long)N * HW * C / 4;
+  DSEE_CHECK_ARG(total4 < (1L << 32));
   norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
                                                              (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope);
   DSEE_LAUNCH_CHECK();
@@ -914,6 +920,7 @@ int dsee_modulate_bwd_apply_amax(const float* dh, const float* h, const float* x
   DSEE_CHECK_ARG(dh && (h || sign_mask) && x && scale && mean && invstd && sums && dx && amax_dx && C % 4 == 0 && inv_count > 0.f);
   DSEE_CHECK_ARG(!sign_mask || C % 32 == 0);
   const long total4 = (long)N * HW * C / 4;
+  DSEE_CHECK_ARG(total4 < (1L << 32));
   norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
                                                              (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope, amax_dx,
                                                              sign_mask);

@@ -173,14 +173,15 @@ constexpr int OUT_F32 = 0, OUT_SPLIT = 1, OUT_SPLIT_T = 2;
 // for slab 1, ... so that every (xi, slab) output stream is written in long sequential runs while x is read from
 // HBM once.
 __device__ __forceinline__ void wave_tile_quad(long i, int C4, long T, int& q, long& t, long& tg, int& kb) {
-  const int C16 = C4 >> 2;
-  const long G16 = T >> 4;
-  const long S = G16 % 256 == 0 ? 256 : G16;
-  const long w = i >> 6;
+  // (32-bit: item counts fit -- the hosts check -- and the ISA has no integer divide, dsee_common.h)
+  const unsigned C16 = (unsigned)C4 >> 2;
+  const unsigned G16 = (unsigned)(T >> 4);
+  const unsigned S = G16 % 256 == 0 ? 256 : G16;
+  const unsigned w = (unsigned)(i >> 6);
   const int l = (int)(i & 63);
-  const long strip = w / (C16 * S), rem = w - strip * (C16 * S);
-  kb = (int)(rem / S);
-  tg = strip * S + rem % S;
+  const unsigned strip = w / (C16 * S), rem = w - strip * (C16 * S), kbu = rem / S;
+  kb = (int)kbu;
+  tg = (long)(strip * S + (rem - kbu * S));
   q = kb * 4 + (l & 3);
   t = tg * 16 + (l >> 2);
 }
@@ -231,12 +232,12 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
     } else if constexpr (OUT == OUT_SPLIT_T) {
       wave_tile_quad(i, C4, T, q, t, tg, kb);
     } else {
-      q = (int)(i % C4);
-      t = i / C4;
+      t = (long)((unsigned)i / (unsigned)C4);
+      q = (int)((unsigned)i - (unsigned)t * (unsigned)C4);
     }
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    // (32-bit divisions: T < 2^31, and a 64-bit division is ~150 instructions on this ISA -- dsee_common.h)
+    const unsigned tu_ = (unsigned)t, r_ = tu_ / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)(tu_ - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     f32x4 tmp[6][6];  // tmp[row][col] = (B^T d)[row][col]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -351,9 +352,9 @@ __global__ __launch_bounds__(256) void wino43_input_f16x2_kernel(const float* __
     long t;
     f16_lane_map<WIDE, PK>(w, l, nkb, kb, t);
     const int q = kb * 4 + (l & 3);
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    // (32-bit divisions: T < 2^31, and a 64-bit division is ~150 instructions on this ISA -- dsee_common.h)
+    const unsigned tu_ = (unsigned)t, r_ = tu_ / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)(tu_ - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     f32x4 tmp[6][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -457,9 +458,9 @@ __global__ __launch_bounds__(256) void wino43_dout_f16x2_kernel(const float* __r
     long t;
     f16_lane_map<WIDE, PK>(w, l, nkb, kb, t);
     const int q = kb * 4 + (l & 3);
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    // (32-bit divisions: T < 2^31, and a 64-bit division is ~150 instructions on this ISA -- dsee_common.h)
+    const unsigned tu_ = (unsigned)t, r_ = tu_ / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)(tu_ - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     f32x4 tmp[6][4];  // tmp[row][col] = (A dY)[row][col]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -594,12 +595,12 @@ __global__ __launch_bounds__(256) void wino43_dout_kernel(const float* __restric
     if constexpr (OUT != OUT_F32) {
       wave_tile_quad(i, C4, T, q, t, tg, kb);
     } else {
-      q = (int)(i % C4);
-      t = i / C4;
+      t = (long)((unsigned)i / (unsigned)C4);
+      q = (int)((unsigned)i - (unsigned)t * (unsigned)C4);
     }
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    // (32-bit divisions: T < 2^31, and a 64-bit division is ~150 instructions on this ISA -- dsee_common.h)
+    const unsigned tu_ = (unsigned)t, r_ = tu_ / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)(tu_ - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     f32x4 tmp[6][4];  // tmp[row][col] = (A dY)[row][col]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -702,11 +703,11 @@ __global__ __launch_bounds__(256, 2) void wino43_output_kernel(const TM* __restr
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    const long t = (long)((unsigned)i / (unsigned)C4);
+    const int q = (int)((unsigned)i - (unsigned)t * (unsigned)C4);
+    // (32-bit divisions: T < 2^31, and a 64-bit division is ~150 instructions on this ISA -- dsee_common.h)
+    const unsigned tu_ = (unsigned)t, r_ = tu_ / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)(tu_ - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     f32x4 tmp[4][6];  // tmp[i][col] = (A^T m)[i][col]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -796,11 +797,11 @@ __global__ __launch_bounds__(256, 2) void wino43_output_modulate_kernel(
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4), c = q * 4;
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    const long t = (long)((unsigned)i / (unsigned)C4);
+    const int q = (int)((unsigned)i - (unsigned)t * (unsigned)C4), c = q * 4;
+    // (32-bit divisions: T < 2^31, and a 64-bit division is ~150 instructions on this ISA -- dsee_common.h)
+    const unsigned tu_ = (unsigned)t, r_ = tu_ / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)(tu_ - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     const int pg = (c >> 6) * 128 + ((c & 63) >> 5) * 64 + (c & 31);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bg = bias ? *reinterpret_cast<const f32x4*>(bias + pg) : z4;
@@ -868,11 +869,11 @@ __global__ __launch_bounds__(256) void wino43_input_adjoint_kernel(const TM* __r
   const int C4 = C / 4, th = H / 4, tw = W / 4;
   const long T = (long)N * th * tw, total = T * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th), n = (int)(r / th);
+    const long t = (long)((unsigned)i / (unsigned)C4);
+    const int q = (int)((unsigned)i - (unsigned)t * (unsigned)C4);
+    // (32-bit divisions: T < 2^31, and a 64-bit division is ~150 instructions on this ISA -- dsee_common.h)
+    const unsigned tu_ = (unsigned)t, r_ = tu_ / (unsigned)tw, n_ = r_ / (unsigned)th;
+    const int tx = (int)(tu_ - r_ * (unsigned)tw), ty = (int)(r_ - n_ * (unsigned)th), n = (int)n_;
     auto at = [&](int xi, long tt) {
       const f32x4 v = ldm4(dV + ((size_t)xi * T + tt) * C + q * 4);
       return v * dsee_dm_posr(xi);
