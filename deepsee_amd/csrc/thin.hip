@@ -201,6 +201,136 @@ __global__ __launch_bounds__(256) void thin_gather_bwd_kernel(const float* __res
   }
 }
 
+// ---- backward of the 27-output 1x1 GEMM the to-RGB layer runs as (ops.conv2d, thin path): K <= 32 rows.
+// As implicit GEMMs the two gradients have 27 of a 128-wide tile's columns (data gradient: 1.07 GB written at 1.8 TB/s) or 27
+// of its rows (weight gradient: 1.07 GB read at 1.8 TB/s).  Laid out along the 512 input channels instead, like the kernels
+// above: a thread owns 4 consecutive channels and keeps the K x 4 weights (data gradient) or K x 4 accumulators (weight
+// gradient) in registers; dz of a pixel is block-uniform (its rows go through LDS, 128 pixels at a time, and are read back as
+// broadcasts), so a pixel costs one 16-byte load or store and K float4 FMAs per thread.  Exact fp32 FMAs.
+constexpr int THIN1_CHUNK = 128;      // pixels whose dz rows a block stages in LDS at a time (<= 16 KB at ldz = 32)
+
+// the block's next chunk of dz rows -> LDS (the rows of consecutive pixels are one contiguous range: coalesced 16-byte loads)
+__device__ __forceinline__ void thin1_stage(float* __restrict__ zs, const float* __restrict__ dz, int ldz, long m, int np) {
+  const int n4 = np * ldz / 4;
+  for (int i = threadIdx.x; i < n4; i += 128)
+    reinterpret_cast<f32x4*>(zs)[i] = *reinterpret_cast<const f32x4*>(dz + m * ldz + (size_t)i * 4);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(128) void thin1x1_dgrad_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ w,
+                                                            float* __restrict__ dx, long M, int C, int K, int px_per_block) {
+  __shared__ __attribute__((aligned(16))) float zs[THIN1_CHUNK * 32];
+  const int c = (blockIdx.y * 128 + threadIdx.x) * 4;
+  const bool on = c < C;
+  f32x4 wr[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    wr[k] = (on && k < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)k * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  const long m0 = (long)blockIdx.x * px_per_block, m1 = min(M, m0 + px_per_block);
+  for (long mc = m0; mc < m1; mc += THIN1_CHUNK) {
+    const int np = (int)min((long)THIN1_CHUNK, m1 - mc);
+    __syncthreads();
+    thin1_stage(zs, dz, ldz, mc, np);
+    __syncthreads();
+    if (!on) continue;
+#pragma unroll 4
+    for (int p = 0; p < np; ++p) {
+      const f32x4* __restrict__ zr = reinterpret_cast<const f32x4*>(zs + p * ldz);     // (uniform address: LDS broadcast)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+        if (k4 * 4 >= K) break;          // (uniform; rows are ldz >= K floats, ldz % 4 == 0: the float4 holding row K-1 is in the row)
+        const f32x4 z = zr[k4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += z[e] * wr[k4 * 4 + e];
+      }
+      __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(dx + (mc + p) * C + c));
+    }
+  }
+}
+
+// part[block][k][c] = sum over the block's pixels of dz[m][k] x[m][c]
+template <int KMAX>
+__global__ __launch_bounds__(128) void thin1x1_wgrad_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ x,
+                                                            float* __restrict__ part, long M, int C, int K, int px_per_block) {
+  __shared__ __attribute__((aligned(16))) float zs[THIN1_CHUNK * 32];
+  const int c = (blockIdx.y * 128 + threadIdx.x) * 4;
+  const bool on = c < C;
+  f32x4 acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const long m0 = (long)blockIdx.x * px_per_block, m1 = min(M, m0 + px_per_block);
+  for (long mc = m0; mc < m1; mc += THIN1_CHUNK) {
+    const int np = (int)min((long)THIN1_CHUNK, m1 - mc);
+    __syncthreads();
+    thin1_stage(zs, dz, ldz, mc, np);
+    __syncthreads();
+    if (!on) continue;
+    int p = 0;
+    for (; p + 4 <= np; p += 4) {      // (4 independent 16-byte loads in flight per thread)
+      f32x4 xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (mc + p + j) * C + c));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4* __restrict__ zr = reinterpret_cast<const f32x4*>(zs + (p + j) * ldz);
+#pragma unroll
+        for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+          if (k4 * 4 >= K) break;
+          const f32x4 z = zr[k4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[k4 * 4 + e] += z[e] * xv[j];
+        }
+      }
+    }
+    for (; p < np; ++p) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (mc + p) * C + c);
+      const f32x4* __restrict__ zr = reinterpret_cast<const f32x4*>(zs + p * ldz);
+#pragma unroll
+      for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+        if (k4 * 4 >= K) break;
+        const f32x4 z = zr[k4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k4 * 4 + e] += z[e] * xv;
+      }
+    }
+  }
+  if (on) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K + k) * C + c) = acc[k];
+  }
+}
+
+// dw[k][c] = sum_blocks part[block][k][c] in a fixed order: 8 float4 outputs x 32 block-lanes per workgroup (lane j folds blocks
+// j, j + 32, ... with 4 loads in flight, then the 32 lanes are folded in order)
+__global__ __launch_bounds__(256) void thin1x1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                   int blocks, long KC4) {
+  __shared__ f32x4 red[32][8];
+  const int o = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const long i = (long)blockIdx.x * 8 + o;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (i < KC4) {
+    int b = lane;
+    for (; b + 96 < blocks; b += 128) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(part + ((size_t)b * KC4 + i) * 4);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(part + ((size_t)(b + 32) * KC4 + i) * 4);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(part + ((size_t)(b + 64) * KC4 + i) * 4);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(part + ((size_t)(b + 96) * KC4 + i) * 4);
+      v += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < blocks; b += 32) v += *reinterpret_cast<const f32x4*>(part + ((size_t)b * KC4 + i) * 4);
+  }
+  red[lane][o] = v;
+  __syncthreads();
+  if (lane == 0 && i < KC4) {
+    for (int j = 1; j < 32; ++j) v += red[j][o];
+    *reinterpret_cast<f32x4*>(dw + i * 4) = v;
+  }
+}
+
+constexpr int THIN1_BLOCKS = 2048;   // pixel blocks of the two kernels (8 per CU; 2048 x K x C partial sums)
+
 }  // namespace
 
 extern "C" {
@@ -250,6 +380,34 @@ int dsee_conv3x3_thin_wgrad(const float* x, const float* dout, float* workspace,
   thin_wgrad_reduce_kernel<<<(int)min(4096L, (total + 255) / 256), 256, 0, st>>>(workspace, dw_oihw, NWALK, C, Cout,
                                                                                  Cin);
   DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* Backward of y [M][ldz] = x [M][C] . w^T with w [K][C], K <= 32 (the 27-output 1x1 GEMM of the to-RGB layer, sr.py:65,94, in
+ * ops.conv2d's thin path): dx [M][C] = dz w (NULL: skipped) and dw [K][C] = dz^T x (NULL: skipped).  C % 4 == 0, K <= ldz <= 32,
+ * ldz % 4 == 0 (the padding columns of dz must be finite).
+ * workspace: dsee_thin1x1_bwd_workspace(C, K) bytes (weight gradient only). */
+size_t dsee_thin1x1_bwd_workspace(int C, int K) { return (size_t)THIN1_BLOCKS * K * C * sizeof(float); }
+
+int dsee_thin1x1_bwd(const float* dz, int ldz, const float* w, const float* x, float* dx, float* dw, long M, int C, int K,
+                     float* workspace, hipStream_t st) {
+  DSEE_CHECK_ARG(dz && M > 0 && C % 4 == 0 && K > 0 && K <= 32 && ldz >= K && ldz <= 32 && ldz % 4 == 0);
+  DSEE_CHECK_ARG((!dx || w) && (!dw || (x && workspace)));
+  const int ppb = (int)((M + THIN1_BLOCKS - 1) / THIN1_BLOCKS), blocks = (int)((M + ppb - 1) / ppb);
+  const dim3 grid(blocks, dsee_cdiv(C, 512));
+  if (dx) {
+    if (K <= 28) thin1x1_dgrad_kernel<28><<<grid, 128, 0, st>>>(dz, ldz, w, dx, M, C, K, ppb);
+    else thin1x1_dgrad_kernel<32><<<grid, 128, 0, st>>>(dz, ldz, w, dx, M, C, K, ppb);
+    DSEE_LAUNCH_CHECK();
+  }
+  if (dw) {
+    if (K <= 28) thin1x1_wgrad_kernel<28><<<grid, 128, 0, st>>>(dz, ldz, x, workspace, M, C, K, ppb);
+    else thin1x1_wgrad_kernel<32><<<grid, 128, 0, st>>>(dz, ldz, x, workspace, M, C, K, ppb);
+    DSEE_LAUNCH_CHECK();
+    const long kc4 = (long)K * C / 4;
+    thin1x1_wgrad_reduce_kernel<<<dsee_cdiv(kc4, 8), 256, 0, st>>>(workspace, dw, blocks, kc4);
+    DSEE_LAUNCH_CHECK();
+  }
   return DSEE_OK;
 }
 

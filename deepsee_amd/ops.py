@@ -816,12 +816,23 @@ class Conv2d(torch.autograd.Function):
             if (want["bias"] or want["n0"] is not None or want["n1"] is not None) and \
                     _dout_sums_ok(geom.N, nb_w, geom.Cout, _wgrad_mode(geom.Cin, geom.Cout)):
                 sums = want
-        if fused:
+        # the 27-output 1x1 GEMM of the to-RGB layer (conv2d's thin path): both gradients laid out along the input channels
+        thin1 = (P().thin_gemm and kh == 1 and kw == 1 and geom.ups == 0 and co <= 32 and ci == geom.Cin and not ctx.has_res
+                 and geom.Ho == geom.Hi and geom.Wo == geom.Wi and geom.Cin >= 128)
+        if thin1:
+            m = geom.N * geom.Hi * geom.Wi
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+            if ctx.needs_input_grad[1]:
+                dw = new(co, ci, 1, 1)
+            ws = scratch(L.lib().dsee_thin1x1_bwd_workspace(geom.Cin, co), "wgrad") if dw is not None else None
+            L.call("thin1x1_bwd", g, geom.Cout, w, x, dx, dw, C.c_long(m), geom.Cin, co, ws)
+        elif fused:
             # one A dY A^T transform of g serves the weight gradient AND (adjoint form) the data gradient
             dw, dx = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, w_for_dx=w, sums=sums)
         elif ctx.needs_input_grad[0] and ctx.wino:
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
-        elif ctx.needs_input_grad[0]:
+        elif ctx.needs_input_grad[0] and not thin1:
             gd = L.geom_dgrad(geom)
             dxl = conv_raw(g, _pack_dgrad(w, geom.Cout, gd.korder), gd, amax_cache=getattr(ctx, "amax_cache", None),
                            exact=ctx.exact)
@@ -830,7 +841,7 @@ class Conv2d(torch.autograd.Function):
                 L.call("sumpool", dxl, dx, geom.N, gd.Ho, gd.Wo, geom.Cin, geom.ups)
             else:
                 dx = dxl
-        if dw is not None:
+        if dw is not None or thin1:
             pass
         elif ctx.needs_input_grad[1] and ctx.thin:
             ws = scratch(L.lib().dsee_conv3x3_thin_wgrad_workspace(geom.Cin), "wgrad")

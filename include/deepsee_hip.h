@@ -312,6 +312,13 @@ int dsee_thin_gather_fwd(const float* z, const float* bias, float* out, int N, i
                          float slope, hipStream_t stream);
 int dsee_thin_gather_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int ldz, int Cout, int act,
                          float slope, hipStream_t stream);
+/* Backward of the 27-output 1x1 GEMM the to-RGB layer runs as (y [M][ldz] = x [M][C] . w^T, w [K][C], K <= 32; sr.py:65,94):
+ * dx [M][C] = dz w (NULL: skipped), dw [K][C] = dz^T x (NULL: skipped).  Laid out along the C input channels (a thread owns 4
+ * channels, dz of a pixel is block-uniform): exact fp32 FMAs at HBM speed where the implicit-GEMM kernels fill 27 of 128 tile
+ * columns.  workspace: dsee_thin1x1_bwd_workspace(C, K) bytes (weight gradient only).  C % 4 == 0, K <= ldz <= 32, ldz % 4 == 0. */
+size_t dsee_thin1x1_bwd_workspace(int C, int K);
+int dsee_thin1x1_bwd(const float* dz, int ldz, const float* w, const float* x, float* dx, float* dw, long M, int C, int K,
+                     float* workspace, hipStream_t stream);
 int dsee_conv3x3_thin_fwd(const float* x, const float* w_oihw, const float* bias, float* out, int N, int H, int W, int C,
                           int Cout, int act, float slope, hipStream_t stream);
 size_t dsee_conv3x3_thin_wgrad_workspace(int C);

@@ -993,3 +993,29 @@ def test_winograd_conv_16bit_storage_mode(n, cin, cout, h):
             "dw": rel(wd.grad.cpu().double(), wr.grad), "db": rel(bd.grad.cpu().double(), br.grad)}
     print(errs)
     assert errs["y"] < 8e-3 and errs["dx"] < 8e-3 and errs["dw"] < 8e-3 and errs["db"] < 1e-5, errs
+
+
+@pytest.mark.parametrize("m,c,k,ldz", [(2 * 64 * 64, 512, 27, 28), (3 * 17 * 5, 128, 27, 28), (4096 + 3, 640, 32, 32), (77, 256, 5, 8)])
+def test_thin_1x1_backward(m, c, k, ldz):
+    """dsee_thin1x1_bwd: both gradients of the to-RGB layer's 27-output 1x1 GEMM, laid out along the input channels (exact fp32
+    FMAs; per-block partial sums of the weight gradient folded in a fixed order) against float64; ragged pixel counts, K up to 32,
+    either output optional; bit-reproducible."""
+    from deepsee_amd import lib as L, ops
+    g = torch.Generator().manual_seed(m + c + k)
+    dz = torch.randn(m, ldz, generator=g)
+    w = torch.randn(k, c, generator=g) * 0.1
+    x = torch.randn(m, c, generator=g)
+    want_dx = dz[:, :k].double() @ w.double()
+    want_dw = dz[:, :k].double().t() @ x.double()
+    dzd, wd, xd = dz.cuda(), w.cuda(), x.cuda()
+    ws = ops.scratch(L.lib().dsee_thin1x1_bwd_workspace(c, k), "wgrad")
+    dx, dw = torch.full((m, c), float("nan"), device="cuda"), torch.full((k, c), float("nan"), device="cuda")
+    L.call("thin1x1_bwd", dzd, ldz, wd, xd, dx, dw, C.c_long(m), c, k, ws)
+    torch.cuda.synchronize()
+    assert rel(dx.cpu().double(), want_dx) < 1e-6
+    assert rel(dw.cpu().double(), want_dw) < 2e-6
+    dx2, dw2 = torch.empty_like(dx), torch.empty_like(dw)
+    L.call("thin1x1_bwd", dzd, ldz, wd, None, dx2, None, C.c_long(m), c, k, None)
+    L.call("thin1x1_bwd", dzd, ldz, None, xd, None, dw2, C.c_long(m), c, k, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx) and torch.equal(dw2, dw)
