@@ -30,9 +30,9 @@ __global__ __launch_bounds__(256) void onehot_conv_fwd_kernel(const uint8_t* __r
   if (s < ppb) {
     const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (long m = (long)blockIdx.x * ppb + s; m < M; m += (long)gridDim.x * ppb) {
-      const int w = (int)(m % Rw);
-      const long t = m / Rw;
-      const int h = (int)(t % R), n = (int)(t / R);
+      // (32-bit divisions: M < 2^32 -- the host checks --, and the ISA has no integer divide: dsee_common.h)
+      const unsigned mu_ = (unsigned)m, t_ = mu_ / (unsigned)Rw, n_ = t_ / (unsigned)R;
+      const int w = (int)(mu_ - t_ * (unsigned)Rw), h = (int)(t_ - n_ * (unsigned)R), n = (int)n_;
       f32x4 acc = b;
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
@@ -82,9 +82,9 @@ __global__ __launch_bounds__(1024) void onehot_conv_fwd_lds_kernel(const uint8_t
   const long M = (long)N * R * Rw, stride = (long)gridDim.x * ppb;
   float vmax = amax_floor;
   auto labels = [&](long m, int (&r)[9]) {
-    const int w = (int)(m % Rw);
-    const long t = m / Rw;
-    const int h = (int)(t % R), n = (int)(t / R);
+    // (32-bit divisions: M < 2^32 -- the host checks --, and the ISA has no integer divide: dsee_common.h)
+    const unsigned mu_ = (unsigned)m, t_ = mu_ / (unsigned)Rw, n_ = t_ / (unsigned)R;
+    const int w = (int)(mu_ - t_ * (unsigned)Rw), h = (int)(t_ - n_ * (unsigned)R), n = (int)n_;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
@@ -118,6 +118,69 @@ __global__ __launch_bounds__(1024) void onehot_conv_fwd_lds_kernel(const uint8_t
       }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) cur[tap] = nxt[tap];
+    }
+  }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);
+}
+
+// ... and with 4 consecutive pixels of a row per thread (Rw % 4 == 0): the 32 threads of a pixel all formed the same 9 label
+// addresses and bounds checks, ~300 instructions per 16-byte store (1.8 TB/s of output at 256^2, issue-bound); a run of 4 pixels
+// shares its 3 x 6 label window (18 loads for 4 pixels instead of 36) and one index decomposition.
+__global__ __launch_bounds__(1024) void onehot_conv_fwd_lds4_kernel(const uint8_t* __restrict__ lab,
+                                                                    const float* __restrict__ wt,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    int N, int H, int W, int shift, int R, int Rw, int L,
+                                                                    int Co, int out_ld, int coff, int relu, int onehot_coff,
+                                                                    float* __restrict__ amax, float amax_floor) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  for (int i = threadIdx.x; i < 9 * L * Co / 4; i += 1024)
+    reinterpret_cast<f32x4*>(tab)[i] = reinterpret_cast<const f32x4*>(wt)[i];
+  __syncthreads();
+  const int tpp = Co / 4, gpb = 1024 / tpp;          // pixel runs per block and step
+  const int q = threadIdx.x % tpp, s = threadIdx.x / tpp;
+  const unsigned Rw4 = (unsigned)Rw >> 2;
+  const long G = (long)N * R * Rw4, stride = (long)gridDim.x * gpb;
+  float vmax = amax_floor;
+  if (s < gpb) {
+    const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* const tq = tab + q * 4;
+    for (long g = (long)blockIdx.x * gpb + s; g < G; g += stride) {
+      const unsigned gu = (unsigned)g, t_ = gu / Rw4, n_ = t_ / (unsigned)R;
+      const int w0 = (int)(gu - t_ * Rw4) * 4, h = (int)(t_ - n_ * (unsigned)R), n = (int)n_;
+      int win[3][6];      // labels of rows h-1 .. h+1, columns w0-1 .. w0+4 (-1 outside the image)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int hh = h + a - 1;
+        const bool rin = hh >= 0 && hh < R;
+        const uint8_t* const row = lab + ((size_t)n * H + ((size_t)(rin ? hh : 0) << shift)) * W;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int ww = w0 + c - 1;
+          win[a][c] = (rin && ww >= 0 && ww < Rw) ? (int)row[(size_t)ww << shift] : -1;
+        }
+      }
+      const size_t m0 = ((size_t)n * R + h) * Rw + w0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        f32x4 acc = b;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int r = win[tap / 3][p + tap % 3];
+          if (r >= 0) acc += *reinterpret_cast<const f32x4*>(tq + (tap * L + r) * Co);
+        }
+        if (relu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+        }
+        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + (m0 + p) * out_ld + coff + q * 4));
+        vmax = fmaxf(vmax, dsee_absmax4(acc));
+        if (onehot_coff >= 0 && q < 8) {   // the 32 one-hot label channels of the same pixel (dsee_label_onehot)
+          f32x4 oh;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) oh[k] = (q * 4 + k == win[1][p + 1]) ? 1.f : 0.f;
+          *reinterpret_cast<f32x4*>(out + (m0 + p) * out_ld + onehot_coff + q * 4) = oh;
+        }
+      }
     }
   }
   if (amax) dsee_block_atomic_absmax(amax, vmax);
@@ -163,9 +226,9 @@ __global__ __launch_bounds__(1024) void onehot_conv_wgrad_kernel(const uint8_t* 
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const long m = mb + j;
-      const int w = (int)(m % Rw);
-      const long t = m / Rw;
-      const int h = (int)(t % R), n = (int)(t / R);
+      // (32-bit divisions: M < 2^32 -- the host checks --, and the ISA has no integer divide: dsee_common.h)
+      const unsigned mu_ = (unsigned)m, t_ = mu_ / (unsigned)Rw, n_ = t_ / (unsigned)R;
+      const int w = (int)(mu_ - t_ * (unsigned)Rw), h = (int)(t_ - n_ * (unsigned)R), n = (int)n_;
       {
         const int hh = h + t0 / 3 - 1, ww = w + t0 % 3 - 1;
         r0[j] = (m < m1 && hh >= 0 && hh < R && ww >= 0 && ww < Rw) ? lab_at(lab, n, H, W, shift, hh, ww) : -1;
@@ -222,9 +285,9 @@ __global__ __launch_bounds__(256) void label_onehot_kernel(const uint8_t* __rest
   const int q = threadIdx.x & 7, s = threadIdx.x >> 3;  // 8 float4 per pixel, 32 pixels per block pass
   const long M = (long)N * R * Rw;
   for (long m = (long)blockIdx.x * 32 + s; m < M; m += (long)gridDim.x * 32) {
-    const int w = (int)(m % Rw);
-    const long t = m / Rw;
-    const int h = (int)(t % R), n = (int)(t / R);
+    // (32-bit divisions: M < 2^32 -- the host checks --, and the ISA has no integer divide: dsee_common.h)
+    const unsigned mu_ = (unsigned)m, t_ = mu_ / (unsigned)Rw, n_ = t_ / (unsigned)R;
+    const int w = (int)(mu_ - t_ * (unsigned)Rw), h = (int)(t_ - n_ * (unsigned)R), n = (int)n_;
     const int r = lab_at(lab, n, H, W, shift, h, w);
     f32x4 v;
 #pragma unroll
@@ -243,9 +306,9 @@ __global__ __launch_bounds__(256) void label_gather_kernel(const uint8_t* __rest
   if (s >= ppb) return;
   const long M = (long)N * R * Rw;
   for (long m = (long)blockIdx.x * ppb + s; m < M; m += (long)gridDim.x * ppb) {
-    const int w = (int)(m % Rw);
-    const long t = m / Rw;
-    const int h = (int)(t % R), n = (int)(t / R);
+    // (32-bit divisions: M < 2^32 -- the host checks --, and the ISA has no integer divide: dsee_common.h)
+    const unsigned mu_ = (unsigned)m, t_ = mu_ / (unsigned)Rw, n_ = t_ / (unsigned)R;
+    const int w = (int)(mu_ - t_ * (unsigned)Rw), h = (int)(t_ - n_ * (unsigned)R), n = (int)n_;
     const int r = lab_at(lab, n, H, W, shift, h, w);
     f32x4 v = *reinterpret_cast<const f32x4*>(table + ((size_t)n * L + r) * Cs + q * 4) * scale;
     *reinterpret_cast<f32x4*>(out + m * ld + coff + q * 4) = v;
@@ -325,6 +388,7 @@ int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float*
   DSEE_CHECK_ARG(onehot_coff < 0 || (onehot_coff % 4 == 0 && out_ld >= onehot_coff + 32 && Co >= 32 && L <= 32));
   const int R = H >> shift, Rw = W >> shift;
   const long M = (long)N * R * Rw;
+  DSEE_CHECK_ARG(M < (1L << 32));      // (32-bit pixel index in the kernels)
   const size_t lds = (size_t)9 * L * Co * sizeof(float);
   if (lds <= 150 * 1024 && 1024 % (Co / 4) == 0 && M >= 4096) {
     static size_t attr_lds = 0;   // (the block also holds 64 bytes of static LDS: ask for what is needed, not for 160 KB)
@@ -337,6 +401,21 @@ int dsee_onehot_conv3x3_fwd(const uint8_t* lab, const float* table, const float*
       attr_lds = lds;
     }
     const int ppb1k = 1024 / (Co / 4);
+    if (Rw % 4 == 0) {
+      static size_t attr_lds4 = 0;
+      if (lds > attr_lds4) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&onehot_conv_fwd_lds4_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          (void)hipGetLastError();
+          DSEE_CHECK_ARG(!"onehot_conv_fwd: cannot reserve the LDS table");
+        }
+        attr_lds4 = lds;
+      }
+      onehot_conv_fwd_lds4_kernel<<<(int)min(256L, (M / 4 + ppb1k - 1) / ppb1k), 1024, lds, st>>>(
+          lab, table, bias, out, N, H, W, shift, R, Rw, L, Co, out_ld, coff, relu, onehot_coff, amax, amax_floor);
+      DSEE_LAUNCH_CHECK();
+      return DSEE_OK;
+    }
     onehot_conv_fwd_lds_kernel<<<(int)min(256L, (M + ppb1k - 1) / ppb1k), 1024, lds, st>>>(
         lab, table, bias, out, N, H, W, shift, R, Rw, L, Co, out_ld, coff, relu, onehot_coff, amax, amax_floor);
     DSEE_LAUNCH_CHECK();
