@@ -1116,6 +1116,151 @@ __global__ void wino43_weight_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
+// ---- the same two weight transforms with 8 consecutive k of a row per thread.  The one-k-per-thread kernels above store every
+// fp16 term on its own (72 two-byte stores per weight: 2 TB/s of U at best, store-issue-bound); here a thread forms G g G^T for 8
+// neighbouring input channels and writes each position's 8 values as ONE 16-byte vector per term (two for fp32).  Same expressions
+// in the same order as ggt(): bit-identical U.  split = 0 (fp32), 2 (two-term fp16x2), 3 / 4 (one scaled fp16 term, [K/16] / packed
+// [K/32] rows); the 3-term bf16 form (split = 1) stays on the kernels above.
+template <typename Store>
+__device__ __forceinline__ void ggt8(const float (&g)[8][9], Store&& st) {
+  float t[8][6][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float g0 = g[j][b], g1 = g[j][3 + b], g2 = g[j][6 + b];
+      t[j][0][b] = 0.25f * g0;
+      t[j][1][b] = (-1.f / 6.f) * (g0 + g1 + g2);
+      t[j][2][b] = (-1.f / 6.f) * (g0 - g1 + g2);
+      t[j][3][b] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      t[j][4][b] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      t[j][5][b] = g2;
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t0 = t[j][a][0], t1 = t[j][a][1], t2 = t[j][a][2];
+        v[j] = b == 0   ? 0.25f * t0
+               : b == 1 ? (-1.f / 6.f) * (t0 + t1 + t2)
+               : b == 2 ? (-1.f / 6.f) * (t0 - t1 + t2)
+               : b == 3 ? (1.f / 24.f) * t0 + (1.f / 12.f) * t1 + (1.f / 6.f) * t2
+               : b == 4 ? (1.f / 24.f) * t0 - (1.f / 12.f) * t1 + (1.f / 6.f) * t2
+                        : t2;
+      }
+      st(a * 6 + b, v);
+    }
+}
+
+// 8 values of one position -> U.  base = first element of the position's [rows][Kpad] block in units of the split's element
+// (fp32 / fp16 / 2 x fp16); row, k0 (% 8 == 0) inside it.
+__device__ __forceinline__ void store_u8(float* __restrict__ U, int split, size_t block, size_t per, int rows, int Kpad, int row,
+                                         int k0, float sc, const float (&v)[8]) {
+  if (split == 0) {
+    float* o = U + block * per + (size_t)row * Kpad + k0;
+    *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    return;
+  }
+  _Float16 h0[8], h1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * sc;
+    h0[j] = (_Float16)x;
+    h1[j] = (_Float16)(x - (float)h0[j]);
+  }
+  auto pk = [](_Float16 a, _Float16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+  };
+  const dsee_u32x4 w0 = {pk(h0[0], h0[1]), pk(h0[2], h0[3]), pk(h0[4], h0[5]), pk(h0[6], h0[7])};
+  _Float16* Uh = reinterpret_cast<_Float16*>(U);
+  if (split == 2) {
+    const dsee_u32x4 w1 = {pk(h1[0], h1[1]), pk(h1[2], h1[3]), pk(h1[4], h1[5]), pk(h1[6], h1[7])};
+    _Float16* o = Uh + block * per * 2 + (((size_t)(k0 >> 4) * rows + row) * 2) * 16 + (k0 & 15);
+    *reinterpret_cast<dsee_u32x4*>(o) = w0;
+    *reinterpret_cast<dsee_u32x4*>(o + 16) = w1;
+  } else if (split == 3) {
+    *reinterpret_cast<dsee_u32x4*>(Uh + block * per + ((size_t)(k0 >> 4) * rows + row) * 16 + (k0 & 15)) = w0;
+  } else {
+    *reinterpret_cast<dsee_u32x4*>(Uh + block * per + ((size_t)(k0 >> 5) * rows + row) * 32 + (k0 & 31)) = w0;
+  }
+}
+
+__global__ __launch_bounds__(256) void wino43_weight_table8_kernel(const float* __restrict__ w2a, const float* __restrict__ table,
+                                                                   float* __restrict__ U, int N, int rows, int ca, int Kpad,
+                                                                   int split, const float* __restrict__ amax) {
+  const unsigned K8 = (unsigned)Kpad >> 3;
+  const size_t per = (size_t)rows * Kpad;
+  const long total = (long)N * rows * K8;
+  const float sc = split >= 2 ? dsee_pow2_scale(dsee_amax_read(amax)) : 1.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const unsigned iu = (unsigned)i, rr = iu / K8, n = rr / (unsigned)rows;
+    const int k0 = (int)(iu - rr * K8) * 8, row = (int)(rr - n * (unsigned)rows);
+    float g[8][9];
+    if (k0 < ca) {          // 8 shared embedding columns: 72 contiguous floats of w2a
+      const f32x4* src = reinterpret_cast<const f32x4*>(w2a + ((size_t)row * ca + k0) * 9);
+#pragma unroll
+      for (int q = 0; q < 18; ++q) {
+        const f32x4 v = src[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[(q * 4 + e) / 9][(q * 4 + e) % 9] = v[e];
+      }
+    } else if (k0 < ca + 32) {      // 8 columns of this image's style table: [tap][row][32]
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float* src = table + (((size_t)n * 9 + tap) * rows + row) * 32 + (k0 - ca);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g[e][tap] = a[e];
+          g[4 + e][tap] = b[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) g[j][tap] = 0.f;
+    }
+    ggt8(g, [&](int xi, const float (&v)[8]) { store_u8(U, split, (size_t)xi * N + n, per, rows, Kpad, row, k0, sc, v); });
+  }
+}
+
+__global__ __launch_bounds__(256) void wino43_weight8_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
+                                                             int rows, int Kpad, int transpose_flip, int split,
+                                                             const float* __restrict__ amax, long w_stride, long u_stride) {
+  w += (size_t)blockIdx.y * w_stride;
+  U += (size_t)blockIdx.y * u_stride;
+  if (amax) amax += (size_t)blockIdx.y * (DSEE_AMAX_LINES * DSEE_AMAX_STRIDE);
+  const unsigned K8 = (unsigned)Kpad >> 3;
+  const size_t per = (size_t)rows * Kpad;
+  const long total = (long)rows * K8;
+  const float sc = split >= 2 ? dsee_pow2_scale(dsee_amax_read(amax)) : 1.f;
+  const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const unsigned iu = (unsigned)i, row = iu / K8;
+    const int k0 = (int)(iu - row * K8) * 8;
+    float g[8][9];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      const bool ok = (int)row < R && k < K;
+      const int co = transpose_flip ? k : (int)row, ci = transpose_flip ? (int)row : k;
+      const float* src = w + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int a = tap / 3, b = tap % 3;
+        const int kh = transpose_flip == 1 ? 2 - a : a, kw = transpose_flip == 1 ? 2 - b : b;
+        g[j][tap] = ok ? src[kh * 3 + kw] : 0.f;
+      }
+    }
+    ggt8(g, [&](int xi, const float (&v)[8]) { store_u8(U, split, (size_t)xi, per, rows, Kpad, (int)row, k0, sc, v); });
+  }
+}
+
 // *amax = max(*amax, max |x[0..n)|); 16 bytes per lane, scalar tail
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ amax) {
   float v = 0.f;
@@ -1421,8 +1566,12 @@ int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int tr
   DSEE_CHECK_ARG(w_oihw && U && (split < 2 || amax_w));
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
-  wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip,
-                                                                 split, amax_w, 0, 0);
+  if (split != 1 && Kpad % 8 == 0)
+    wino43_weight8_kernel<<<wgrid((long)rows * Kpad / 8), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip, split,
+                                                                        amax_w, 0, 0);
+  else
+    wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip,
+                                                                   split, amax_w, 0, 0);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1434,9 +1583,14 @@ int dsee_wino43_weights_batch(const float* w_oihw, float* U, int layers, long w_
   DSEE_CHECK_ARG(w_oihw && U && layers > 0 && layers < 65536 && (split < 2 || amax_w));
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
-  wino43_weight_kernel<<<dim3(wgrid((long)rows * Kpad), layers), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad,
-                                                                               transpose_flip, split, amax_w, w_stride,
-                                                                               u_stride);
+  if (split != 1 && Kpad % 8 == 0)
+    wino43_weight8_kernel<<<dim3(wgrid((long)rows * Kpad / 8), layers), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad,
+                                                                                      transpose_flip, split, amax_w, w_stride,
+                                                                                      u_stride);
+  else
+    wino43_weight_kernel<<<dim3(wgrid((long)rows * Kpad), layers), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad,
+                                                                                 transpose_flip, split, amax_w, w_stride,
+                                                                                 u_stride);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -1463,8 +1617,12 @@ int dsee_wino43_weights_table(const float* w2a, const float* table, float* U, in
                               const float* amax_w, hipStream_t st) {
   DSEE_CHECK_ARG(table && U && (ca == 0 || w2a) && ca % 32 == 0 && rows % 128 == 0 && (split < 2 || amax_w));
   const int Kpad = dsee_conv_kpad(1, 1, ca + 32);
-  wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad, split,
-                                                                           amax_w);
+  if (split != 1 && Kpad % 8 == 0)
+    wino43_weight_table8_kernel<<<wgrid((long)N * rows * Kpad / 8), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad, split,
+                                                                                  amax_w);
+  else
+    wino43_weight_table_kernel<<<wgrid((long)N * rows * Kpad), 256, 0, st>>>(w2a, table, U, N, rows, ca, Kpad, split,
+                                                                             amax_w);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
