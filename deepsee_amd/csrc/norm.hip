@@ -366,6 +366,18 @@ __device__ __forceinline__ float store_ata(const f32x4 (&v)[4][4], float* __rest
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4n __attribute__((ext_vector_type(4)));
+
+// the saved modulation factor of element offset o: fp32, or -- 16-bit storage mode -- fp16 (written by dsee_spade_fused_fwd_f16p)
+template <bool S16>
+__device__ __forceinline__ f32x4 ld_scale4(const float* __restrict__ scale, size_t o) {
+  if constexpr (S16) {
+    const f16x4n h = *reinterpret_cast<const f16x4n*>(reinterpret_cast<const _Float16*>(scale) + o);
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  } else {
+    return *reinterpret_cast<const f32x4*>(scale + o);
+  }
+}
 
 // The same 36 values written into the PRE-SPLIT fp16x2 image dM2 [rows/16][36*T][2][16] (winograd.hip:
 // wino43_dout_f16x2_kernel): the four lanes of a 16-column slab (consecutive channel quads, same tile) exchange halves so
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_reduce_wino_split_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = dv[e] * (yv[e] > 0.f ? 1.f : slope);
         }
-        const f32x4 d = g * *reinterpret_cast<const f32x4*>(scale + o);
+        const f32x4 d = g * ld_scale4<PK>(scale, o);
         gg[k][j] = g;
         cx[k] = g * xh;
         acc[0] += d;
@@ -624,7 +636,7 @@ __global__ __launch_bounds__(256) void sums_finalize_kernel(const float* __restr
 }
 
 // ---- backward, pass 2: dx = invstd * (d - S0/M - xhat * S1/M) [+ add]
-template <int MODE>
+template <int MODE, bool S16 = false>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                              const float* __restrict__ x,
                                                              const float* __restrict__ scale,
@@ -662,7 +674,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = dv[k] * dsee_act_grad_from_out(yv[k], act, slope);
     }
-    if constexpr (MODE == 1) d = d * *reinterpret_cast<const f32x4*>(scale + e);
+    if constexpr (MODE == 1) d = d * ld_scale4<S16>(scale, (size_t)e);
     f32x4 r = is * (d - s0 * inv_count - xh * (s1 * inv_count));
     if (add) r += *reinterpret_cast<const f32x4*>(add + e);
     *reinterpret_cast<f32x4*>(dx + e) = r;
@@ -916,14 +928,20 @@ int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, con
  * of this norm, whose A dY A^T transform is then written pre-split with the scale known in advance (dsee_wino43_dout_f16x2) */
 int dsee_modulate_bwd_apply_amax(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                                  const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
-                                 float inv_count, float slope, float* amax_dx, const uint32_t* sign_mask, hipStream_t st) {
+                                 float inv_count, float slope, float* amax_dx, int scale_f16, const uint32_t* sign_mask,
+                                 hipStream_t st) {
   DSEE_CHECK_ARG(dh && (h || sign_mask) && x && scale && mean && invstd && sums && dx && amax_dx && C % 4 == 0 && inv_count > 0.f);
   DSEE_CHECK_ARG(!sign_mask || C % 32 == 0);
   const long total4 = (long)N * HW * C / 4;
   DSEE_CHECK_ARG(total4 < (1L << 32));
-  norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
-                                                             (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope, amax_dx,
-                                                             sign_mask);
+  if (scale_f16)
+    norm_bwd_apply_kernel<1, true><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
+                                                                     (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope,
+                                                                     amax_dx, sign_mask);
+  else
+    norm_bwd_apply_kernel<1><<<grid_for(total4), 256, 0, st>>>(dh, h, x, scale, mean, invstd, sums, add, dx, total4, C,
+                                                               (long)N * HW * C, 1, inv_count, DSEE_ACT_LRELU, slope, amax_dx,
+                                                               sign_mask);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -511,7 +511,13 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + px * 32 + ch);
       const f32x4 xh = (xr[k][it] - mu) * is;
       const f32x4 sc = gv * oscale + bg + a.add_one;
-      if constexpr (WSCALE) __builtin_nontemporal_store(sc, reinterpret_cast<f32x4*>(sb + off));
+      if constexpr (WSCALE && PK) {      // 16-bit storage mode: the saved modulation factor is fp16 as well (8 bytes per lane)
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 sh = {(_Float16)sc[0], (_Float16)sc[1], (_Float16)sc[2], (_Float16)sc[3]};
+        __builtin_nontemporal_store(sh, reinterpret_cast<f16x4*>(sb + (off >> 1)));
+      } else if constexpr (WSCALE) {
+        __builtin_nontemporal_store(sc, reinterpret_cast<f32x4*>(sb + off));
+      }
       f32x4 v = (xh * sc + bb) + bv * oscale;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;

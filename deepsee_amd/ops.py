@@ -1423,7 +1423,11 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     dgb = dm = None
     t = n * (h // 4) * (w // 4)
     dha = carried_amax(dh)
-    if as_dm and P().presplit_dm and P().presplit_gb and xhat_amax is not None and dha is not None and t % 256 == 0:
+    pre = as_dm and P().presplit_dm and P().presplit_gb and xhat_amax is not None and dha is not None and t % 256 == 0
+    s16 = scale.dtype == torch.float16       # written by dsee_spade_fused_fwd_f16p (16-bit storage mode)
+    if s16 and not (pre and P().half):
+        scale, s16 = scale.float(), False    # (a pass the packed kernels do not take: they read fp32)
+    if pre:
         # max |dh| (written by the kernel that produced dh) x max(1, max |xhat|) (written by the forward pass) bounds both halves
         # (g * xhat | g) of the gradient: dM leaves the reduce pass pre-split, for the table / embedding weight gradient's P
         # operand and the adjoint data-gradient GEMM's A operand
@@ -1453,7 +1457,7 @@ def modulate_bwd(dh, out, x, scale, mean, invstd, rows, cfg, as_dm=False, add=No
     da = amax_slot()             # max |dx|: dx is the output gradient of the convolution in front of this norm
     # dx += add: the gradient of the other consumer of x (the resblock shortcut)
     L.call("modulate_bwd_apply_amax", dh.contiguous(), None if mask is not None else out, x, scale, mean, invstd, sums, add, dx,
-           n, h * w, c, 1.0 / count, LRELU_SLOPE, da, mask)
+           n, h * w, c, 1.0 / count, LRELU_SLOPE, da, int(s16), mask)
     tag_amax(dx, da)
     return dx, dgb, sums[2:4], dm
 
@@ -1579,8 +1583,10 @@ class SeanNormTable(torch.autograd.Function):
         nb = ctx.wino_nb = _wino_mod_chunk(n, h, w, c, rows, has_t)
         # `scale` is only read by the backward pass: the no-grad generator forward of the D step does not write it
         need_scale = any(ctx.needs_input_grad) or not nb
-        out, scale = torch.empty_like(x), (torch.empty_like(x) if need_scale else None)
         fused = nb and _fused_norm_ok(n, h, w, c, rows, ld)
+        # (16-bit storage mode: the fused kernel writes the modulation factor as fp16 -- the backward pass is its only reader)
+        sdt = torch.float16 if (fused and P().half) else torch.float32
+        out, scale = torch.empty_like(x), (torch.empty(x.shape, dtype=sdt, device=x.device) if need_scale else None)
         if fused:
             # round 3: gamma/beta GEMM + output transform + normalise + modulate + LeakyReLU in ONE kernel
             # (spade_fused.hip): the Winograd-domain product M never reaches HBM

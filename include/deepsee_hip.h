@@ -170,6 +170,8 @@ int dsee_gemm_f16p_pre(const void* A1, const void* B1, void* C16, long M, int N,
 int dsee_gemm_f16p_tn_pqpre(const void* P1, const void* Q1, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                             int splits, const float* amax_dy, float p_bound, const float* amax_x, float q_bound,
                             hipStream_t stream);
+/* (the saved modulation factor `scale` / `out_scale` of the two f16p entry points below is fp16 [N][H][W][C] as well: it is only
+ * ever read by the backward pass, dsee_modulate_bwd_apply_amax takes it with scale_f16 = 1) */
 int dsee_modulate_bwd_reduce_wino_f16p(const float* dh, const float* h, const float* x, const float* scale,
                                        const float* mean, const float* invstd, void* dM1, int rows, float* sums, int N,
                                        int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
@@ -442,10 +444,11 @@ int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int
 int dsee_modulate_bwd_apply(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                             const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
                             float inv_count, float slope, hipStream_t stream);
-/* ... also writing max |dx| (64-line form): the operand bound of dsee_wino43_dout_f16x2 for the convolution in front of the norm */
+/* ... also writing max |dx| (64-line form): the operand bound of dsee_wino43_dout_f16x2 for the convolution in front of the norm;
+ * scale_f16 != 0: `scale` is the fp16 tensor dsee_spade_fused_fwd_f16p wrote (16-bit storage mode) */
 int dsee_modulate_bwd_apply_amax(const float* dh, const float* h, const float* x, const float* scale, const float* mean,
                                  const float* invstd, const float* sums, const float* add, float* dx, int N, int HW, int C,
-                                 float inv_count, float slope, float* amax_dx, const uint32_t* sign_mask,
+                                 float inv_count, float slope, float* amax_dx, int scale_f16, const uint32_t* sign_mask,
         hipStream_t stream);
 
 /* ------------------------------------------------------------------ label-map kernels (uint8 [N][H][W])

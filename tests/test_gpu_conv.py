@@ -538,7 +538,7 @@ def test_norm_backward_reduce_writes_pre_split_gradient(n, h, c):
     x = (torch.randn(n, h, h, c, generator=g) * 2 + 0.3).cuda()
     dh = (torch.randn(n, h, h, c, generator=g) * 0.01).cuda()
     out = torch.randn(n, h, h, c, generator=g).cuda()             # (only its sign is used: LeakyReLU branch)
-    scale = (torch.rand(n, h, h, c, generator=g) + 0.5).cuda()
+    scale = (torch.rand(n, h, h, c, generator=g) + 0.5).half().float().cuda()      # (values fp16 holds exactly: see scale16 below)
     mean, invstd = (torch.randn(c, generator=g) * 0.3).cuda(), (torch.rand(c, generator=g) + 0.5).cuda()
     rows, t = 2 * c, n * (h // 4) ** 2
     ws = ops.scratch(L.lib().dsee_modulate_bwd_wino_workspace(n, h, h, c), "norm")
@@ -562,7 +562,9 @@ def test_norm_backward_reduce_writes_pre_split_gradient(n, h, c):
     assert rel(sums.cpu(), sums_ref.cpu()) < 1e-5          # (same sums, folded in a different fixed order)
     # 16-bit storage mode: the same pass writing the packed one-term image (one scaled fp16 term per element)
     dm1, sums1 = ops._i16(36 * t * rows), ops.new(4, c)
-    L.call("modulate_bwd_reduce_wino_f16p", dh, out, x, scale, mean, invstd, dm1, rows, sums1, n, h, h, c, 0.2, ws, ga,
+    # (... reading the fp16 modulation factor dsee_spade_fused_fwd_f16p saves)
+    scale16 = scale.half()
+    L.call("modulate_bwd_reduce_wino_f16p", dh, out, x, scale16, mean, invstd, dm1, rows, sums1, n, h, h, c, 0.2, ws, ga,
            ops.DM_BOUND, None)
     torch.cuda.synchronize()
     dec1 = dm1.view(torch.float16).view(rows // 32, 36 * t, 32).permute(1, 0, 2).reshape(36, t, rows).float() / _pow2_scale(bound)
@@ -573,16 +575,22 @@ def test_norm_backward_reduce_writes_pre_split_gradient(n, h, c):
     mask = _sign_words(out)
     for name, want_dm, width in (("modulate_bwd_reduce_wino_f16x2", dm2, 2), ("modulate_bwd_reduce_wino_f16p", dm1, 1)):
         dmm, sm = ops._i16(36 * t * rows * width), ops.new(4, c)
-        L.call(name, dh, None, x, scale, mean, invstd, dmm, rows, sm, n, h, h, c, 0.2, ws, ga, ops.DM_BOUND, mask)
+        L.call(name, dh, None, x, scale if width == 2 else scale16, mean, invstd, dmm, rows, sm, n, h, h, c, 0.2, ws, ga,
+               ops.DM_BOUND, mask)
         torch.cuda.synchronize()
         assert torch.equal(dmm, want_dm) and torch.equal(sm, sums)
     dx0, dx1, da0, da1 = torch.empty_like(x), torch.empty_like(x), ops.amax_slot(), ops.amax_slot()
     L.call("modulate_bwd_apply_amax", dh, out, x, scale, mean, invstd, sums, None, dx0, n, h * h, c, 1.0 / (n * h * h), 0.2, da0,
-           None)
+           0, None)
     L.call("modulate_bwd_apply_amax", dh, None, x, scale, mean, invstd, sums, None, dx1, n, h * h, c, 1.0 / (n * h * h), 0.2, da1,
-           mask)
+           0, mask)
     torch.cuda.synchronize()
     assert torch.equal(dx0, dx1) and torch.equal(da0, da1) and float(dx0.abs().max()) > 0
+    dx2, da2 = torch.empty_like(x), ops.amax_slot()        # the fp16 form of the same scale: the same bits
+    L.call("modulate_bwd_apply_amax", dh, None, x, scale16, mean, invstd, sums, None, dx2, n, h * h, c, 1.0 / (n * h * h), 0.2, da2,
+           1, mask)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx2) and torch.equal(da0, da2)
 
 
 def test_f16x2_special_values():
@@ -730,7 +738,9 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale, packed):
         L.call("wino43_weights_table", w2a.cuda(), table.cuda(), u, n, rows, ca, sp, ua)
     else:
         u, ua = ops._wino_u(w2a.cuda(), rows, ca, False, rows, K, sp)
-    out, sc = torch.empty_like(xd), (torch.empty_like(xd) if with_scale else None)
+    # (16-bit storage mode: the saved modulation factor is fp16 too)
+    out, sc = torch.empty_like(xd), (torch.empty(xd.shape, dtype=torch.float16 if packed else torch.float32, device="cuda")
+                                     if with_scale else None)
     sink = torch.zeros(1, device="cuda")
     first = None
     for it in range(4):

@@ -30,8 +30,9 @@ dm2 = ops._i16(36 * t * rows * 2)
 t2 = timeit(lambda: L.call("modulate_bwd_reduce_wino_f16x2", dh, out, x, scale, mean, invstd, dm2, rows, sums, n, h, h, c, 0.2, ws, ga, 1.0, MASK))
 print("reduce two-term : %.3f ms  (%.2f TB/s on 4 x 1.07 GB read + 4.8 GB written)" % (t2, (4 * x.numel() * 4 + dm2.numel() * 2) / t2 / 1e9))
 dm1 = ops._i16(36 * t * rows)
-t1 = timeit(lambda: L.call("modulate_bwd_reduce_wino_f16p", dh, out, x, scale, mean, invstd, dm1, rows, sums, n, h, h, c, 0.2, ws, ga, 1.0, MASK))
+scale16 = scale.half()
+t1 = timeit(lambda: L.call("modulate_bwd_reduce_wino_f16p", dh, out, x, scale16, mean, invstd, dm1, rows, sums, n, h, h, c, 0.2, ws, ga, 1.0, MASK))
 print("reduce packed   : %.3f ms  (%.2f TB/s)" % (t1, (4 * x.numel() * 4 + dm1.numel() * 2) / t1 / 1e9))
 dx = torch.empty_like(x); da = ops.amax_slot()
-ta = timeit(lambda: L.call("modulate_bwd_apply_amax", dh, out, x, scale, mean, invstd, sums, None, dx, n, h * h, c, 1.0 / (n * h * h), 0.2, da, MASK))
+ta = timeit(lambda: L.call("modulate_bwd_apply_amax", dh, out, x, scale, mean, invstd, sums, None, dx, n, h * h, c, 1.0 / (n * h * h), 0.2, da, 0, MASK))
 print("apply           : %.3f ms  (%.2f TB/s)" % (ta, 5 * x.numel() * 4 / ta / 1e9))
