@@ -171,6 +171,40 @@ __global__ __launch_bounds__(256) void thin_gather_fwd_kernel(const float* __res
   }
 }
 
+// The same gather with the z rows of a 16 x 16 pixel tile and its halo staged in LDS through coalesced 16-byte loads (H, W
+// multiples of 16, ldz % 4 == 0, ldz <= 32): a thread of the form above issues 27 four-byte loads at a 112-byte lane stride --
+// 178 us for 59 MB at 256^2.
+__global__ __launch_bounds__(256) void thin_gather_fwd_tile_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                                   float* __restrict__ out, int N, int H, int W, int ldz,
+                                                                   int Cout, int act, float slope) {
+  __shared__ __attribute__((aligned(16))) float zs[18 * 18 * 32];
+  const int tw = W >> 4, th = H >> 4;
+  const int bx = blockIdx.x % tw, by = (blockIdx.x / tw) % th, n = blockIdx.x / (tw * th);
+  const int l4 = ldz >> 2;
+  for (int i = threadIdx.x; i < 18 * 18 * l4; i += 256) {
+    const int px = i / l4, q = i - px * l4;
+    const int hy = px / 18, hx = px - hy * 18;
+    const int y = by * 16 + hy - 1, x = bx * 16 + hx - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const f32x4*>(z + (((size_t)n * H + y) * W + x) * ldz + q * 4);
+    *reinterpret_cast<f32x4*>(zs + px * ldz + q * 4) = v;      // (zero rows outside the image: the padding of the convolution)
+  }
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  float acc[TCO] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* zp = zs + ((ty + t / 3) * 18 + tx + t % 3) * ldz + t * Cout;
+#pragma unroll
+    for (int co = 0; co < TCO; ++co)
+      if (co < Cout) acc[co] += zp[co];
+  }
+  f32x4 o;
+#pragma unroll
+  for (int co = 0; co < TCO; ++co) o[co] = co < Cout ? dsee_act(acc[co] + (bias ? bias[co] : 0.f), act, slope) : 0.f;
+  *reinterpret_cast<f32x4*>(out + (((size_t)n * H + by * 16 + ty) * W + bx * 16 + tx) * TCO) = o;
+}
+
 // dz[p][tap*Cout + co] = g[p - d(tap)][co], g = dout * act'(out)   (every element of dz is written, padding columns 0)
 __global__ __launch_bounds__(256) void thin_gather_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                               float* __restrict__ dz, int N, int H, int W, int ldz, int Cout,
@@ -352,6 +386,11 @@ int dsee_conv3x3_thin_fwd(const float* x, const float* w_oihw, const float* bias
 int dsee_thin_gather_fwd(const float* z, const float* bias, float* out, int N, int H, int W, int ldz, int Cout, int act,
                          float slope, hipStream_t st) {
   DSEE_CHECK_ARG(z && out && Cout >= 1 && Cout <= TCO && ldz >= 9 * Cout);
+  if (H % 16 == 0 && W % 16 == 0 && ldz % 4 == 0 && ldz <= 32 && (long)N * (H / 16) * (W / 16) < (1L << 31)) {
+    thin_gather_fwd_tile_kernel<<<N * (H / 16) * (W / 16), 256, 0, st>>>(z, bias, out, N, H, W, ldz, Cout, act, slope);
+    DSEE_LAUNCH_CHECK();
+    return DSEE_OK;
+  }
   thin_gather_fwd_kernel<<<(int)min(8192L, ((long)N * H * W + 255) / 256), 256, 0, st>>>(z, bias, out, N, H, W, ldz, Cout,
                                                                                          act, slope);
   DSEE_LAUNCH_CHECK();

@@ -201,10 +201,12 @@ def test_gemm_bf16x3_is_fp32_accurate(groups, tg, n, k, tile):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,act,use_bias", [(2, 256, 3, 8, 64, 3, True), (1, 512, 3, 12, 128, 0, False),
-                                                          (2, 512, 1, 4, 64, 1, True)])
+                                                          (2, 512, 1, 4, 64, 1, True), (2, 128, 3, 32, 48, 3, True),
+                                                          (1, 512, 2, 16, 16, 1, False)])
 def test_thin_conv3x3(n, cin, cout, h, w, act, use_bias):
-    """The to-RGB layer (512 -> 3, tanh) runs on the channel-walking VALU kernels of thin.hip (forward + weight
-    gradient; exact fp32 FMAs, different summation order than ATen): ops.conv2d must route there."""
+    """The to-RGB layer (512 -> 3, tanh): ops.conv2d routes it to the thin path -- a 27-output 1x1 GEMM + a 9-point gather (tiled
+    through LDS when H, W are multiples of 16), backward on the channel-walking kernels of thin.hip (exact fp32 FMAs, different
+    summation order than ATen)."""
     from deepsee_amd import ops
     g = torch.Generator().manual_seed(cin + cout + w)
     x = torch.randn(n, cin, h, w, generator=g).requires_grad_()
