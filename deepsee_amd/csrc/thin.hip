@@ -252,7 +252,12 @@ __device__ __forceinline__ void thin1_stage(float* __restrict__ zs, const float*
 
 template <int KMAX>
 __global__ __launch_bounds__(128) void thin1x1_dgrad_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ w,
-                                                            float* __restrict__ dx, long M, int C, int K, int px_per_block) {
+                                                            float* __restrict__ dx, long M, int C, int K, int px_per_block,
+                                                            const float* __restrict__ act_x, float slope,
+                                                            float* __restrict__ amax) {
+  // act_x (optional): the layer input x = LeakyReLU(pre), whose producer left its activation's backward to this kernel:
+  // dx *= x > 0 ? 1 : slope (the pass over dx, x and out that producer would run is 2 GB of traffic at 256^2); amax: max |dx|
+  float vmax = 0.f;
   __shared__ __attribute__((aligned(16))) float zs[THIN1_CHUNK * 32];
   const int c = (blockIdx.y * 128 + threadIdx.x) * 4;
   const bool on = c < C;
@@ -278,9 +283,16 @@ __global__ __launch_bounds__(128) void thin1x1_dgrad_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc += z[e] * wr[k4 * 4 + e];
       }
+      if (act_x) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(act_x + (mc + p) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] *= xv[e] > 0.f ? 1.f : slope;
+      }
+      vmax = fmaxf(vmax, dsee_absmax4(acc));
       __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(dx + (mc + p) * C + c));
     }
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);      // (every thread arrives here)
 }
 
 // part[block][k][c] = sum over the block's pixels of dz[m][k] x[m][c]
@@ -425,18 +437,21 @@ int dsee_conv3x3_thin_wgrad(const float* x, const float* dout, float* workspace,
 /* Backward of y [M][ldz] = x [M][C] . w^T with w [K][C], K <= 32 (the 27-output 1x1 GEMM of the to-RGB layer, sr.py:65,94, in
  * ops.conv2d's thin path): dx [M][C] = dz w (NULL: skipped) and dw [K][C] = dz^T x (NULL: skipped).  C % 4 == 0, K <= ldz <= 32,
  * ldz % 4 == 0 (the padding columns of dz must be finite).
- * workspace: dsee_thin1x1_bwd_workspace(C, K) bytes (weight gradient only). */
+ * workspace: dsee_thin1x1_bwd_workspace(C, K) bytes (weight gradient only).
+ * in_lrelu != 0: x = LeakyReLU(pre) came out of a producer that leaves its activation's backward to this call -- dx is the
+ * gradient w.r.t. `pre` (dx *= x > 0 ? 1 : slope); amax_dx (optional, 64-line form): max |dx|. */
 size_t dsee_thin1x1_bwd_workspace(int C, int K) { return (size_t)THIN1_BLOCKS * K * C * sizeof(float); }
 
 int dsee_thin1x1_bwd(const float* dz, int ldz, const float* w, const float* x, float* dx, float* dw, long M, int C, int K,
-                     float* workspace, hipStream_t st) {
+                     float* workspace, int in_lrelu, float slope, float* amax_dx, hipStream_t st) {
   DSEE_CHECK_ARG(dz && M > 0 && C % 4 == 0 && K > 0 && K <= 32 && ldz >= K && ldz <= 32 && ldz % 4 == 0);
-  DSEE_CHECK_ARG((!dx || w) && (!dw || (x && workspace)));
+  DSEE_CHECK_ARG((!dx || w) && (!dw || (x && workspace)) && (!in_lrelu || x));
   const int ppb = (int)((M + THIN1_BLOCKS - 1) / THIN1_BLOCKS), blocks = (int)((M + ppb - 1) / ppb);
   const dim3 grid(blocks, dsee_cdiv(C, 512));
   if (dx) {
-    if (K <= 28) thin1x1_dgrad_kernel<28><<<grid, 128, 0, st>>>(dz, ldz, w, dx, M, C, K, ppb);
-    else thin1x1_dgrad_kernel<32><<<grid, 128, 0, st>>>(dz, ldz, w, dx, M, C, K, ppb);
+    const float* ax = in_lrelu ? x : nullptr;
+    if (K <= 28) thin1x1_dgrad_kernel<28><<<grid, 128, 0, st>>>(dz, ldz, w, dx, M, C, K, ppb, ax, slope, amax_dx);
+    else thin1x1_dgrad_kernel<32><<<grid, 128, 0, st>>>(dz, ldz, w, dx, M, C, K, ppb, ax, slope, amax_dx);
     DSEE_LAUNCH_CHECK();
   }
   if (dw) {

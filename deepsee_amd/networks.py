@@ -347,7 +347,8 @@ class SPADEResnetBlock(nn.Module):
         if self.add_noise_cfg:
             self.noise_in, self.noise_skip, self.noise_middle = VecP(c), VecP(c), VecP(c)
 
-    def forward(self, x, labels, style, noise, tag, ups, training, out_act=L.ACT_NONE):
+    def forward(self, x, labels, style, noise, tag, ups, training, out_act=L.ACT_NONE, defer_act_bwd=False):
+        """`defer_act_bwd`: the block's only consumer applies the backward of `out_act` (ops.Conv2d.forward)."""
         noisy = self.add_noise_cfg and training
         n, h0, w0, c = x.shape
         shp = (n, h0 << ups, w0 << ups, c)
@@ -368,7 +369,7 @@ class SPADEResnetBlock(nn.Module):
                         stats=training)
         h = self.norm_1(dx, labels, style, training)
         return ops.conv2d(h, self.conv_1.weight(training), self.conv_1.bias, res=x, act=out_act, res_noise=res_noise,
-                          res_sink=sink)
+                          res_sink=sink, defer_act_bwd=defer_act_bwd)
 
 
 class DeepSEESR(nn.Module):
@@ -396,9 +397,11 @@ class DeepSEESR(nn.Module):
         x = ops.conv2d(image_lr, self.initial.weight, self.initial.bias)
         for i, (tag, blk, ups) in enumerate(blocks):
             # the LeakyReLU in front of conv_img (sr.py:94) rides in the last block's epilogue
+            # ... and its BACKWARD in conv_img's data-gradient kernel (x has no other consumer): ops.Conv2d.forward
             last = i == len(blocks) - 1
-            x = blk(x, labels, style, noise, tag, ups, training, L.ACT_LRELU if last else L.ACT_NONE)
-        return ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, act=L.ACT_TANH)
+            defer = last and torch.is_grad_enabled() and x.requires_grad and ops.P().defer_act
+            x = blk(x, labels, style, noise, tag, ups, training, L.ACT_LRELU if last else L.ACT_NONE, defer)
+        return ops.conv2d(x, self.conv_img.weight, self.conv_img.bias, act=L.ACT_TANH, in_act=L.ACT_LRELU if defer else 0)
 
 
 # ------------------------------------------------------------------------------------ style encoders

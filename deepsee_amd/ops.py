@@ -738,10 +738,16 @@ class Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, res, stride, pad, ups, act, noise_w=None, noise_eps=None, res_noise_w=None,
-                res_noise_eps=None, res_sink=None, exact=False, stats=False):
-        """`exact`: keep a direct convolution on the fp32 MFMA (no operand-maximum passes over its activations)."""
+                res_noise_eps=None, res_sink=None, exact=False, stats=False, in_act=0, defer_act_bwd=False):
+        """`exact`: keep a direct convolution on the fp32 MFMA (no operand-maximum passes over its activations).
+        `defer_act_bwd` / `in_act` are the two halves of ONE contract set up by the caller (networks.DeepSEESR.forward): this
+        layer's output y = LeakyReLU(.) has exactly one consumer, a convolution called with `in_act = ACT_LRELU`, whose backward
+        multiplies the gradient it hands back by LeakyReLU'(y) (inside its data-gradient kernel where it can) and attaches its
+        maximum; this layer's backward then skips its own pass over (dy, y) -> g."""
         ctx.plan = P()
         ctx.exact = bool(exact)
+        ctx.in_act, ctx.defer_act_bwd = int(in_act or 0), bool(defer_act_bwd)
+        assert ctx.in_act in (0, L.ACT_LRELU) and (not ctx.defer_act_bwd or act == L.ACT_LRELU)
         _bind_rng(noise_eps, res_noise_eps)
         co, ci, kh, kw = w.shape
         n, hi, wi, cin_s = x.shape
@@ -795,7 +801,9 @@ class Conv2d(torch.autograd.Function):
         geom = ctx.geom
         co, ci, kh, kw = w.shape
         dy = dy.contiguous()
-        if ctx.act != L.ACT_NONE and ctx.wino and P().presplit_dm:
+        if ctx.defer_act_bwd:
+            g = dy          # (the consumer's backward already applied LeakyReLU'(out) and tagged max |g|: see forward)
+        elif ctx.act != L.ACT_NONE and ctx.wino and P().presplit_dm:
             g = torch.empty_like(dy)
             tag_amax(g, amax_slot())      # (the A dY A^T transform below is written pre-split with this bound)
             L.call("act_bwd_amax", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE, g.dsee_amax)
@@ -826,7 +834,11 @@ class Conv2d(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = new(co, ci, 1, 1)
             ws = scratch(L.lib().dsee_thin1x1_bwd_workspace(geom.Cin, co), "wgrad") if dw is not None else None
-            L.call("thin1x1_bwd", g, geom.Cout, w, x, dx, dw, C.c_long(m), geom.Cin, co, ws)
+            da = None
+            if dx is not None and ctx.in_act:
+                da = amax_slot()       # (x = LeakyReLU(.) of a producer that deferred its activation's backward to this kernel)
+                tag_amax(dx, da)
+            L.call("thin1x1_bwd", g, geom.Cout, w, x, dx, dw, C.c_long(m), geom.Cin, co, ws, int(da is not None), LRELU_SLOPE, da)
         elif fused:
             # one A dY A^T transform of g serves the weight gradient AND (adjoint form) the data gradient
             dw, dx = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, w_for_dx=w, sums=sums)
@@ -874,7 +886,13 @@ class Conv2d(torch.autograd.Function):
         else:
             dnw = noise_wgrad(ctx.noise) if (ctx.noise is not None and ctx.needs_input_grad[8]) else None
             drnw = noise_wgrad(ctx.res_noise) if (ctx.res_noise is not None and ctx.needs_input_grad[10]) else None
-        return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None, None, None
+        if ctx.in_act and dx is not None and not thin1:
+            # (any other kernel path of a layer under the `in_act` contract: the deferred LeakyReLU backward as its own pass)
+            gx = torch.empty_like(dx)
+            tag_amax(gx, amax_slot())
+            L.call("act_bwd_amax", dx.contiguous(), x, gx, C.c_long(dx.numel()), ctx.in_act, LRELU_SLOPE, gx.dsee_amax)
+            dx = gx
+        return dx, dw, db, dres, None, None, None, None, dnw, None, drnw, None, None, None, None, None, None
 
 
 class GradSink:
@@ -942,17 +960,20 @@ def _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
 
 
 def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, noise=None, res_noise=None, res_sink=None,
-           stats=False):
+           stats=False, in_act=0, defer_act_bwd=False):
     """`noise` = (noise_w, eps): the NoiseInjection that follows the conv; `res_noise` = (noise_w, eps): the
     NoiseInjection on the residual (the shortcut x_s = noise_skip(x)).  PhiloxNormal draws on a Winograd layer ride in
     the output transform; anything else (a replayed tensor, a non-Winograd layer) runs as its own UpNoise pass.
     `res_sink` (GradSink): the residual's gradient is handed to the norm backward instead of the autograd engine.
     `stats`: the output feeds a training-mode BatchNorm -- a Winograd layer then writes the statistics rows in its output
-    transform (bn_stats finds them on the tensor)."""
+    transform (bn_stats finds them on the tensor).
+    `in_act` / `defer_act_bwd`: see Conv2d.forward (x is the LeakyReLU output of a layer called with defer_act_bwd)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        in_act = 0
     if _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
         co, ci = w.shape[0], w.shape[1]
         w27 = w.permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1)          # row tap*co_n + co (55 KB of parameter glue)
-        z = Conv2d.apply(x, w27, None, None, 1, 0, 0, L.ACT_NONE, None, None, None, None, None, True)
+        z = Conv2d.apply(x, w27, None, None, 1, 0, 0, L.ACT_NONE, None, None, None, None, None, True, False, in_act)
         return ThinGather.apply(z, bias, co, act)
     if res_noise is not None and not _fusable_noise(x, w, stride, pad, ups, res_noise[1]):
         # (the shortcut's own node must see its gradient: no sink)
@@ -960,8 +981,10 @@ def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, no
     rn = (None, None) if res_noise is None else res_noise
     if noise is None or (_fusable_noise(x, w, stride, pad, ups, noise[1]) and act == L.ACT_NONE):
         nz = (None, None) if noise is None else noise
-        return Conv2d.apply(x, w, bias, res, stride, pad, ups, act, nz[0], nz[1], rn[0], rn[1], res_sink, False, bool(stats))
-    y = Conv2d.apply(x, w, bias, res, stride, pad, ups, act, None, None, rn[0], rn[1], res_sink)
+        return Conv2d.apply(x, w, bias, res, stride, pad, ups, act, nz[0], nz[1], rn[0], rn[1], res_sink, False, bool(stats),
+                            in_act, defer_act_bwd)
+    assert not defer_act_bwd
+    y = Conv2d.apply(x, w, bias, res, stride, pad, ups, act, None, None, rn[0], rn[1], res_sink, False, False, in_act)
     return UpNoise.apply(y, noise[0], noise[1], 0)
 
 

@@ -72,6 +72,9 @@ class KernelPlan:
     # the fused forward also writes the LeakyReLU branch of h as a bit mask ([pixel][C/32] words) and the two passes of the norm
     # backward read it instead of h (False: they read h, 32x the bytes, for its sign)
     sign_mask: bool = True
+    # the backward of the LeakyReLU in front of the to-RGB layer inside that layer's data-gradient kernel (False: the last
+    # resblock's own pass over (dy, y))
+    defer_act: bool = True
     # direct (non-Winograd) convolutions with at least this much work run their MFMAs on fp16x2-split operands; 0 disables
     conv_f16x2_min_flop: float = 1e9
     # SyncBN-over-RCCL (ops.SyncBNConfig) or None for north_star's sync-free BatchNorm

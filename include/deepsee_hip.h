@@ -317,10 +317,14 @@ int dsee_thin_gather_bwd(const float* dout, const float* out, float* dz, int N, 
 /* Backward of the 27-output 1x1 GEMM the to-RGB layer runs as (y [M][ldz] = x [M][C] . w^T, w [K][C], K <= 32; sr.py:65,94):
  * dx [M][C] = dz w (NULL: skipped), dw [K][C] = dz^T x (NULL: skipped).  Laid out along the C input channels (a thread owns 4
  * channels, dz of a pixel is block-uniform): exact fp32 FMAs at HBM speed where the implicit-GEMM kernels fill 27 of 128 tile
- * columns.  workspace: dsee_thin1x1_bwd_workspace(C, K) bytes (weight gradient only).  C % 4 == 0, K <= ldz <= 32, ldz % 4 == 0. */
+ * columns.  workspace: dsee_thin1x1_bwd_workspace(C, K) bytes (weight gradient only).  C % 4 == 0, K <= ldz <= 32, ldz % 4 == 0.
+ * in_lrelu != 0: x = LeakyReLU(pre) is the output of a convolution whose epilogue applied the activation (the last resblock in
+ * front of conv_img, sr.py:94) and which leaves the activation's BACKWARD to this call: dx is the gradient w.r.t. `pre`
+ * (dx *= x > 0 ? 1 : slope) and amax_dx (optional, 64-line form) receives max |dx| -- in place of that layer's own pass over
+ * (dx, x) -> g, 2 GB of traffic at 256^2. */
 size_t dsee_thin1x1_bwd_workspace(int C, int K);
 int dsee_thin1x1_bwd(const float* dz, int ldz, const float* w, const float* x, float* dx, float* dw, long M, int C, int K,
-                     float* workspace, hipStream_t stream);
+                     float* workspace, int in_lrelu, float slope, float* amax_dx, hipStream_t stream);
 int dsee_conv3x3_thin_fwd(const float* x, const float* w_oihw, const float* bias, float* out, int N, int H, int W, int C,
                           int Cout, int act, float slope, hipStream_t stream);
 size_t dsee_conv3x3_thin_wgrad_workspace(int C);

@@ -1022,12 +1022,18 @@ def test_thin_1x1_backward(m, c, k, ldz):
     dzd, wd, xd = dz.cuda(), w.cuda(), x.cuda()
     ws = ops.scratch(L.lib().dsee_thin1x1_bwd_workspace(c, k), "wgrad")
     dx, dw = torch.full((m, c), float("nan"), device="cuda"), torch.full((k, c), float("nan"), device="cuda")
-    L.call("thin1x1_bwd", dzd, ldz, wd, xd, dx, dw, C.c_long(m), c, k, ws)
+    L.call("thin1x1_bwd", dzd, ldz, wd, xd, dx, dw, C.c_long(m), c, k, ws, 0, 0.2, None)
     torch.cuda.synchronize()
     assert rel(dx.cpu().double(), want_dx) < 1e-6
     assert rel(dw.cpu().double(), want_dw) < 2e-6
     dx2, dw2 = torch.empty_like(dx), torch.empty_like(dw)
-    L.call("thin1x1_bwd", dzd, ldz, wd, None, dx2, None, C.c_long(m), c, k, None)
-    L.call("thin1x1_bwd", dzd, ldz, None, xd, None, dw2, C.c_long(m), c, k, ws)
+    L.call("thin1x1_bwd", dzd, ldz, wd, None, dx2, None, C.c_long(m), c, k, None, 0, 0.2, None)
+    L.call("thin1x1_bwd", dzd, ldz, None, xd, None, dw2, C.c_long(m), c, k, ws, 0, 0.2, None)
     torch.cuda.synchronize()
     assert torch.equal(dx2, dx) and torch.equal(dw2, dw)
+    # in_lrelu: x is the LeakyReLU output of a producer that left its activation's backward to this kernel
+    dx3, am = torch.empty_like(dx), ops.amax_slot()
+    L.call("thin1x1_bwd", dzd, ldz, wd, xd, dx3, None, C.c_long(m), c, k, None, 1, 0.2, am)
+    torch.cuda.synchronize()
+    want3 = dx * torch.where(xd > 0, 1.0, 0.2)
+    assert torch.equal(dx3, want3) and float(am.max()) == float(want3.abs().max())

@@ -15,7 +15,7 @@ def timeit(fn, it=20):
     for _ in range(it): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / it
-t = timeit(lambda: L.call("thin1x1_bwd", dz, ldz, w, None, dx, None, C.c_long(m), c, k, None))
+t = timeit(lambda: L.call("thin1x1_bwd", dz, ldz, w, None, dx, None, C.c_long(m), c, k, None, 0, 0.2, None))
 print("data gradient  : %.3f ms  %.2f TB/s" % (t, x.numel() * 4 / 1e9 / t))
-t = timeit(lambda: L.call("thin1x1_bwd", dz, ldz, None, x, None, dw, C.c_long(m), c, k, ws))
+t = timeit(lambda: L.call("thin1x1_bwd", dz, ldz, None, x, None, dw, C.c_long(m), c, k, ws, 0, 0.2, None))
 print("weight gradient: %.3f ms  %.2f TB/s" % (t, x.numel() * 4 / 1e9 / t))
