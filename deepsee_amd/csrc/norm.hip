@@ -774,7 +774,7 @@ int dsee_norm_eval_stats(const float* running_mean, const float* running_var, in
 
 int dsee_norm_act_fwd(const float* x, const float* mean, const float* invstd, float* y, int N, int HW, int C,
                       int groups, int act, float slope, hipStream_t st) {
-  DSEE_CHECK_ARG(x && mean && invstd && y && C % 4 == 0 && N % groups == 0);
+  DSEE_CHECK_ARG(x && mean && invstd && y && C % 4 == 0 && N % groups == 0 && (long)N * HW * C / 4 < (1L << 32));
   const long total4 = (long)N * HW * C / 4;
   norm_act_fwd_kernel<<<grid_for(total4), 256, 0, st>>>(x, mean, invstd, y, total4, C, (long)(N / groups) * HW * C, act,
                                                         slope);
@@ -845,6 +845,7 @@ int dsee_modulate_bwd_reduce_wino(const float* dh, const float* h, const float* 
                                   float slope, float* workspace, float* amax, hipStream_t st) {
   DSEE_CHECK_ARG(dh && h && x && scale && mean && invstd && dM && sums && workspace);
   DSEE_CHECK_ARG(C % 64 == 0 && C <= 1024 && 256 % (C / 4) == 0 && rows == 2 * C && H % 4 == 0 && W % 4 == 0);
+  DSEE_CHECK_ARG((long)N * H * W * C / 64 < (1L << 32));      // (32-bit item index in the kernels: dsee_common.h)
   const int blocks = wino_reduce_blocks(N, H, W, C);
   norm_bwd_reduce_wino_kernel<<<blocks, 256, 0, st>>>(dh, h, x, scale, mean, invstd, dM, rows, workspace, N, H, W, C,
                                                       slope, amax);
@@ -865,6 +866,7 @@ static int reduce_wino_split_launch(const float* dh, const float* h, const float
                                         const uint32_t* sign_mask, hipStream_t st) {
   DSEE_CHECK_ARG(dh && (h || sign_mask) && x && scale && mean && invstd && dM2 && sums && workspace && amax_g && bound >= DSEE_WINO_DM_BOUND);
   DSEE_CHECK_ARG(C % 64 == 0 && C <= 1024 && 256 % (C / 4) == 0 && rows == 2 * C && H % 4 == 0 && W % 4 == 0);
+  DSEE_CHECK_ARG((long)N * H * W * C / 64 < (1L << 32));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 16 == 0);
   // a grid whose wave count is a multiple of the C/64 channel groups (every wave keeps its channels)
   const int ncg = C / 64, m = ncg / (ncg % 4 == 0 ? 4 : (ncg % 2 == 0 ? 2 : 1));

@@ -1273,6 +1273,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }
 
 inline int wgrid(long n) { return (int)min(16384L, (n + 255) / 256); }
+// the transform kernels decompose a 32-bit item index (tile, channel quad)
+inline bool wino_items32(int N, int H, int W, int C) { return (long)N * ((H + 3) / 4) * ((W + 3) / 4) * ((C + 3) / 4) < (1L << 32); }
 
 }  // namespace
 
@@ -1291,6 +1293,7 @@ int dsee_absmax(const float* x, long n, float* amax, hipStream_t st) {
 
 /* amax (optional device scalar, zeroed by the caller): receives max |V| (atomic max: order independent) */
 int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, float* amax, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(x && V && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   wino43_input_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(x, V, N, H, W, C, amax);
   DSEE_LAUNCH_CHECK();
@@ -1301,6 +1304,7 @@ int dsee_wino43_input(const float* x, float* V, int N, int H, int W, int C, floa
  * dsee_pow2_scale(bound * *amax_x) with amax_x >= max |x| (device maximum, 64-line form) and bound >= 100 */
 int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C, const float* amax_x, float bound,
                             hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(x && V2 && amax_x && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 100.f);
   DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 16 == 0);
   if (C % 64 == 0)
@@ -1317,6 +1321,7 @@ int dsee_wino43_input_f16x2(const float* x, void* V2, int N, int H, int W, int C
  * per element, 64-byte rows of 32 channels), scale dsee_pow2_scale(bound * *amax_x).  C % 32 == 0, T % 8 == 0. */
 int dsee_wino43_input_f16p(const float* x, void* V1, int N, int H, int W, int C, const float* amax_x, float bound,
                            hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(x && V1 && amax_x && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && bound >= 100.f);
   DSEE_CHECK_ARG(((long)N * (H / 4) * (W / 4)) % 8 == 0);
   if (C % 64 == 0)
@@ -1331,6 +1336,7 @@ int dsee_wino43_input_f16p(const float* x, void* V1, int N, int H, int W, int C,
 
 /* same transform, output as bf16x3-split rows for dsee_gemm_bf16x3: V3 [C/16][36*T][3][16] bf16 (C % 32 == 0) */
 int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(x && V3 && C % 32 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 8 == 0);
   wino43_input_kernel<OUT_SPLIT><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
       x, reinterpret_cast<float*>(V3), N, H, W, C, nullptr);
@@ -1339,6 +1345,7 @@ int dsee_wino43_input_split(const float* x, void* V3, int N, int H, int W, int C
 }
 
 int dsee_wino43_dout(const float* dy, float* dM, int N, int H, int W, int C, float* amax, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(dy && dM && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   wino43_dout_kernel<OUT_F32><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(dy, dM, N, H, W, C, amax, DoutSums{});
   DSEE_LAUNCH_CHECK();
@@ -1356,6 +1363,7 @@ size_t dsee_wino43_dout_sums_workspace(int C) { return (size_t)DOUT_SUMS_GRID * 
 int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C, float* amax, float* workspace,
                           float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0, float* dnoise1, uint64_t seed1,
                           uint64_t offset1, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(dy && dM && workspace && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(C / 4 <= 256 && 256 % (C / 4) == 0 && (dbias || dnoise0 || dnoise1));
   const int grid = (int)min((long)DOUT_SUMS_GRID, ((long)N * (H / 4) * (W / 4) * (C / 4) + 255) / 256);
@@ -1428,6 +1436,7 @@ extern "C" {
 int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int C, const float* amax_dy, float bound,
                            float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
                            float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   return dout_f16_launch<false>(dy, dM2, N, H, W, C, amax_dy, bound, workspace, dbias, dnoise0, seed0, offset0, dnoise1, seed1,
                                 offset1, st);
 }
@@ -1437,12 +1446,14 @@ int dsee_wino43_dout_f16x2(const float* dy, void* dM2, int N, int H, int W, int 
 int dsee_wino43_dout_f16p(const float* dy, void* dM1, int N, int H, int W, int C, const float* amax_dy, float bound,
                           float* workspace, float* dbias, float* dnoise0, uint64_t seed0, uint64_t offset0,
                           float* dnoise1, uint64_t seed1, uint64_t offset1, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   return dout_f16_launch<true>(dy, dM1, N, H, W, C, amax_dy, bound, workspace, dbias, dnoise0, seed0, offset0, dnoise1, seed1,
                                offset1, st);
 }
 
 /* weight-gradient operands for dsee_gemm_bf16x3_tn: [36][T/16][C][3][16 tiles] bf16 (T % 16 == 0, C % 16 == 0) */
 int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(x && V3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
   wino43_input_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
       x, reinterpret_cast<float*>(V3t), N, H, W, C, nullptr);
@@ -1451,6 +1462,7 @@ int dsee_wino43_input_split_t(const float* x, void* V3t, int N, int H, int W, in
 }
 
 int dsee_wino43_dout_split_t(const float* dy, void* dM3t, int N, int H, int W, int C, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(dy && dM3t && C % 16 == 0 && H % 4 == 0 && W % 4 == 0 && ((long)N * (H / 4) * (W / 4)) % 16 == 0);
   wino43_dout_kernel<OUT_SPLIT_T><<<wgrid((long)N * (H / 4) * (W / 4) * (C / 4)), 256, 0, st>>>(
       dy, reinterpret_cast<float*>(dM3t), N, H, W, C, nullptr, DoutSums{});
@@ -1465,6 +1477,7 @@ int dsee_wino43_output_stats(const float* M, const float* bias, const float* res
                              int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
                              uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
                              uint64_t res_noise_offset, float* stats_part, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(M && y && stats_part && C % 4 == 0 && H % 4 == 0 && W % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
   DSEE_CHECK_ARG(act != DSEE_ACT_MASK);
   DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
@@ -1486,6 +1499,7 @@ int dsee_wino43_output_stats_f16(const void* M16, const float* bias, const float
                                  int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
                                  uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
                                  uint64_t res_noise_offset, const float* mscale, float* stats_part, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(M16 && y && mscale && stats_part && C % 4 == 0 && H % 4 == 0 && W % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
   DSEE_CHECK_ARG(act != DSEE_ACT_MASK);
   DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
@@ -1504,6 +1518,7 @@ int dsee_wino43_output_stats_f16(const void* M16, const float* bias, const float
 /* dx [N][H][W][C] from dV [36][T][C] (see wino43_input_adjoint_kernel); mask [pixels][mask_ld] optional */
 int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
                               const float* dvscale, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(dV && dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(!mask || (mask_ld >= C && mask_ld % 4 == 0));
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
@@ -1516,6 +1531,7 @@ int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, f
 
 /* dsee_wino43_input_adjoint (fp32 dV) that also writes max |dx| (64-line form) */
 int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int W, int C, float* amax_dx, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(dV && dx && amax_dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
   wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, nullptr, 0, dx, N, H, W, C, nullptr, amax_dx);
@@ -1526,6 +1542,7 @@ int dsee_wino43_input_adjoint_amax(const float* dV, float* dx, int N, int H, int
 /* ... and from the scaled-fp16 dV16 of the 16-bit storage mode (*dvscale undoes its power-of-two scale) */
 int dsee_wino43_input_adjoint_amax_f16(const void* dV16, float* dx, int N, int H, int W, int C, const float* dvscale,
                                        float* amax_dx, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(dV16 && dx && dvscale && amax_dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
   const _Float16* dVh = reinterpret_cast<const _Float16*>(dV16);
@@ -1538,6 +1555,7 @@ int dsee_wino43_output(const float* M, const float* bias, const float* residual,
                        int H, int W, int C, int act, float slope, const float* noise_w, uint64_t noise_seed,
                        uint64_t noise_offset, const float* res_noise_w, uint64_t res_noise_seed,
                        uint64_t res_noise_offset, const float* mscale, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(M && y && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(act != DSEE_ACT_MASK || residual);
   DSEE_CHECK_ARG(!residual || (residual_ld >= C && residual_ld % 4 == 0));
@@ -1598,6 +1616,7 @@ int dsee_wino43_weights_batch(const float* w_oihw, float* U, int layers, long w_
 int dsee_wino43_output_modulate(const float* M, const float* bias_packed, const float* x, const float* mean,
                                 const float* invstd, float* out_h, float* out_scale, int N, int H, int W, int C,
                                 int rows, float add_one, float slope, const float* mscale, hipStream_t st) {
+  DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(M && x && mean && invstd && out_h && C % 64 == 0 && rows == 2 * C);  // out_scale may be NULL
   DSEE_CHECK_ARG(H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG((long)N * (H / 4) * (W / 4) * rows * 4 < 0xFFFFFFF0L);   // 32-bit offsets within one transform plane
