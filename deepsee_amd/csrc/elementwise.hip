@@ -431,6 +431,43 @@ __global__ __launch_bounds__(256) void chdot_rng_partial_kernel(const float* __r
   }
 }
 
+// UpNoise backward in ONE pass over dy: dx = sum-pool(dy) (+ max |dx|) and the NoiseInjection weight gradient
+// part[block][c] = sum dy * eps with eps regenerated from the Philox stream the forward drew (the two stand-alone passes, sumpool
+// and chdot_rng_partial, each read the 1.07 GB of dy at 256^2).  256 % (C/4) == 0: a thread keeps its channel quad over the
+// grid-stride loop; per-block rows folded in block order by chdot_finalize_kernel.
+__global__ __launch_bounds__(256) void sumpool_dot_rng_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H,
+                                                              int W, int C, int ups, float* __restrict__ amax,
+                                                              float* __restrict__ part, uint64_t seed, uint64_t offset,
+                                                              const uint64_t* __restrict__ epoch) {
+  if (epoch) offset += *epoch;
+  __shared__ f32x4 red[256];
+  float vmax = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int h0 = H >> ups, w0 = W >> ups, C4 = C / 4, f = 1 << ups;
+  const long total4 = (long)N * h0 * w0 * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const dsee_nhwq p = dsee_split_nhwq((unsigned)i, C4, w0, h0);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < f; ++a)
+      for (int b = 0; b < f; ++b) {
+        const size_t px = ((size_t)p.n * H + p.h * f + a) * W + p.w * f + b;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + px * C + p.q * 4);
+        v += d;
+        acc += d * philox_normal4(seed, offset + (uint64_t)(px * C4 + p.q));
+      }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = v;
+    vmax = fmaxf(vmax, dsee_absmax4(v));
+  }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < C4) {      // threads t, t + C4, ... share the channel quad t
+    f32x4 s = red[threadIdx.x];
+    for (int k = threadIdx.x + C4; k < 256; k += C4) s += red[k];
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + threadIdx.x * 4) = s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -498,6 +535,24 @@ int dsee_sumpool_amax(const float* dy, float* dx, int N, int H, int W, int C, in
   DSEE_CHECK_ARG(dy && dx && amax_dx && C % 4 == 0 && ups >= 1);
   DSEE_CHECK_ARG((long)N * H * W * C / 4 < (1L << 32));      // (32-bit item index: dsee_split_nhwq)
   sumpool_kernel<<<egrid((long)N * (H >> ups) * (W >> ups) * C / 4), 256, 0, st>>>(dy, dx, N, H, W, C, ups, amax_dx);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* UpNoise backward in one pass (normalization.py:289-304 + nn.Upsample, sr.py:57): dx = sum-pool of dy over 2^ups x 2^ups blocks,
+ * *amax_dx = max |dx| (64-line form, optional), dnoise_w[c] = sum dy * eps with eps the Philox stream (seed, offset) of the forward.
+ * workspace: dsee_sumpool_dot_rng_workspace(N, H, W, C, ups) bytes.  256 % (C/4) == 0. */
+size_t dsee_sumpool_dot_rng_workspace(int N, int H, int W, int C, int ups) {
+  return (size_t)egrid((long)N * (H >> ups) * (W >> ups) * C / 4) * C * sizeof(float);
+}
+int dsee_sumpool_dot_rng(const float* dy, float* dx, int N, int H, int W, int C, int ups, float* amax_dx, float* dnoise_w,
+                         float* workspace, uint64_t seed, uint64_t offset, hipStream_t st) {
+  DSEE_CHECK_ARG(dy && dx && dnoise_w && workspace && C % 4 == 0 && ups >= 1 && 256 % (C / 4) == 0);
+  DSEE_CHECK_ARG((long)N * H * W * C / 4 < (1L << 32));      // (32-bit item index: dsee_split_nhwq)
+  const int grid = egrid((long)N * (H >> ups) * (W >> ups) * C / 4);
+  sumpool_dot_rng_kernel<<<grid, 256, 0, st>>>(dy, dx, N, H, W, C, ups, amax_dx, workspace, seed, offset, dsee_rng_epoch());
+  DSEE_LAUNCH_CHECK();
+  chdot_finalize_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, grid, C, dnoise_w);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -1198,6 +1198,15 @@ class UpNoise(torch.autograd.Function):
         dy = dy.contiguous()
         n, h, w, c = dy.shape
         dx = dw = None
+        if (ctx.ups and ctx.philox is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and P().fuse_noise
+                and 256 % (c // 4) == 0):
+            # one pass over dy for both gradients (dsee_sumpool_dot_rng)
+            dx, dw = new(*ctx.xshape), new(c)
+            tag_amax(dx, amax_slot())      # (dx is the output gradient of the previous block's conv_1)
+            ws = scratch(L.lib().dsee_sumpool_dot_rng_workspace(n, h, w, c, ctx.ups), "chdot")
+            L.call("sumpool_dot_rng", dy, dx, n, h, w, c, ctx.ups, dx.dsee_amax, dw, ws, C.c_uint64(ctx.philox.seed),
+                   C.c_uint64(ctx.philox.offset))
+            return dx, dw, None, None, None
         if ctx.needs_input_grad[0]:
             if ctx.ups:
                 dx = new(*ctx.xshape)

@@ -496,6 +496,11 @@ int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* works
                          hipStream_t stream);
 int dsee_sumpool(const float* dy, float* dx, int N, int H, int W, int C, int ups, hipStream_t stream);
 int dsee_sumpool_amax(const float* dy, float* dx, int N, int H, int W, int C, int ups, float* amax_dx, hipStream_t stream);
+/* UpNoise backward in one pass over dy (both stand-alone passes, dsee_sumpool_amax and dsee_channel_dot_rng, read it in full):
+ * dx = sum-pool, *amax_dx = max |dx| (optional), dnoise_w[c] = sum dy * eps(seed, offset).  256 % (C/4) == 0. */
+size_t dsee_sumpool_dot_rng_workspace(int N, int H, int W, int C, int ups);
+int dsee_sumpool_dot_rng(const float* dy, float* dx, int N, int H, int W, int C, int ups, float* amax_dx, float* dnoise_w,
+                         float* workspace, uint64_t seed, uint64_t offset, hipStream_t stream);
 size_t dsee_channel_dot_workspace(long M, int C);
 int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, float* workspace, hipStream_t stream);
 int dsee_act_fwd(const float* x, float* y, long n, int act, float slope, hipStream_t stream);
