@@ -272,8 +272,7 @@ __global__ __launch_bounds__(128) void thin1x1_dgrad_kernel(const float* __restr
     thin1_stage(zs, dz, ldz, mc, np);
     __syncthreads();
     if (!on) continue;
-#pragma unroll 4
-    for (int p = 0; p < np; ++p) {
+    auto pixel = [&](int p, const f32x4& xv) {
       const f32x4* __restrict__ zr = reinterpret_cast<const f32x4*>(zs + p * ldz);     // (uniform address: LDS broadcast)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -284,13 +283,24 @@ __global__ __launch_bounds__(128) void thin1x1_dgrad_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) acc += z[e] * wr[k4 * 4 + e];
       }
       if (act_x) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(act_x + (mc + p) * C + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] *= xv[e] > 0.f ? 1.f : slope;
       }
       vmax = fmaxf(vmax, dsee_absmax4(acc));
       __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(dx + (mc + p) * C + c));
+    };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    for (; p + 4 <= np; p += 4) {        // (the 4 loads of x -- the activation's sign -- are in flight while the FMAs run)
+      f32x4 xv[4] = {z4, z4, z4, z4};
+      if (act_x) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(act_x + (mc + p + j) * C + c));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pixel(p + j, xv[j]);
     }
+    for (; p < np; ++p) pixel(p, act_x ? *reinterpret_cast<const f32x4*>(act_x + (mc + p) * C + c) : z4);
   }
   if (amax) dsee_block_atomic_absmax(amax, vmax);      // (every thread arrives here)
 }

@@ -17,5 +17,8 @@ def timeit(fn, it=20):
     return a.elapsed_time(b) / it
 t = timeit(lambda: L.call("thin1x1_bwd", dz, ldz, w, None, dx, None, C.c_long(m), c, k, None, 0, 0.2, None))
 print("data gradient  : %.3f ms  %.2f TB/s" % (t, x.numel() * 4 / 1e9 / t))
+am = ops.amax_slot()
+t = timeit(lambda: L.call("thin1x1_bwd", dz, ldz, w, x, dx, None, C.c_long(m), c, k, None, 1, 0.2, am))
+print("data gradient + LeakyReLU' + max: %.3f ms  %.2f TB/s" % (t, 2 * x.numel() * 4 / 1e9 / t))
 t = timeit(lambda: L.call("thin1x1_bwd", dz, ldz, None, x, None, dw, C.c_long(m), c, k, ws, 0, 0.2, None))
 print("weight gradient: %.3f ms  %.2f TB/s" % (t, x.numel() * 4 / 1e9 / t))
