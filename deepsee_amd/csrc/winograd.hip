@@ -1517,14 +1517,14 @@ int dsee_wino43_output_stats_f16(const void* M16, const float* bias, const float
 
 /* dx [N][H][W][C] from dV [36][T][C] (see wino43_input_adjoint_kernel); mask [pixels][mask_ld] optional */
 int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
-                              const float* dvscale, hipStream_t st) {
+                              const float* dvscale, float* amax_dx, hipStream_t st) {
   DSEE_CHECK_ARG(wino_items32(N, H, W, C));      // (32-bit item index in the kernels: dsee_common.h)
   DSEE_CHECK_ARG(dV && dx && C % 4 == 0 && H % 4 == 0 && W % 4 == 0);
   DSEE_CHECK_ARG(!mask || (mask_ld >= C && mask_ld % 4 == 0));
   const int grid = wgrid((long)N * (H / 4) * (W / 4) * (C / 4));
   const _Float16* dVh = reinterpret_cast<const _Float16*>(dV);
-  if (dvscale) wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dVh, mask, mask_ld, dx, N, H, W, C, dvscale);
-  else wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, mask, mask_ld, dx, N, H, W, C, nullptr);
+  if (dvscale) wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dVh, mask, mask_ld, dx, N, H, W, C, dvscale, amax_dx);
+  else wino43_input_adjoint_kernel<<<grid, 256, 0, st>>>(dV, mask, mask_ld, dx, N, H, W, C, nullptr, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -688,7 +688,9 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
         tag_amax(dx, amax_slot())
         L.call("wino43_input_adjoint_amax_f16", dv, dx, nb, h, wd, r_s, dvs, dx.dsee_amax)
     else:
-        L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s, dvs)
+        # (masked form: dx is the embedding's gradient, the dout operand of mlp_shared's weight gradient -- its maximum rides along)
+        tag_amax(dx, amax_slot())
+        L.call("wino43_input_adjoint", dv, mask, mask_ld, dx, nb, h, wd, r_s, dvs, dx.dsee_amax)
     return dx
 
 
@@ -1651,6 +1653,7 @@ class SeanNormTable(torch.autograd.Function):
                 tag_amax(out, hm)
                 ctx.xhat_amax = xm
                 ctx.sign_mask = smask
+                ctx.cat_amax = ac        # (max |cat|: the backward's mlp_shared weight gradient takes `cat` as an operand again)
             keep = None
             if P().keep_v and need_scale and nb == n and _wgrad_mode(ld, rows) == 2:
                 if P().presplit_a:
@@ -1778,7 +1781,10 @@ class SeanNormTable(torch.autograd.Function):
                 else:
                     dactv = conv_raw(dgb, _pack_dgrad(w2a, rows, 1), ga, None, cat, L.ACT_MASK, res_ld=ld)
                 gs = L.geom_fwd(n, h, w, ld, NHIDDEN, 3, 1, 1, 0)
-                dw_sh = wgrad_raw(cat, dactv, gs, NHIDDEN, lab.nc, 3, 3, cin_first=NHIDDEN)
+                known = {}          # operand maxima the forward pass / the producer of dactv already wrote
+                if getattr(ctx, "cat_amax", None) is not None:
+                    known[(cat.data_ptr(), cat.numel(), cat._version)] = ctx.cat_amax
+                dw_sh = wgrad_raw(cat, dactv, gs, NHIDDEN, lab.nc, 3, 3, cin_first=NHIDDEN, amax_cache=known)
                 db_sh = channel_dot(dactv, None, NHIDDEN).clone()
             else:
                 dactv = (dactv_fused[0] if fused_d else

@@ -283,7 +283,7 @@ int dsee_wino43_dout_sums(const float* dy, float* dM, int N, int H, int W, int C
  * U^T = dsee_wino43_weights(w, transpose_flip = 2) [36][rows(Cin)][Cout], then dx = sum over tiles of the overlapping
  * 6x6 patches B dV B^T (gather form).  mask != NULL: dx = mask > 0 ? dx : 0 (ReLU backward, like DSEE_ACT_MASK). */
 int dsee_wino43_input_adjoint(const float* dV, const float* mask, int mask_ld, float* dx, int N, int H, int W, int C,
-                              const float* dvscale, hipStream_t stream);
+                              const float* dvscale, float* amax_dx, hipStream_t stream);   /* amax_dx: optional, 64-line form */
 size_t dsee_wino43_wgrad_workspace(long T, int Cin_stored, int Cout_stored);
 int dsee_wino43_wgrad(const float* V, const float* dM, float* workspace, size_t workspace_bytes, float* dw_oihw,
                       long T, int Cin_stored, int Cout_stored, int Cout, int Cin, int split, const float* amax_v,
