@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--arith", choices=["f16x2", "bf16x3", "f32"], default="f16x2",
                     help="how the fp32 Winograd-domain GEMMs run on the matrix cores: two-term fp16 split (default), exact "
                          "3-term bf16 split, or v_mfma_f32")
+    ap.add_argument("--dp-comm", choices=["torch", "capi"], default="torch",
+                    help="--gpus N > 1: the collectives through torch.distributed (RCCL backend) or through dsee_comm_* of the C ABI")
     ap.add_argument("--plan", nargs="*", default=[], metavar="FIELD=VALUE",
                     help="KernelPlan fields of the model (deepsee_amd/plan.py), e.g. --plan fused_norm=False (A/B runs)")
     args = ap.parse_args()
@@ -219,7 +221,7 @@ def main():
     n = args.batch_per_gpu or n_default
     headline = args.config == "independent_8x_256"
     # the kernel-path choices of this run are the MODEL's plan (deepsee_amd/plan.py), not module state
-    opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype, hip_graphs=not args.no_graphs,
+    opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype, hip_graphs=not args.no_graphs, dp_comm=args.dp_comm,
                    kernel_plan=dict(dict(gemm_split=args.arith != "f32", gemm_f16x2=args.arith == "f16x2"),
                                     **{kv.split("=")[0]: eval(kv.split("=", 1)[1]) for kv in args.plan}))
     import warnings
@@ -453,6 +455,8 @@ def main():
     if world > 1:
         dist.barrier()
         tm.release_graphs()          # (the graphs hold captured RCCL operations: gone before their communicator)
+        if getattr(tm, "dp_comm", None) is not None:
+            tm.dp_comm.close()
         dist.destroy_process_group()
 
 
