@@ -181,6 +181,128 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def dp_report(tm, step, fence, world, rank, n, dev, elapsed_local, elapsed, steps):
+    """world > 1: what a reader needs to check an N-rank run without trusting `n_gpus`.  Every rank calls this
+    (collectives inside); returns the `dp` object on every rank.
+      ranks_seen        sum of ones through the SAME communicator the gradients travel on
+      per_rank          every rank's own wall time over the timed region -> img/s min / max
+      allreduce         the two flat gradient buffers (G + E, D) reduced alone with the step's chunking, HIP events on the
+                        stream the collectives run on: ms per step, bytes, bus GB/s = 2 (N-1)/N bytes / t (ring convention)
+      compute_only      the same step with the collectives switched off (every rank steps on its own gradient), all ranks
+                        at once -> `exposed_comm_ms` = step - compute-only step (what the all-reduce costs after overlap)
+      n1_reference      rank 0 stepping ALONE while the other ranks wait: the 1-process number of this job, to be compared with
+                        the N = 1 line of the same box"""
+    import torch.distributed as dist
+    hook = tm.optimizer_G.reduce_hook
+    comm = getattr(hook, "comm", None)
+    backend = dist.get_backend() if dist.is_initialized() else "none"
+
+    def allreduce_(t):
+        if comm is not None:
+            comm.all_reduce_sum_(t)
+        else:
+            dist.all_reduce(t)
+        return t
+
+    ones = allreduce_(torch.ones(1, device=dev))
+    torch.cuda.synchronize()
+    times = torch.zeros(world, dtype=torch.float64, device=dev)
+    times[rank] = elapsed_local
+    dist.all_reduce(times)
+    per_rank = [n * steps / float(t) for t in times.tolist()]
+    # ---- the gradient exchange alone (buffers as the last step left them; sums of sums are harmless here: scratch copies)
+    bufs = [o.grad.clone() for o in (tm.optimizer_G, tm.optimizer_D) if o is not None]
+    nbytes = sum(b.numel() * 4 for b in bufs)
+    reps = 5
+    stream = comm.stream if comm is not None else torch.cuda.current_stream()
+    fence()
+    ar_ms = []
+    for it in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if comm is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+        e0.record(stream)
+        works = []
+        for o, b in zip((tm.optimizer_G, tm.optimizer_D), bufs):
+            works += hook.start(b, [(lo, hi) for _, _, lo, hi in o.chunk_ranges(hook.chunk_elems)])
+        for w in works:
+            if w is not None:
+                w.wait()
+        e1.record(stream if comm is not None else torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        if it:
+            ar_ms.append(e0.elapsed_time(e1))
+    ar = sorted(ar_ms)[len(ar_ms) // 2]
+    t = torch.tensor([ar], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ar = float(t)
+
+    def timed_steps(k=3):
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / k
+
+    # ---- compute only: no collectives, all ranks concurrently (the parameters of the ranks drift apart from here on: this
+    #      runs AFTER everything that is reported as the job's throughput)
+    fence()
+    hook.active = False
+    try:
+        dt = timed_steps()
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        compute_only = float(t)
+        fence()
+        alone = timed_steps() if rank == 0 else 0.0
+        fence()
+        t = torch.tensor([alone], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        alone = float(t)
+    finally:
+        hook.active = True
+    step_s = elapsed / steps
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl = "unknown"
+    return {
+        "ranks_seen": int(round(float(ones))), "world": world, "backend": backend,
+        "communicator": "dsee_comm_* (C ABI, RCCL via dlopen)" if comm is not None else "torch.distributed (%s)" % backend,
+        "rccl_version": rccl,
+        "per_rank_img_s": {"min": min(per_rank), "max": max(per_rank), "all": [round(v, 3) for v in per_rank]},
+        "allreduce": {"bytes_per_step": nbytes, "chunk_mb": hook.chunk_elems * 4 / 2 ** 20, "ms_per_step_alone": ar,
+                      "bus_gbps": 2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9 if ar > 0 else None,
+                      "note": "G+E and D flat gradient buffers reduced alone with the step's chunking (median of %d), HIP events "
+                              "on the collective stream, max over ranks; bus GB/s in the ring convention 2 (N-1)/N bytes / t" % reps},
+        "compute_only": {"ms_per_step": compute_only * 1e3, "img_s": n * world / compute_only,
+                         "note": "same step, collectives off, all ranks at once (3 steps, max over ranks)"},
+        "exposed_comm_ms_per_step": (step_s - compute_only) * 1e3,
+        "n1_reference": {"ms_per_step": alone * 1e3, "img_s": n / alone if alone > 0 else None,
+                         "note": "rank 0 stepping alone, collectives off, the other ranks idle (3 steps): the 1-process rate "
+                                 "inside this job"},
+        "scaling_vs_n1_reference": (n * world / step_s) / (n / alone) if alone > 0 else None,
+    }
+
+
+def plan_overrides(pairs):
+    """--plan FIELD=VALUE ...: values are Python literals, fields those of deepsee_amd.plan.KernelPlan."""
+    import ast
+    from deepsee_amd.plan import KernelPlan
+    out = {}
+    for kv in pairs:
+        key, sep, val = kv.partition("=")
+        if not sep or key not in KernelPlan.fields():
+            raise SystemExit("bench.py --plan: %r is not FIELD=VALUE with FIELD one of %s" % (kv, ", ".join(KernelPlan.fields())))
+        try:
+            out[key] = ast.literal_eval(val)
+        except (ValueError, SyntaxError):
+            raise SystemExit("bench.py --plan %s: %r is not a Python literal" % (key, val))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +345,7 @@ def main():
     # the kernel-path choices of this run are the MODEL's plan (deepsee_amd/plan.py), not module state
     opt = make_opt(preset, batchSize=n, seed=0, precision=args.dtype, hip_graphs=not args.no_graphs, dp_comm=args.dp_comm,
                    kernel_plan=dict(dict(gemm_split=args.arith != "f32", gemm_f16x2=args.arith == "f16x2"),
-                                    **{kv.split("=")[0]: eval(kv.split("=", 1)[1]) for kv in args.plan}))
+                                    **plan_overrides(args.plan)))
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)   # (the no-pretrained-VGG notice: synthetic benchmark)
@@ -264,7 +386,7 @@ def main():
     # launches ahead of the GPU, hipGraphLaunch blocks until the device catches up and the time measured is the GPU's, not
     # the host's -- the median of the first four timed steps (queues empty after the fence) is the enqueue cost itself
     host = sorted(host_steps[:4])[len(host_steps[:4]) // 2] * args.steps
-    elapsed = time.perf_counter() - t0
+    elapsed = elapsed_local = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -318,6 +440,8 @@ def main():
                                gemm_f16x2=False)
         tm.sr_model.plan = base_plan
         tm.use_graphs = not args.no_graphs
+
+    dp = dp_report(tm, step, fence, world, rank, n, dev, elapsed_local, elapsed, args.steps) if world > 1 else None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -445,6 +569,8 @@ def main():
                 "mfma_peak": pk, "mfma_frac": tfl / pk,
                 "bytes_note": "algorithmic bytes = x read + y written (4 N R^2 (Cin + Cout)); the Winograd formulation "
                               "additionally writes and re-reads V and M (DESIGN 3)"}
+        if dp:
+            out["dp"] = dp
         if f32_only:
             out["f32_mfma_only"] = f32_only
         if bf16x3:
@@ -454,9 +580,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
-        tm.release_graphs()          # (the graphs hold captured RCCL operations: gone before their communicator)
-        if getattr(tm, "dp_comm", None) is not None:
-            tm.dp_comm.close()
+        tm.close()                   # (graphs may hold captured RCCL operations: gone before their communicator)
         dist.destroy_process_group()
 
 

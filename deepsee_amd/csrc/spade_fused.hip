@@ -582,14 +582,14 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 
 static float* g_fused_stamps = nullptr;
 
-extern "C" {
-
-/* measurement hook (not in the header): device buffer for the cycle stamps of DSEE_FUSED_ABL & 32 builds */
-void dsee_fused_set_stamps(float* p) { g_fused_stamps = p; }
+#if DSEE_FUSED_ABL
+/* measurement builds only (tools/exp/build_fused_abl.sh; the shipped library does not export it): device buffer for the cycle
+ * stamps of DSEE_FUSED_ABL & 32 */
+extern "C" void dsee_fused_set_stamps(float* p) { g_fused_stamps = p; }
+#endif
 
 /* The fused SPADE / SEAN normalisation forward (see the head of this file).  V2 = dsee_wino43_input_f16x2(cat, amax_cat,
  * v_bound), U2 = dsee_wino43_weights[_table](..., split = 2, amax_u); groups = images with per-image tables, else 1. */
-}  // extern "C"
 
 static int spade_fused_launch(bool packed, const void* V2, const void* U2, const float* amax_cat, float v_bound,
                               const float* amax_u, const float* bias_packed, const float* x, const float* mean,

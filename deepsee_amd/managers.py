@@ -52,7 +52,8 @@ class BaseManager:
 class TrainerManager(BaseManager):
     """trainer_manager.py:6-96.
 
-    opt.hip_graphs (default off): a G step and a D step are each captured ONCE per encoder-branch variant as a hipGraph
+    opt.hip_graphs (default ON for a training manager; bench.py --no-graphs / opt.hip_graphs = False enqueue every kernel from
+    Python): a G step and a D step are each captured ONCE per encoder-branch variant as a hipGraph
     (zero_grad, preprocessing, forward, backward, clipping, fused Adam: ~1 500 kernel launches each) and replayed
     afterwards -- one host call instead of ~50 ms of Python launch enqueue per step.  What makes that legal: every
     shape is static; inputs are copied into static buffers; kernel arguments that change per step do not exist (the
@@ -74,10 +75,19 @@ class TrainerManager(BaseManager):
         self.generated = None
         self.logs = {}
         self.g_losses, self.d_losses = {}, {}
-        self.use_graphs = bool(getattr(opt, "hip_graphs", False))
+        self.use_graphs = bool(getattr(opt, "hip_graphs", True))
         self.dp_in_graph = bool(getattr(opt, "dp_graph_collectives", False))
         self._graphs, self._seen, self._static, self._pool = {}, {}, {}, None
-        self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0}
+        # batch-shape signatures that own graphs / static buffers, least recently used first; at most `max_graph_shapes` are
+        # kept (a loader with many distinct shapes would otherwise grow device memory without bound)
+        self._sig_lru = []
+        self.max_graph_shapes = int(getattr(opt, "max_graph_shapes", 4))
+        self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0, "evicted_shapes": 0}
+        self.dp_comm = None
+        import atexit
+        import weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
 
     def get_logs(self):
         return {**self.logs, **self.sr_model_on_one_gpu.get_logs()}
@@ -168,6 +178,7 @@ class TrainerManager(BaseManager):
         if not hasattr(noise, "step"):            # (a replayed oracle tape: no graphs)
             return step_fn(data)
         sig = self._shape_signature(data)
+        self._touch_signature(sig)
         # (the plan is part of the key: a graph replays the kernels chosen under the plan it was captured with)
         key = (which,) + tuple(model.encoder_branch(False, step=noise.step + 1)) + (sig, model.plan)
         seen = self._seen.get(key, 0)
@@ -224,6 +235,37 @@ class TrainerManager(BaseManager):
             model.logs[k] = rec["out_logs"][k]
         return rec["out_losses"], rec["out_generated"]
 
+    def _touch_signature(self, sig):
+        """LRU bookkeeping of the batch shapes that own graphs: a shape beyond `max_graph_shapes` evicts the least recently
+        used one with everything keyed by it (graphs, static input buffers, eager-first counters)."""
+        if self._sig_lru and self._sig_lru[-1] == sig:
+            return
+        if sig in self._sig_lru:
+            self._sig_lru.remove(sig)
+        self._sig_lru.append(sig)
+        while len(self._sig_lru) > max(1, self.max_graph_shapes):
+            old = self._sig_lru.pop(0)
+            dead = [k for k in self._graphs if old in k]
+            if dead:
+                torch.cuda.synchronize()       # (a replay of one of them may still be running)
+            for k in dead:
+                del self._graphs[k]
+            for k in [k for k in self._seen if old in k]:
+                del self._seen[k]
+            for k in [k for k in self._static if old in k]:
+                del self._static[k]
+            self.graph_stats["evicted_shapes"] += 1
+
+    def close(self):
+        """Drop the captured graphs, then the data-parallel communicator of opt.dp_comm = "capi" (parallel.attach) -- in that
+        order, and before the HIP runtime goes away at interpreter exit (registered with atexit; idempotent)."""
+        try:
+            self.release_graphs()
+        finally:
+            comm, self.dp_comm = getattr(self, "dp_comm", None), None
+            if comm is not None:
+                comm.close()
+
     def release_graphs(self):
         """Drop every captured graph (and its static buffers).  Call it BEFORE torch.distributed.destroy_process_group() in a
         data-parallel run: with opt.dp_graph_collectives the graphs hold captured RCCL operations, and destroying them after
@@ -233,6 +275,7 @@ class TrainerManager(BaseManager):
         self._graphs.clear()
         self._seen.clear()
         self._static.clear()
+        del self._sig_lru[:]
         import gc
         gc.collect()
         if torch.cuda.is_available():

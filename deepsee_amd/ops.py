@@ -1645,8 +1645,10 @@ class SeanNormTable(torch.autograd.Function):
                 hm = amax_slot()     # max |h|: the convolution that consumes h writes its V pre-split with this bound
                 xm = amax_slot() if need_scale else None     # max |xhat|: bounds the backward pass's gamma/beta gradient
                 # the LeakyReLU branch of h as bits: all the backward pass needs of h (1/32 of its bytes, read twice)
+                # (the kernel forms the mask index with a shift: a channel count that is not a power of two -- ngf = 24, 48 --
+                # keeps the backward pass on `out`)
                 smask = (torch.empty(n * h * w * (c // 32), dtype=torch.int32, device=x.device)
-                         if (need_scale and P().sign_mask) else None)
+                         if (need_scale and P().sign_mask and (c & (c - 1)) == 0) else None)
                 L.call("spade_fused_fwd_f16p" if pk else "spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
                        scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE,
                        hm, xm, smask)

@@ -138,8 +138,10 @@ class CapiComm:
         from . import lib as L
         if self.handle is not None:
             torch.cuda.synchronize()
-            L.lib().dsee_comm_destroy(self.handle)
-            self.handle = None
+            handle, self.handle = self.handle, None
+            rc = L.lib().dsee_comm_destroy(handle)
+            if rc != 0:
+                raise L.DseeError("dsee_comm_destroy failed (%d): %s" % (rc, L.lib().dsee_last_error().decode()))
 
 
 class _StreamWork:

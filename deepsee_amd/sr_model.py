@@ -70,6 +70,8 @@ def init_weights(net, init_type, gain, gen):
 
 def _sum_terms(terms):
     """Sum of the [1]-shaped loss terms in two launches (cat + reduce) instead of one ATen add per term."""
+    if not terms:        # a discriminator without intermediate features (the reference starts its sums from 0, sr_model.py:535)
+        return torch.zeros(1, device="cuda")
     return terms[0] if len(terms) == 1 else torch.cat(terms).sum(0, keepdim=True)
 
 

@@ -28,9 +28,10 @@ CASES = {
                                  max_fm_size=64),
     "clip_nottur_4to32": dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8, add_noise=False,
                               no_TTUR=True, gradient_clip=0.01),
-    # the benchmark's geometry (32 -> 256, 5 resolutions) AND its batch size 8 -- BatchNorm over 8 images, per-image
-    # style-table groups x 8, the Winograd chunking of 8-image batches -- at 128 channels so the CPU oracle stays cheap
-    "indep_32to256_bs8_ngf8": dict(batchSize=8, ngf=8),
+    # the benchmark's geometry (32 -> 256, 5 resolutions) with a batch > 1 on the EAGER path -- BatchNorm over several images,
+    # per-image style-table groups, the Winograd chunking of a batch -- at 128 channels so the CPU oracle stays cheap (the
+    # benchmark's own bs = 8 x 512 channels: test_benchmark_path_matches_oracle)
+    "indep_32to256_bs4_ngf8": dict(batchSize=4, ngf=8),
 }
 
 
@@ -102,6 +103,8 @@ def run_case(over, seed, iters=1, sync_before_d=True):
 # kink-flip floor described in DESIGN 4, tight enough to catch a 3x regression.  The kink-free 1e-3 claim is carried by
 # test_full_size_smooth_loss_backward and the benchmark-shape layer tests.
 GRAD_MEDIAN_BOUND, GRAD_MAX_BOUND = 6e-3, 2.5e-2
+# 16-bit storage mode (one-term fp16 operands), model-level gradients against the fp32 oracle
+HALF_GRAD_MEDIAN_BOUND, HALF_GRAD_MAX_BOUND = 5e-2, 5e-1
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -180,34 +183,189 @@ def test_full_size_step_matches_oracle():
           % (dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
 
 
-def test_benchmark_config_step_matches_oracle():
-    """BASELINE.json configs[1] EXACTLY as bench.py runs it -- independent 8x 32 -> 256, 512 channels, bs = 8 (the per-image
-    style-table group counts, Winograd chunking and the fused SPADE kernel's tile lists at N = 8) -- one G step + one D
-    step against the CPU oracle on identical weights, inputs, noise and branch decisions: losses <= 1e-4, generated image
-    <= 1e-4 (north_star asks 1e-3).  The oracle needs ~60 GB of host memory for the batch of 8; on a smaller host the
-    test drops to bs = 4 and says so."""
+class _TapedNoise:
+    """Mixin over networks.DeviceNoise: logs every draw request of a forward -- (kind, tag, shape, Philox seed, stream offset)
+    -- so that the numbers a captured / replayed step drew in registers can be regenerated afterwards with dsee_rng_fill at the
+    same (seed, offset, device epoch) and handed to the oracle as its noise tape (normalization.py:299-304 takes `noise=`)."""
+
+    def begin_step(self):
+        super().begin_step()
+        self.log = []
+
+    def coin(self, tag, step=None):
+        v = super().coin(tag, step)
+        if step is None:
+            self.log.append(("coin", tag, v))
+        return v
+
+    def normal_nhwc(self, shape, tag):
+        self.log.append(("normal_nhwc", tag, tuple(shape), self.seed, self.offset))
+        return super().normal_nhwc(shape, tag)
+
+    def uniform(self, shape, tag):
+        self.log.append(("uniform", tag, tuple(shape), self.seed, self.offset))
+        return super().uniform(shape, tag)
+
+    def normal(self, shape, tag):
+        self.log.append(("normal", tag, tuple(shape), self.seed, self.offset))
+        return super().normal(shape, tag)
+
+    def dump(self, log):
+        """The oracle tape of one forward: every logged stream position regenerated under the CURRENT device epoch (call it
+        right after the step that drew them: the next training forward advances the epoch)."""
+        from deepsee_amd import ops
+        self.ensure_registered()
+        tape = []
+        for e in log:
+            if e[0] == "coin":
+                tape.append(e)
+            elif e[0] == "normal_nhwc":
+                t = ops.rng_fill(e[2], e[3], e[4], True)
+                tape.append(("normal", e[1], ops.to_nchw(t, e[2][3]).cpu()))
+            else:
+                tape.append((e[0], e[1], ops.rng_fill(e[2], e[3], e[4], e[0] == "normal").cpu()))
+        return tape
+
+
+@pytest.mark.parametrize("preset", ["independent_8x_256", "guided_8x_256"])
+def test_benchmark_path_matches_oracle(preset):
+    """The path bench.py TIMES, under the oracle: BASELINE configs[1] (and configs[3]'s per-rank workload,
+    guided, bs = 8) with the manager's defaults -- hipGraph replay, DeviceNoise (Philox regenerated in registers by the fused
+    noise / shortcut kernels), bs = 8 x 512 channels.  The model is stepped until the next G and D half steps are REPLAYS of
+    captured graphs; its state is snapshotted; the replayed G step runs; every Philox draw of that step is regenerated with
+    dsee_rng_fill at the same (seed, offset, epoch) into a tape; the oracle runs the same step from the snapshot on that tape.
+    Losses <= 1e-4, generated image <= 1e-4, G gradients (the flat buffer the in-graph Adam consumed) within the model-level
+    bounds; then the D replay from the oracle's post-G state: losses <= 2e-3, D gradients <= 5e-3.  The oracle needs ~60 GB of
+    host memory at bs = 8; on a smaller host the test drops to bs = 4 and says so."""
     import os
+    import warnings
+    from deepsee_amd import networks as N
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt, PRESETS
     try:
         ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9
     except (ValueError, OSError):
         ram_gb = 0.0
     bs = 8 if ram_gb >= 90 else 4
-    over = dict(batchSize=bs)
-    orc, tm, out = run_case(over, seed=2468)
-    r = out[0]
-    for k, v in r["gl"].items():
-        assert abs(r["hgl"][k] - v) <= 1e-4 * abs(v), (k, r["hgl"][k], v)
-    dev = rel(r["hfake"], r["fake"])
+    over = dict(PRESETS[preset], batchSize=bs)
+    oopt = O.make_opt(**over)
+    states = O.recipe_state(oopt, gain=1.0)
+    batch = O.synthetic_batch(oopt, bs, seed=2468)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        tm = TrainerManager(make_opt(preset, batchSize=bs, seed=0))
+    assert tm.use_graphs                                   # the default
+    m = tm.sr_model
+    m.load_states(states)
+
+    class Taped(_TapedNoise, N.DeviceNoise):
+        pass
+    m.noise = Taped(0)
+    feed = lambda: {k: v.clone() for k, v in batch.items()}
+    sig = tm._shape_signature(batch)
+
+    def key(which):
+        return (which,) + tuple(m.encoder_branch(False, step=m.noise.step + 1)) + (sig, m.plan)
+
+    logs = {}
+
+    def half(which):
+        k, before = key(which), tm.graph_stats["replayed"]
+        (tm.run_generator_one_step if which == "G" else tm.run_discriminator_one_step)(feed())
+        replayed = tm.graph_stats["replayed"] > before
+        if not replayed:
+            logs[k] = list(m.noise.log)     # (eager or capture pass: the Python side ran; a replay draws at the same positions)
+        return k, replayed
+
+    # ---- until the NEXT G and the D behind it are both replays
+    for it in range(48):
+        kg = key("G")
+        m.noise.step += 1
+        kd = key("D")
+        m.noise.step -= 1
+        if kg in tm._graphs and kd in tm._graphs:
+            break
+        half("G")
+        half("D")
+    else:
+        pytest.fail("no replayable G + D pair after 48 iterations: %r" % (tm.graph_stats,))
+    torch.cuda.synchronize()
+    snap = {net: {k: v.detach().cpu().clone() for k, v in getattr(m, "net" + net).state_dict().items()} for net in ("SR", "D", "E")}
+    snap["VGG"] = states["VGG"]
+    # ---- the replayed G step and its tape
+    kg2, replayed = half("G")
+    assert replayed and kg2 == kg
+    torch.cuda.synchronize()
+    tape = m.noise.dump(logs[kg])
+    hgl = {k: float(v) for k, v in tm.g_losses.items()}
+    hfake = tm.get_latest_generated().detach().cpu()
+    hg = {nm: tm.optimizer_G.grad_view(nm).detach().cpu().clone() for nm in tm.optimizer_G.names}
+    active = tm.optimizer_G._active_dev.cpu().tolist()
+    touched = {nm for nm, a in zip(tm.optimizer_G.names, active) if a}
+    # ---- the oracle on the same state and tape
+    ctl = O.ReplayCtl(tape)
+    orc = O.Oracle(oopt, snap, ctl)
+    orc.create_optimizers()
+    gl, fake = orc.run_generator_one_step(feed())
+    assert ctl.pos == len(ctl.tape)
+    ggrads = {"%s.%s" % (net, k): p.grad.clone() for net in ("SR", "E") for k, p in orc.params(net) if p.grad is not None}
+    for k, v in gl.items():
+        assert abs(hgl[k] - float(v.detach())) <= 1e-4 * abs(float(v.detach())), (k, hgl[k], float(v.detach()))
+    dev = rel(hfake, fake.detach())
     assert dev < 1e-4, dev
-    assert r["touched_g"] == set(r["ggrads"])
-    for k, v in r["dl"].items():
-        assert abs(r["hdl"][k] - v) <= 2e-3 * abs(v), (k, r["hdl"][k], v)
-    gmax = max(float(v.norm()) for v in r["ggrads"].values())
-    errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
-                  for k, v in r["ggrads"].items())
+    assert touched == set(ggrads), touched ^ set(ggrads)
+    gmax = max(float(v.norm()) for v in ggrads.values())
+    errs = sorted(float((hg[k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax) for k, v in ggrads.items())
     assert errs[len(errs) // 2] < GRAD_MEDIAN_BOUND and errs[-1] < GRAD_MAX_BOUND, (errs[len(errs) // 2], errs[-1])
-    print("configs[1] at bs = %d (host RAM %.0f GB): |fake - oracle| / |oracle| = %.2e, G-grad rel err median %.2e max %.2e, "
-          "losses %s" % (bs, ram_gb, dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
+    report = ("%s at bs = %d, REPLAYED graphs + Philox tape (%d draws, host RAM %.0f GB): |fake - oracle| / |oracle| = %.2e, "
+              "G-grad rel err median %.2e max %.2e, losses %s" % (preset, bs, len(tape), ram_gb, dev, errs[len(errs) // 2],
+                                                                  errs[-1], {k: round(v, 5) for k, v in hgl.items()}))
+    if preset != "independent_8x_256":
+        # (configs[3]: the G half only -- the oracle's D step at bs = 8 is another ~30 s of CPU time that the independent case
+        # already spends on the same discriminator kernels)
+        print(report)
+        tm.close()
+        return
+    # ---- BASELINE configs[2]'s per-rank workload on the SAME oracle pass: the 16-bit storage mode (eager, the tape replayed)
+    # from the same snapshot -- generated image within SURVEY 8(d)'s 3e-2, losses within 5 %, gradients within HALF_GRAD_*
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        th = TrainerManager(make_opt(preset, batchSize=bs, seed=0, precision="fp16", hip_graphs=False))
+    assert th.sr_model.plan.half and th.sr_model.plan.half_norms
+    th.sr_model.load_states(snap)
+    th.sr_model.noise = N.ReplayNoise(tape)
+    th.run_generator_one_step(feed())
+    torch.cuda.synchronize()
+    hdev = rel(th.get_latest_generated().detach().cpu(), fake.detach())
+    assert hdev < 3e-2, hdev
+    for k, v in gl.items():
+        w = float(th.g_losses[k])
+        assert abs(w - float(v.detach())) <= 0.05 * abs(float(v.detach())) + 1e-3, (k, w, float(v.detach()))
+    hh = {nm: _grad_or_zero(p) for nm, p in zip(th.optimizer_G.names, th.optimizer_G.params)}
+    herrs = sorted(float((hh[k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax) for k, v in ggrads.items())
+    report += (" | 16-bit mode from the same state: fake %.2e, G-grad rel err median %.2e, 90 %% %.2e, max %.2e"
+               % (hdev, herrs[len(herrs) // 2], herrs[int(0.9 * (len(herrs) - 1))], herrs[-1]))
+    assert herrs[len(herrs) // 2] < HALF_GRAD_MEDIAN_BOUND and herrs[-1] < HALF_GRAD_MAX_BOUND, (herrs[len(herrs) // 2], herrs[-1])
+    del th
+    # ---- the replayed D step from the oracle's post-G state (both sides identical weights / buffers again)
+    load_oracle_state(tm, orc)
+    kd2, replayed = half("D")
+    assert replayed and kd2 == kd
+    torch.cuda.synchronize()
+    ctl.tape += m.noise.dump(logs[kd])
+    hdl = {k: float(v) for k, v in tm.d_losses.items()}
+    hd = {nm: tm.optimizer_D.grad_view(nm).detach().cpu().clone() for nm in tm.optimizer_D.names}
+    dl = orc.run_discriminator_one_step(feed())
+    assert ctl.pos == len(ctl.tape)
+    dgrads = {"D." + k: p.grad.clone() for k, p in orc.params("D") if p.grad is not None}
+    for k, v in dl.items():
+        assert abs(hdl[k] - float(v.detach())) <= 2e-3 * abs(float(v.detach())), (k, hdl[k], float(v.detach()))
+    dmax = max(float(v.norm()) for v in dgrads.values())
+    derrs = sorted(float((hd[k].double() - v.double()).norm()) / max(float(v.norm()), 1e-2 * dmax) for k, v in dgrads.items())
+    assert derrs[-1] < 5e-3, derrs[-1]
+    print(report + " | D step replayed from the oracle's post-G state: D-grad max %.2e, losses %s"
+          % (derrs[-1], {k: round(v, 5) for k, v in hdl.items()}))
+    tm.close()
 
 
 def smooth_loss_errors(over, seed=555, plain_f32=True):
@@ -331,11 +489,17 @@ def test_smooth_loss_backward(name):
 
 @pytest.mark.parametrize("name,over", [
     ("config1_32to256_bs1", dict(batchSize=1)),                       # BASELINE configs[1] geometry, 512 channels
-    ("indep_32to256_bs8_ngf8", dict(batchSize=8, ngf=8)),             # the benchmark's batch size (128 channels)
-    # BASELINE configs[3]: guided 8x 32 -> 256 -- the full style encoder's backward on a 256^2 guiding image
-    ("guided_32to256_bs1", dict(batchSize=1, netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True)),
+    # a batch > 1 at 128 channels (round 5: bs = 4 instead of 8 -- the benchmark's own bs = 8 x 512 channels is now held against
+    # the oracle on the replayed graphs, test_benchmark_path_matches_oracle, and the float64 CPU passes here are what the
+    # suite's wall time is made of)
+    ("indep_32to256_bs4_ngf8", dict(batchSize=4, ngf=8)),
+    # BASELINE configs[3]: guided 8x 32 -> 256 -- the full style encoder's backward on a 256^2 guiding image (nef = 32 as
+    # shipped; the generator at 256 channels: its 512-channel kernels are the first case's, and configs[3] at bs = 8 x 512
+    # channels runs under test_benchmark_path_matches_oracle[guided_8x_256])
+    ("guided_32to256_bs1_ngf16", dict(batchSize=1, ngf=16, netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True)),
     # BASELINE configs[4]: independent 32x 16 -> 512 -- PureSEAN tail, the capped path's 2x2 block-sum gradient at 512^2
-    ("indep_16to512_bs1", dict(batchSize=1, start_size=16, crop_size=512, load_size=512, add_noise=False)),
+    # (256 channels: what is specific to configs[4] is its resolution; forward + losses at 512 channels: test_full_size_forward_and_losses)
+    ("indep_16to512_bs1_ngf16", dict(batchSize=1, ngf=16, start_size=16, crop_size=512, load_size=512, add_noise=False)),
 ])
 def test_full_size_smooth_loss_backward(name, over):
     """Gradients of the whole path at the BENCHMARK shapes (512 channels, 32 -> 256: the 256x256 / 256x160 bf16x3 GEMM
@@ -366,8 +530,7 @@ def test_full_size_smooth_loss_backward(name, over):
 
 
 @pytest.mark.parametrize("name,over", [
-    # BASELINE configs[3]: guided 8x 32 -> 256 (full style encoder on a 256^2 guiding image: feature map [N,128,128,128])
-    ("guided_32to256", dict(batchSize=1, netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True)),
+    # (BASELINE configs[3], guided 8x 32 -> 256, at full size: test_benchmark_path_matches_oracle[guided_8x_256], bs = 8)
     # BASELINE configs[4]: independent 32x 16 -> 512 (PureSEAN tail, max_fm_size 256 < 512: the capped path at 512^2)
     ("indep_16to512", dict(batchSize=1, start_size=16, crop_size=512, load_size=512, add_noise=False)),
 ])
@@ -469,13 +632,14 @@ def test_data_parallel_path_on_one_gpu_nccl_world1():
 
     # (SyncBN computes its statistics in a pass of its own; the plain run does the same here so that the two runs differ
     # by the collectives only -- beta1 = 0 Adam turns any rounding difference of step 1 into +-lr differences at step 2)
-    plain = steps(TrainerManager(make_opt(seed=3, kernel_plan=dict(producer_stats=False), **over)))
+    plain = steps(TrainerManager(make_opt(seed=3, hip_graphs=False, kernel_plan=dict(producer_stats=False), **over)))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
-        tm = TrainerManager(make_opt(seed=3, sync_bn=True, sync_bn_clamp=False, kernel_plan=dict(producer_stats=False), **over))
+        tm = TrainerManager(make_opt(seed=3, hip_graphs=False, sync_bn=True, sync_bn_clamp=False,
+                                     kernel_plan=dict(producer_stats=False), **over))
         parallel.attach(tm, 1, chunk_mb=0.25, force=True)
         assert tm.optimizer_G.reduce_hook.active and tm.sr_model.plan.sync_bn is not None
         assert len(tm.optimizer_G.chunk_ranges(tm.optimizer_G.reduce_hook.chunk_elems)) > 4
@@ -550,7 +714,7 @@ def test_hip_graphs_with_rccl_group_world1():
     from deepsee_amd.options import make_opt
     over = dict(start_size=8, crop_size=64, load_size=64, batchSize=2, ngf=8)
     batch = O.synthetic_batch(O.make_opt(**over), 2, seed=17)
-    tm = TrainerManager(make_opt(seed=5, **over))
+    tm = TrainerManager(make_opt(seed=5, hip_graphs=False, **over))
     plain = []
     for _ in range(8):
         tm.run_generator_one_step({k: v.clone() for k, v in batch.items()})
@@ -567,6 +731,49 @@ def test_hip_graphs_with_rccl_group_world1():
     for x, y in ((pg, dp[1]), (pd, dp[2])):
         assert float((x - y).abs().max()) <= 2.5 * 8 * 4e-4           # beta1 = 0 Adam: <= lr per step and element
         assert float((x - y).abs().mean()) <= 5e-5
+
+
+def test_hip_graphs_default_on_partial_batches_and_shape_eviction():
+    """opt.hip_graphs is ON by default for a training manager (a maintainer following INTEGRATION 1 gets the replayed path, not
+    60 ms of Python enqueue per step).  A loader without drop_last hands over a partial last batch: graphs, static input buffers
+    and the eager-first counters are keyed by the batch shape, so the sequence full, full, full, partial, full, partial, partial,
+    full ... must equal the same sequence stepped eagerly (hip_graphs = False) -- with room for both shapes
+    (max_graph_shapes = 4) and with room for ONE (every shape change evicts the other shape's graphs and buffers and
+    re-captures)."""
+    from deepsee_amd.managers import TrainerManager
+    from deepsee_amd.options import make_opt
+    over = dict(start_size=4, crop_size=32, load_size=32, batchSize=4, ngf=8, seed=21)
+    assert make_opt().hip_graphs is True
+    full = O.synthetic_batch(O.make_opt(**over), 4, seed=8)
+    part = {k: v[:2].clone() for k, v in full.items()}
+    seq = [full, full, full, part, full, part, part, full, full, part, part, part, full, full]
+
+    def run(**kw):
+        tm = TrainerManager(make_opt(**over, **kw))
+        out = []
+        for b in seq:
+            tm.run_generator_one_step({k: v.clone() for k, v in b.items()})
+            tm.run_discriminator_one_step({k: v.clone() for k, v in b.items()})
+            out.append({k: float(v) for k, v in tm.get_latest_losses().items()})
+            assert tuple(tm.get_latest_generated().shape)[0] == b["image"].shape[0]
+        torch.cuda.synchronize()
+        flat = (tm.optimizer_G.flat.detach().cpu().clone(), tm.optimizer_D.flat.detach().cpu().clone())
+        stats = dict(tm.graph_stats)
+        tm.close()
+        return out, flat, stats
+
+    eager = run(hip_graphs=False)
+    assert eager[2]["captured"] == 0 and eager[2]["replayed"] == 0
+    both = run()
+    assert both[2]["captured"] >= 2 and both[2]["replayed"] >= 2 and both[2]["evicted_shapes"] == 0, both[2]
+    one = run(max_graph_shapes=1)
+    assert one[2]["evicted_shapes"] >= 5, one[2]
+    for got in (both, one):
+        for it, (a, b) in enumerate(zip(eager[0], got[0])):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 1e-5 * abs(a[k]) + 1e-7, (it, k, a[k], b[k])
+        for x, y in zip(eager[1], got[1]):
+            assert float((x - y).abs().max()) <= 1e-6, float((x - y).abs().max())
 
 
 def test_dp_collectives_captured_inside_the_graph_world1():
@@ -650,8 +857,7 @@ def _two_gpu_worker(rank, world, port, sync_bn, q, dp_comm="torch"):
            {k: float(v) for k, v in tm.get_latest_losses().items()}))
     import torch.distributed as dist
     dist.barrier()
-    if tm.dp_comm is not None:
-        tm.dp_comm.close()
+    tm.close()
     dist.destroy_process_group()
 
 
@@ -762,12 +968,12 @@ def test_half_mode_tracks_fp32():
         assert abs(ma - mb) <= tol, (lo, hi, k, ma, mb, my)
 
 
-@pytest.mark.parametrize("bs", [1, 8])
+@pytest.mark.parametrize("bs", [1])
 def test_half_mode_vs_oracle(bs):
     """The 16-bit mode against the CPU ORACLE (not only against the fp32 HIP path): one G step of BASELINE configs[1]'s
-    geometry on identical weights, inputs, noise and branch decisions -- at bs = 1 and at the benchmark's bs = 8 (the oracle
-    needs ~60 GB of host memory there; skipped below 90 GB): generated image within SURVEY 8(d)'s 3e-2, generator losses
-    within 5 %."""
+    geometry on identical weights, inputs, noise and branch decisions at bs = 1 (the benchmark's bs = 8 shares the oracle pass
+    of test_benchmark_path_matches_oracle[independent_8x_256]): generated image within SURVEY 8(d)'s 3e-2, generator losses
+    within 5 %, parameter gradients within HALF_GRAD_*_BOUND."""
     import os
     from deepsee_amd import networks as N, ops
     from deepsee_amd.managers import TrainerManager
@@ -803,6 +1009,17 @@ def test_half_mode_vs_oracle(bs):
     assert dev < 3e-2, dev
     for k, v in gl.items():
         assert abs(hgl[k] - float(v.detach())) <= 0.05 * abs(float(v.detach())) + 1e-3, (k, hgl[k], float(v.detach()))
+    # gradients of the 16-bit mode against the ORACLE: every G / E parameter tensor the step reached, relative
+    # to its own norm (floored at 1e-3 of the largest gradient norm).  One-term fp16 operands carry 2^-11 per element and
+    # F(4x4,3x3) amplifies it ~10x per layer, on top of the LeakyReLU-kink floor the fp32 path already has.
+    ggrads = {"%s.%s" % (net, k): p.grad.clone() for net in ("SR", "E") for k, p in orc.params(net) if p.grad is not None}
+    hg = {nm: _grad_or_zero(p) for nm, p in zip(tm.optimizer_G.names, tm.optimizer_G.params)}
+    gmax = max(float(v.norm()) for v in ggrads.values())
+    errs = sorted(float((hg[k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax) for k, v in ggrads.items())
+    med, q90, worst = errs[len(errs) // 2], errs[int(0.9 * (len(errs) - 1))], errs[-1]
+    print("fp16 mode vs the CPU oracle at bs = %d: G-gradient rel err median %.2e, 90 %% %.2e, max %.2e over %d tensors"
+          % (bs, med, q90, worst, len(errs)))
+    assert med < HALF_GRAD_MEDIAN_BOUND and worst < HALF_GRAD_MAX_BOUND, (med, q90, worst)
 
 
 SWITCHES = [("keep_v", False), ("adjoint_dgrad", False), ("fuse_dm", False), ("fuse_noise", False), ("gemm_af32", False),

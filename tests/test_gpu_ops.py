@@ -110,6 +110,9 @@ def test_spade_sean_norm_fwd_bwd(kind, C, R, N):
 @pytest.mark.parametrize("kind,C,R,N,max_fm", [
     ("spade", 64, 16, 2, 256), ("sean", 64, 16, 2, 256), ("sean", 128, 32, 3, 256), ("puresean", 64, 16, 2, 256),
     ("spade", 64, 64, 2, 256), ("sean", 64, 64, 2, 256), ("sean", 128, 64, 3, 256), ("puresean", 64, 64, 2, 256),
+    # a channel count that is not a power of two (ngf = 12 / 24 / 48): the fused forward then writes no sign mask (its index
+    # is a shift) and the backward pass reads `out`
+    ("sean", 192, 64, 2, 256),
     # the reference's max_fm_size cap (normalization.py:188-190, 275-277): embedding at 32^2 / 16^2, upsampled, style ignored
     ("puresean", 128, 64, 2, 32), ("sean", 128, 64, 2, 16), ("puresean", 64, 16, 2, 8)])
 def test_sean_norm_table_path(kind, C, R, N, max_fm):
