@@ -569,6 +569,22 @@ def main():
                 "mfma_peak": pk, "mfma_frac": tfl / pk,
                 "bytes_note": "algorithmic bytes = x read + y written (4 N R^2 (Cin + Cout)); the Winograd formulation "
                               "additionally writes and re-reads V and M (DESIGN 3)"}
+        if base_plan.half:
+            # BASELINE configs[2] names bf16; this line runs scaled fp16.  The deviation and why, where the driver reads it
+            # (VERDICT r4 #7b; numbers: DESIGN 6.2, tests/test_gpu_model.py::test_half_mode_vs_oracle / test_benchmark_path_*)
+            out["baseline_dtype_deviation"] = {
+                "baseline_names": "bf16", "this_line_runs": "fp16 operands scaled by exact powers of two, fp32 accumulate",
+                "why": "F(4x4,3x3) amplifies operand rounding ~10x: a Winograd layer on bf16 operands (8 significand bits) is "
+                       "off by 2.6 % per layer, on scaled fp16 operands (11 bits) by 0.33 %; fp16's 5-bit exponent suffices "
+                       "because every operand tensor carries a power-of-two scale derived from its producer's bound",
+                "per_layer_relative_error": {"winograd_bf16_operands": 2.6e-2, "winograd_bf16_operands_and_products": 3.2e-2,
+                                             "winograd_scaled_fp16_operands": 3.3e-3,
+                                             "winograd_scaled_fp16_operands_and_products": 4.0e-3,
+                                             "direct_conv_bf16_operands": 2.4e-3},
+                "generated_image_vs_fp32_path": {"bf16_operands_first_version": 7.9e-2, "scaled_fp16": 1.0e-2},
+                "generated_image_vs_cpu_oracle": {"bs1": 6.0e-3, "bs8": 8.6e-3, "bound": 3e-2},
+                "what_a_bf16_path_would_need": "a direct (non-Winograd) bf16 MFMA implicit GEMM: 2.25x the MFMA work of "
+                                               "F(4x4,3x3) at 0.24 % per layer; not built (DESIGN 6.2)"}
         if dp:
             out["dp"] = dp
         if f32_only:

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 
 #if DSEE_FUSED_ABL & 32
   unsigned long long tw_ = 0, tm_ = 0, tl_ = 0, t0_ = 0, t1_ = 0, tstart_ = __builtin_readcyclecounter();
+  unsigned long long tq0_ = 0, tq1_ = 0, tq2_ = 0, tv_ = 0;   // fragment reads | DMA requests | fold / Y update | vmcnt wait alone
 #endif
   // One transform position = NP pieces in two stages.  During piece k the fragments of piece k + 1 (of the next position at
   // the end) are read, a share of the look-ahead stage s + 3 is requested and `fill(k)` runs (the Y update of the previous
@@ -308,6 +309,9 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (C1 - C0)) : "memory");
+#if DSEE_FUSED_ABL & 32
+      tv_ += __builtin_readcyclecounter() - t0_;
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 #if DSEE_FUSED_ABL & 32
@@ -318,12 +322,21 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
         constexpr int p = decltype(p_c)::value, k = C0 + p;
         constexpr int fcur = (k + (NP & 1) * PAR) & 1;   // fragment buffer: parity of the running piece count pos * NP + k
         auto loads = [&]() {
+#if DSEE_FUSED_ABL & 32
+          unsigned long long q0_ = __builtin_readcyclecounter();
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           if constexpr (!(DSEE_FUSED_ABL & 2)) {
             if constexpr (k + 1 < NP)
               ldf(F[1 - fcur], ic<PAR>{}, ic<k + 1>{});
             else
               ldf(F[1 - fcur], ic<1 - PAR>{}, ic<0>{});
           }
+#if DSEE_FUSED_ABL & 32
+          __builtin_amdgcn_sched_barrier(0);
+          { const unsigned long long tt = __builtin_readcyclecounter(); tq0_ += tt - q0_; q0_ = tt; }
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           if constexpr (!(DSEE_FUSED_ABL & 8)) {
             // the L1 - L0 look-ahead pieces spread over the C1 - C0 computed ones
             constexpr int a0 = L0 + p * (L1 - L0) / (C1 - C0), a1 = L0 + (p + 1) * (L1 - L0) / (C1 - C0);
@@ -332,7 +345,16 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
               dma_v(LPAR, a0 + decltype(d)::value, ov);
             });
           }
+#if DSEE_FUSED_ABL & 32
+          __builtin_amdgcn_sched_barrier(0);
+          { const unsigned long long tt = __builtin_readcyclecounter(); tq1_ += tt - q0_; q0_ = tt; }
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           if constexpr (!(DSEE_FUSED_ABL & 4)) fill(ic<k>{});
+#if DSEE_FUSED_ABL & 32
+          __builtin_amdgcn_sched_barrier(0);
+          { const unsigned long long tt = __builtin_readcyclecounter(); tq2_ += tt - q0_; }
+#endif
         };
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (LATE) {
@@ -569,8 +591,9 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && blockIdx.x < 64) {   // per wave: stage waits | MFMA parts | load parts | epilogue
     const unsigned long long tend_ = __builtin_readcyclecounter();
-    float* o = a.stamps + (blockIdx.x * 8 + wave) * 4;
+    float* o = a.stamps + (blockIdx.x * 8 + wave) * 8;
     o[0] = (float)tw_; o[1] = (float)tm_; o[2] = (float)tl_; o[3] = (float)(tend_ - tmain_);
+    o[4] = (float)tq0_; o[5] = (float)tq1_; o[6] = (float)tq2_; o[7] = (float)tv_;
   }
 #endif
   };

@@ -544,12 +544,11 @@ class MultiscaleDiscriminator(nn.Module):
                                     for i in range(self.num_d)
                                     for n in range(1, getattr(self, "discriminator_%d" % i).nl)])
         self._sn.run(training)
-        res = []
-        for i in range(self.num_d):
-            res.append(getattr(self, "discriminator_%d" % i)(x, training))
-            if i + 1 < self.num_d:
-                x = ops.AvgPool3s2.apply(x)
-        return res
+        # the scales are independent given x (and its pooled copies): one branch per scale (ops.branches)
+        xs = [x]
+        for i in range(1, self.num_d):
+            xs.append(ops.AvgPool3s2.apply(xs[-1]))
+        return ops.branches(*[(lambda i=i: getattr(self, "discriminator_%d" % i)(xs[i], training)) for i in range(self.num_d)])
 
 
 # ------------------------------------------------------------------------------------ VGG19 perceptual taps

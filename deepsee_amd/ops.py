@@ -8,6 +8,8 @@ library these functions raise.
 import os
 import ctypes as C
 
+import threading
+
 import torch
 
 from . import lib as L
@@ -74,6 +76,62 @@ def scratch(nbytes, tag="ws"):
 
 def new(*shape):
     return torch.empty(*shape, dtype=torch.float32, device="cuda")
+
+
+# ------------------------------------------------------------------------------------ independent branches on side streams
+_branch_streams = {}
+_branch_tls = threading.local()
+
+
+def _mark_streams(obj, stream):
+    """Tensors a branch hands to the joined stream were allocated on the branch's stream: tell the caching allocator they are
+    in use elsewhere too (eager mode; inside a capture the graph's private pool is not recycled across streams)."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _mark_streams(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _mark_streams(o, stream)
+
+
+def branches(*fns):
+    """Run independent parts of the step -- the two discriminator scales, VGG(fake) / VGG(real) -- on side streams (VERDICT r4
+    #4): their small layers fill a fraction of the 256 CUs each, and serialised on one stream every one of their ~600 launches
+    waits for the previous one to drain.  fns[0] stays on the calling stream, fns[1:] fork from it (each side stream waits for
+    everything the calling stream has enqueued) and are joined before this returns.  Inside a hipGraph capture the forks
+    become parallel branches of the graph.  The autograd engine runs every node's backward on the stream of its forward and
+    inserts the cross-stream waits itself, so the backward passes of the branches overlap the same way.  Scratch buffers and
+    operand-maximum pools are per stream (scratch(), amax_slot()).  plan.branch_streams = False runs them in order."""
+    if len(fns) < 2 or not P().branch_streams:
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    depth = getattr(_branch_tls, "depth", 0)
+    dev = torch.cuda.current_device()
+    sides = []
+    for i in range(len(fns) - 1):
+        key = (dev, depth, i)
+        if key not in _branch_streams:
+            _branch_streams[key] = torch.cuda.Stream()
+        sides.append(_branch_streams[key])
+    _branch_tls.depth = depth + 1
+    try:
+        outs = [None] * len(fns)
+        for i, sd in enumerate(sides):
+            sd.wait_stream(main)
+            with torch.cuda.stream(sd):
+                outs[i + 1] = fns[i + 1]()
+        outs[0] = fns[0]()
+        capturing = torch.cuda.is_current_stream_capturing()
+        for i, sd in enumerate(sides):
+            main.wait_stream(sd)
+            if not capturing:
+                _mark_streams(outs[i + 1], main)
+    finally:
+        _branch_tls.depth = depth
+    return outs
 
 
 def _under_plan(backward):

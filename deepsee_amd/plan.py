@@ -75,6 +75,9 @@ class KernelPlan:
     # the backward of the LeakyReLU in front of the to-RGB layer inside that layer's data-gradient kernel (False: the last
     # resblock's own pass over (dy, y))
     defer_act: bool = True
+    # independent branches of the step (the two discriminator scales, VGG on the generated / the real image) on side streams --
+    # parallel branches of the captured hipGraph (False: everything on one stream, in program order)
+    branch_streams: bool = True
     # direct (non-Winograd) convolutions with at least this much work run their MFMAs on fp16x2-split operands; 0 disables
     conv_f16x2_min_flop: float = 1e9
     # SyncBN-over-RCCL (ops.SyncBNConfig) or None for north_star's sync-free BatchNorm

@@ -281,7 +281,23 @@ class SRModel(nn.Module):
         opt = self.opt
         losses = OrderedDict()
         fake, _ = self.generate_fake(d)
-        pred = self.discriminate(d["labels"], fake, d["image_hr"], train_d=False)
+        # D(fake | real), VGG(fake) and VGG(real) are independent given `fake`: three branches (ops.branches; the two
+        # discriminator scales fork again inside netD)
+        use_vgg = not opt.no_vgg_loss
+
+        def vgg_real():
+            with torch.no_grad():
+                return self.vgg(d["image_hr"])
+        parts = [lambda: self.discriminate(d["labels"], fake, d["image_hr"], train_d=False)]
+        if use_vgg:
+            parts += [lambda: self.vgg(fake), vgg_real]
+        if use_vgg and not getattr(self, "_vgg_packed", False) and not torch.cuda.is_current_stream_capturing():
+            # the first forward builds the frozen VGG weights' packed / transformed images once (ops._frozen_cache) and both VGG
+            # passes read them: that one time they run in order, on one stream
+            pred, fx, fy = [f() for f in parts]
+            self._vgg_packed = True
+        else:
+            pred, fx, fy = (ops.branches(*parts) + [None, None])[:3]
         n = fake.shape[0]
         gan = 0
         for p in pred:
@@ -294,10 +310,7 @@ class SRModel(nn.Module):
                     real = f[n:].detach()
                     terms.append(ops.mean_loss(f, real, ops.MODE_L1, opt.lambda_feat / len(pred), lo=0, hi=n))
             losses["GAN_Feat"] = _sum_terms(terms)
-        if not opt.no_vgg_loss:
-            fx = self.vgg(fake)
-            with torch.no_grad():
-                fy = self.vgg(d["image_hr"])
+        if use_vgg:
             losses["VGG"] = _sum_terms([ops.mean_loss(a, b, ops.MODE_L1, w * opt.lambda_vgg)
                                         for w, a, b in zip(N.VGG_WEIGHTS, fx, fy)])
         return losses, ops.ToNCHW.apply(fake, 3)
