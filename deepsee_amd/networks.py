@@ -548,7 +548,11 @@ class MultiscaleDiscriminator(nn.Module):
         xs = [x]
         for i in range(1, self.num_d):
             xs.append(ops.AvgPool3s2.apply(xs[-1]))
-        return ops.branches(*[(lambda i=i: getattr(self, "discriminator_%d" % i)(xs[i], training)) for i in range(self.num_d)])
+        # (tensors made on this stream that the side branches read, forward and backward: the pooled inputs and the
+        # spectral-normalised weights W / sigma of this forward)
+        shared = xs[1:] + list(self._sn.last)          # (SNGroup.last: the buffer all W / sigma are slices of + their maxima)
+        return ops.branches(*[(lambda i=i: getattr(self, "discriminator_%d" % i)(xs[i], training)) for i in range(self.num_d)],
+                            inputs=shared)
 
 
 # ------------------------------------------------------------------------------------ VGG19 perceptual taps

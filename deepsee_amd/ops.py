@@ -97,14 +97,20 @@ def _mark_streams(obj, stream):
             _mark_streams(o, stream)
 
 
-def branches(*fns):
+def branches(*fns, inputs=()):
     """Run independent parts of the step -- the two discriminator scales, VGG(fake) / VGG(real) -- on side streams (VERDICT r4
     #4): their small layers fill a fraction of the 256 CUs each, and serialised on one stream every one of their ~600 launches
     waits for the previous one to drain.  fns[0] stays on the calling stream, fns[1:] fork from it (each side stream waits for
     everything the calling stream has enqueued) and are joined before this returns.  Inside a hipGraph capture the forks
     become parallel branches of the graph.  The autograd engine runs every node's backward on the stream of its forward and
     inserts the cross-stream waits itself, so the backward passes of the branches overlap the same way.  Scratch buffers and
-    operand-maximum pools are per stream (scratch(), amax_slot()).  plan.branch_streams = False runs them in order."""
+    operand-maximum pools are per stream (scratch(), amax_slot()).  plan.branch_streams = False runs them in order.
+
+    `inputs`: tensors (or nests of them) that were allocated on the CALLING stream, are consumed inside a side branch -- forward
+    or backward -- and may be FREED before the step ends (activations feeding a branch, per-forward weight tensors such as the
+    spectral-normalised W / sigma).  They are marked as in use on every side stream (record_stream): the caching allocator
+    would otherwise hand their memory to the next allocation of the calling stream the moment the last Python reference goes --
+    e.g. right after the branch's backward node RAN on the host, while its kernel is still queued on the side stream."""
     if len(fns) < 2 or not P().branch_streams:
         return [f() for f in fns]
     main = torch.cuda.current_stream()
@@ -120,15 +126,14 @@ def branches(*fns):
     try:
         outs = [None] * len(fns)
         for i, sd in enumerate(sides):
+            _mark_streams(inputs, sd)
             sd.wait_stream(main)
             with torch.cuda.stream(sd):
                 outs[i + 1] = fns[i + 1]()
         outs[0] = fns[0]()
-        capturing = torch.cuda.is_current_stream_capturing()
         for i, sd in enumerate(sides):
             main.wait_stream(sd)
-            if not capturing:
-                _mark_streams(outs[i + 1], main)
+            _mark_streams(outs[i + 1], main)
     finally:
         _branch_tls.depth = depth
     return outs

@@ -297,7 +297,7 @@ class SRModel(nn.Module):
             pred, fx, fy = [f() for f in parts]
             self._vgg_packed = True
         else:
-            pred, fx, fy = (ops.branches(*parts) + [None, None])[:3]
+            pred, fx, fy = (ops.branches(*parts, inputs=[fake, d["image_hr"]]) + [None, None])[:3]
         n = fake.shape[0]
         gan = 0
         for p in pred:
