@@ -42,6 +42,13 @@
 #define DSEE_FUSED_ABL 0
 #endif
 
+// Schedule variants for same-box A/B (tools/exp/build_fused_var.sh): bit 1 the early wave group requests the next piece's
+// fragments before its MFMAs, 2 s_setprio(1) around the MFMAs of a piece, 4 static priority for waves 4-7, 8 the look-ahead
+// LDS-DMA requests of a piece issued between its MFMAs instead of back to back.
+#ifndef DSEE_FUSED_SCHED
+#define DSEE_FUSED_SCHED 0
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -95,11 +102,18 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
 // 64-byte rows holding 32 k's of one scaled fp16 term, gemm_bf16x3.hip) -- a piece is then 64 k's (its two "term" halves are
 // k's 0-31 and 32-63), a position NP = 2 (K = 128) or 3 (K = 160: the last piece half empty, fetched as zeros) pieces, and a
 // piece costs 2 MFMA products per block instead of 3.  Ring, fragment reads, fold and epilogue are unchanged.
-template <int NP, bool WSCALE, bool PK = false>
+// RD: depth of the operand ring in transform positions.  The requests of stage s + 2 RD - 1 are issued during stage s, so
+// (2 RD - 1) / 2 positions of operands are in flight per CU: 123 KB with RD = 2 at K = 160 in the two-term form (the whole
+// 160 KB of LDS is the ring), and what the kernel sustains is that window divided by the loaded L2 / HBM latency -- round 5
+// measured it: no schedule change moves the kernel, removing the requests does.  The packed one-term operands are half the
+// bytes, so their ring takes RD = 3 (144 KB at K = 160, 2.5 positions = 102 KB in flight instead of 1.5 = 61 KB).
+template <int NP, bool WSCALE, bool PK = false, int RD = 2>
 __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PIECE = 8192;                  // 32 k's of one operand: 64 rows x (2 terms x 4 octets x 16 B)   [PK: 64 k's]
-  constexpr int UREG = 2 * NP * PIECE;         // LDS: [2 NP pieces of U][2 NP pieces of V]; piece (par, k) in slot par * NP + k
+  constexpr int UREG = RD * NP * PIECE;        // LDS: [RD NP pieces of U][RD NP pieces of V]; piece (par, k) in slot par * NP + k
+  static_assert(RD == 2 || RD == 3, "a row of 6 positions is a whole number of ring turns");
+  static_assert(2 * UREG <= 160 * 1024 && 2 * UREG >= 65536, "ring fits the LDS and covers the epilogue's 64 KB");
   static_assert(PK ? (NP == 2 || NP == 3) : (NP == 4 || NP == 5), "K = 128 or 160");
   constexpr bool HALF_LAST = PK && NP == 3;    // K = 160 = 2.5 pieces of 64 k's
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * POSB (>= 64 KB for the epilogue)
@@ -138,13 +152,15 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   const float oscale = 1.f / (sv * su);
 
   // ---- LDS-DMA: wave w fills rows 8w .. 8w+7 of every piece (64 slots); lane -> (row 8w + l/8, slot chunk l%8) fetches
-  //      chunk cc = (l%8) ^ f(row) = 4 term + octet: bytes (2 term + octet%2) * 16 of the row in 16-k slab 2 piece + octet/2.
+  //      chunk cc = (l%8) ^ f(row) = 4 slab + 2 term + octet%2: bytes (cc % 4) * 16 of the row in 16-k slab 2 piece + cc / 4 --
+  //      the 4 lanes of a quad fetch the 64 contiguous bytes of ONE (row, slab) in some order, so the texture addresser sees
+  //      one 64-byte segment per quad (round 5; with cc = 4 term + octet a quad straddled both slabs: two segments per quad).
   //      PK: chunk cc = 4 half + octet = k's 8 cc .. 8 cc + 7 of the 64-k piece: bytes (cc % 4) * 16 of the row in 32-k slab
-  //      2 piece + cc / 4.
+  //      2 piece + cc / 4 (the same formulas).
   const int dr = 8 * wave + (lane >> 3);
   const int dcc = (lane & 7) ^ ((dr >> 1) & 7);
-  const int dslab = PK ? (dcc >> 2) : ((dcc >> 1) & 1);   // which of the piece's two slabs this lane reads
-  const unsigned dlo = PK ? (unsigned)(dr * 64 + (dcc & 3) * 16) : (unsigned)(dr * 64 + (2 * (dcc >> 2) + (dcc & 1)) * 16);
+  const int dslab = dcc >> 2;                      // which of the piece's two slabs this lane reads
+  const unsigned dlo = (unsigned)(dr * 64 + (dcc & 3) * 16);
   const unsigned voffu = dlo + (unsigned)dslab * (unsigned)a.u_slab_bytes;
   const unsigned voffv = dlo + (unsigned)dslab * (unsigned)a.v_slab_bytes;
   // the half-empty last piece: its second slab does not exist -- out-of-range offsets make the buffer loads return zeros
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   const unsigned PU = (unsigned)(a.G * a.u_group_bytes), PV = (unsigned)(a.T * 64);       // per position
   const unsigned QU = (unsigned)(2 * a.u_slab_bytes), QV = (unsigned)(2 * a.v_slab_bytes);   // per piece
   const unsigned base_u = (unsigned)((long)g * a.u_group_bytes + (long)rg * 4096), base_v = (unsigned)(t0 * 64);
-  // piece pc of position pos (ring half par): one U and one V instruction per wave
+  // piece pc of position pos (ring slot group par = pos % RD): one U and one V instruction per wave
   auto dma_u = [&](int par, int pc, unsigned opos) {
     unsigned char* dst = smem + (par * NP + pc) * PIECE + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (__attribute__((address_space(3))) void*)dst, 16,
@@ -166,11 +182,15 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
                                              (HALF_LAST && pc == NP - 1) ? voffv_l : voffv, opos + pc * QV, 0, 0);
   };
 
-  // ---- fragment addresses (bytes within a piece): row r, chunk 4 term + octet at slot 8r + (chunk ^ f(r)).
+  // ---- fragment addresses (bytes within a piece): row r, chunk 4 (octet / 2) + 2 term + octet % 2 [PK: 4 half + octet] at slot
+  //      8r + (chunk ^ f(r)).
   //      A operand: lane -> (row l%16 of its 16-row block, octet l/16); gamma block rows 16 wq + i, beta block rows
   //      32 + 16 wq + i of the 64-row group; B operand: tiles 16 wt + i.
   const int fi = lane & 15, oc = lane >> 4;
-  auto foff = [&](int r, int t) { return (unsigned)((8 * r + ((4 * t + oc) ^ ((r >> 1) & 7))) * 16); };
+  auto foff = [&](int r, int t) {
+    const int chunk = PK ? 4 * t + oc : 4 * (oc >> 1) + 2 * t + (oc & 1);
+    return (unsigned)((8 * r + (chunk ^ ((r >> 1) & 7))) * 16);
+  };
   const int rga = 16 * wq + fi, rtv = 16 * wt + fi;
   // DS instructions address VGPR + 16-bit immediate: two windows (slots 0-6, 7-9) per fragment kind cover each 80 / 64 KB region (the
   // beta block's rows are the gamma block's + 32: same swizzle, + 4096 bytes)
@@ -196,7 +216,8 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     f.v1 = *reinterpret_cast<const u32x4*>(bv1 + io);
   };
   // the three products of a piece for both blocks, alternating between the two accumulators
-  auto mm = [&](const Frag& f, f32x4& pg, f32x4& pb) {
+  auto mm = [&](const Frag& f, f32x4& pg, f32x4& pb, auto&& h1, auto&& h2) {
+    if constexpr (DSEE_FUSED_SCHED & 2) __builtin_amdgcn_s_setprio(1);
     const f16x8 g0 = __builtin_bit_cast(f16x8, f.g0), g1 = __builtin_bit_cast(f16x8, f.g1);
     const f16x8 b0 = __builtin_bit_cast(f16x8, f.b0), b1 = __builtin_bit_cast(f16x8, f.b1);
     const f16x8 v0 = __builtin_bit_cast(f16x8, f.v0), v1 = __builtin_bit_cast(f16x8, f.v1);
@@ -206,16 +227,21 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     } else if constexpr (PK) {   // one term: the two chunk groups are k's 0-31 and 32-63 of the piece
       pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, v0, pg, 0, 0, 0);
       pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, v0, pb, 0, 0, 0);
+      h1();
       pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, v1, pg, 0, 0, 0);
       pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, v1, pb, 0, 0, 0);
+      h2();
     } else {
       pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, v0, pg, 0, 0, 0);
       pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, v0, pb, 0, 0, 0);
+      h1();
       pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, v1, pg, 0, 0, 0);
       pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, v1, pb, 0, 0, 0);
+      h2();
       pg = __builtin_amdgcn_mfma_f32_16x16x32_f16(g0, v0, pg, 0, 0, 0);
       pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, v0, pb, 0, 0, 0);
     }
+    if constexpr (DSEE_FUSED_SCHED & 2) __builtin_amdgcn_s_setprio(0);
   };
 
   // Everything from here on exists twice, once per wave group (see `late` below): the accumulator-resident state never
@@ -241,20 +267,19 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) T[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- ring: 2 NP pieces (two positions), piece (pos, k) in slot (pos & 1) * NP + k.  A position is two stages (pieces
-  //      [0, NA) and [NA, NP)), one barrier each; the requests of stage s + 3 are issued during stage s into the slots of
-  //      stage s - 1 (dead: every wave consumed those fragments before it arrived at the barrier that opens s).
+  // ---- ring: RD NP pieces (RD positions), piece (pos, k) in slot (pos % RD) * NP + k.  A position is two stages (pieces
+  //      [0, NA) and [NA, NP)), one barrier each; the requests of stage s + 2 RD - 1 (RD = 2: s + 3) are issued during stage s
+  //      into the slots of stage s - 1 (dead: every wave consumed those fragments before it arrived at the barrier that opens s).
   constexpr int NA = NP == 2 ? 1 : 2;
   auto issue_stage = [&](int pos, int half) {   // prologue only (run-time indices)
     for (int k = half ? NA : 0; k < (half ? NP : NA); ++k) {
-      dma_u(pos & 1, k, base_u + pos * PU);
-      dma_v(pos & 1, k, base_v + pos * PV);
+      dma_u(pos % RD, k, base_u + pos * PU);
+      dma_v(pos % RD, k, base_v + pos * PV);
     }
   };
-  issue_stage(0, 0);
-  issue_stage(0, 1);
-  issue_stage(1, 0);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");   // stage 0 landed (this wave's rows)
+  for (int st = 0; st < 2 * RD - 1; ++st) issue_stage(st >> 1, st & 1);
+  // stage 0 landed (this wave's rows): only the 2 RD - 2 younger stages = RD - 1 whole positions may be in flight
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * (RD - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   ldf(F[0], ic<0>{}, ic<0>{});
@@ -285,30 +310,32 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 #endif
   // One transform position = NP pieces in two stages.  During piece k the fragments of piece k + 1 (of the next position at
   // the end) are read, a share of the look-ahead stage s + 3 is requested and `fill(k)` runs (the Y update of the previous
-  // row of positions).  Between barriers the waves drift freely.  pos is wave-uniform, its parity PAR (ring half) a
+  // row of positions).  Between barriers the waves drift freely.  pos is wave-uniform, its ring slot group PAR = pos % RD and
+  // its parity PP
   // compile-time constant.
-  auto position = [&](auto late_c, int pos, auto par_c, auto&& fill) {
+  auto position = [&](auto late_c, int pos, auto par_c, auto pp_c, auto&& fill) {
     constexpr bool LATE = decltype(late_c)::value != 0;
-    constexpr int PAR = decltype(par_c)::value;
+    constexpr int PAR = decltype(par_c)::value, PP = decltype(pp_c)::value;
     P[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     P[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     static_for<2>([&](auto half_c) {
       constexpr int half = decltype(half_c)::value;
-      // look-ahead stage s + 3 = (pos + 1, second half) | (pos + 2, first half), clamped to the last position (the
-      // surplus requests of the last three stages re-read valid memory into slots nobody reads any more)
-      const int pl = (DSEE_FUSED_ABL & 64) ? 0 : min(pos + 1 + half, 35);   // (64: every request re-reads position 0)
+      // look-ahead stage s + 2 RD - 1 = (pos + RD - 1, second half) | (pos + RD, first half), clamped to the last position
+      // (the surplus requests of the last 2 RD - 1 stages re-read valid memory into slots nobody reads any more)
+      const int pl = (DSEE_FUSED_ABL & 64) ? 0 : min(pos + RD - 1 + half, 35);   // (64: every request re-reads position 0)
       const unsigned ou = base_u + pl * PU, ov = base_v + pl * PV;
-      constexpr int LPAR = half ? PAR : 1 - PAR;               // ring half of the look-ahead position
+      constexpr int LPAR = half ? PAR : (PAR + RD - 1) % RD;   // ring slot group of the look-ahead position
       constexpr int L0 = half ? 0 : NA, L1 = half ? NA : NP;   // its pieces
       constexpr int C0 = half ? NA : 0, C1 = half ? NP : NA;   // the pieces computed now
 #if DSEE_FUSED_ABL & 32
       t0_ = __builtin_readcyclecounter();
 #endif
-      // stage s + 1 has landed (this wave's rows) when only the requests of stage s + 2 are still in flight
+      // stage s + 1 has landed (this wave's rows) when only the requests of stages s + 2 .. s + 2 RD - 2 are still in flight:
+      // RD - 1 stages of this half's piece count and RD - 2 of the other half's
       if constexpr (DSEE_FUSED_ABL & 8)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (C1 - C0)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ((RD - 1) * (C1 - C0) + (RD - 2) * (NP - (C1 - C0)))) : "memory");
 #if DSEE_FUSED_ABL & 32
       tv_ += __builtin_readcyclecounter() - t0_;
 #endif
@@ -320,24 +347,25 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 #endif
       static_for<C1 - C0>([&](auto p_c) {
         constexpr int p = decltype(p_c)::value, k = C0 + p;
-        constexpr int fcur = (k + (NP & 1) * PAR) & 1;   // fragment buffer: parity of the running piece count pos * NP + k
-        auto loads = [&]() {
+        constexpr int fcur = (k + (NP & 1) * PP) & 1;    // fragment buffer: parity of the running piece count pos * NP + k
+        auto loads = [&](auto frags_c, auto rest_c) {
+          constexpr bool FRAGS = decltype(frags_c)::value != 0, REST = decltype(rest_c)::value != 0;
 #if DSEE_FUSED_ABL & 32
           unsigned long long q0_ = __builtin_readcyclecounter();
           __builtin_amdgcn_sched_barrier(0);
 #endif
-          if constexpr (!(DSEE_FUSED_ABL & 2)) {
+          if constexpr (FRAGS && !(DSEE_FUSED_ABL & 2)) {
             if constexpr (k + 1 < NP)
               ldf(F[1 - fcur], ic<PAR>{}, ic<k + 1>{});
             else
-              ldf(F[1 - fcur], ic<1 - PAR>{}, ic<0>{});
+              ldf(F[1 - fcur], ic<(PAR + 1) % RD>{}, ic<0>{});
           }
 #if DSEE_FUSED_ABL & 32
           __builtin_amdgcn_sched_barrier(0);
           { const unsigned long long tt = __builtin_readcyclecounter(); tq0_ += tt - q0_; q0_ = tt; }
           __builtin_amdgcn_sched_barrier(0);
 #endif
-          if constexpr (!(DSEE_FUSED_ABL & 8)) {
+          if constexpr (REST && !(DSEE_FUSED_ABL & 8) && !(DSEE_FUSED_SCHED & 8)) {
             // the L1 - L0 look-ahead pieces spread over the C1 - C0 computed ones
             constexpr int a0 = L0 + p * (L1 - L0) / (C1 - C0), a1 = L0 + (p + 1) * (L1 - L0) / (C1 - C0);
             static_for<a1 - a0>([&](auto d) {
@@ -350,31 +378,59 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
           { const unsigned long long tt = __builtin_readcyclecounter(); tq1_ += tt - q0_; q0_ = tt; }
           __builtin_amdgcn_sched_barrier(0);
 #endif
-          if constexpr (!(DSEE_FUSED_ABL & 4)) fill(ic<k>{});
+          if constexpr (REST && !(DSEE_FUSED_ABL & 4)) fill(ic<k>{});
 #if DSEE_FUSED_ABL & 32
           __builtin_amdgcn_sched_barrier(0);
           { const unsigned long long tt = __builtin_readcyclecounter(); tq2_ += tt - q0_; }
 #endif
         };
+        // DSEE_FUSED_SCHED & 8: this piece's share of the look-ahead requests is issued BETWEEN its MFMAs, half behind the
+        // second and half behind the fourth, instead of back to back in the load part: a request that finds the texture
+        // addresser's queue full blocks the (in-order) wave, and 2 - 4 requests in a row from four waves at once did
+        auto dma_part = [&](auto part_c) {
+          if constexpr ((DSEE_FUSED_SCHED & 8) && !(DSEE_FUSED_ABL & 8)) {
+            constexpr int part = decltype(part_c)::value;
+            constexpr int a0 = L0 + p * (L1 - L0) / (C1 - C0), a1 = L0 + (p + 1) * (L1 - L0) / (C1 - C0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (a1 - a0 == 1) {
+              if constexpr (part == 0) dma_u(LPAR, a0, ou); else dma_v(LPAR, a0, ov);
+            } else if constexpr (a1 - a0 == 2) {
+              dma_u(LPAR, a0 + part, ou);
+              dma_v(LPAR, a0 + part, ov);
+            } else {
+              static_assert(a1 - a0 == 0, "0, 1 or 2 look-ahead pieces per computed piece");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        auto h1 = [&]() { dma_part(ic<0>{}); };
+        auto h2 = [&]() { dma_part(ic<1>{}); };
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (LATE) {
-        loads();
+        loads(ic<1>{}, ic<1>{});
         __builtin_amdgcn_sched_barrier(0);
 #if DSEE_FUSED_ABL & 32
         { const unsigned long long tt = __builtin_readcyclecounter(); tl_ += tt - t1_; t1_ = tt; }
 #endif
-        mm(F[fcur], P[0], P[1]);
+        mm(F[fcur], P[0], P[1], h1, h2);
         __builtin_amdgcn_sched_barrier(0);
 #if DSEE_FUSED_ABL & 32
         { const unsigned long long tt = __builtin_readcyclecounter(); tm_ += tt - t1_; t1_ = tt; }
 #endif
       } else {
-        mm(F[fcur], P[0], P[1]);
+        // (DSEE_FUSED_SCHED & 1: the early group requests the NEXT piece's fragments before its MFMAs -- the other fragment
+        //  buffer is free since the previous piece -- so that their LDS latency runs under its own matrix work instead of in
+        //  front of the next piece's; the DMA requests and the fold slices stay behind the MFMAs)
+        if constexpr (DSEE_FUSED_SCHED & 1) {
+          loads(ic<1>{}, ic<0>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mm(F[fcur], P[0], P[1], h1, h2);
         __builtin_amdgcn_sched_barrier(0);
 #if DSEE_FUSED_ABL & 32
         { const unsigned long long tt = __builtin_readcyclecounter(); tm_ += tt - t1_; t1_ = tt; }
 #endif
-        loads();
+        loads(ic<(DSEE_FUSED_SCHED & 1) ? 0 : 1>{}, ic<1>{});
         __builtin_amdgcn_sched_barrier(0);
 #if DSEE_FUSED_ABL & 32
         { const unsigned long long tt = __builtin_readcyclecounter(); tl_ += tt - t1_; t1_ = tt; }
@@ -415,7 +471,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
     const float cf[4] = {q < 0 ? 0.f : 1.f, q <= 0 ? 0.f : (q == 1 ? 1.f : (q == 2 ? -1.f : (q == 3 ? 2.f : -2.f))),
                          q <= 0 ? 0.f : (q < 3 ? 1.f : 4.f),
                          q <= 0 ? 0.f : (q == 1 ? 1.f : (q == 2 ? -1.f : (q == 3 ? 8.f : -8.f)))};
-    position(late_c, r * 6, ic<0>{}, [&](auto k_c) {
+    position(late_c, r * 6, ic<0>{}, ic<0>{}, [&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
       if constexpr (k >= 1) {
         // rows of At with a zero in column q need no update: q = -1 (first row of positions) none, q = 0 only i = 0
@@ -434,14 +490,15 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
       }
     });
     fold(ic<0>{}, P[0], P[1]);
-#define DSEE_POS(C, PAR)                                        \
-  position(late_c, r * 6 + C, ic<PAR>{}, [&](auto) {});         \
+    // (position r * 6 + C: ring slot group C % RD -- a row is a whole number of ring turns -- and parity C % 2)
+#define DSEE_POS(C)                                                            \
+  position(late_c, r * 6 + C, ic<C % RD>{}, ic<C % 2>{}, [&](auto) {});        \
   fold(ic<C>{}, P[0], P[1]);
-    DSEE_POS(1, 1)
-    DSEE_POS(2, 0)
-    DSEE_POS(3, 1)
-    DSEE_POS(4, 0)
-    DSEE_POS(5, 1)
+    DSEE_POS(1)
+    DSEE_POS(2)
+    DSEE_POS(3)
+    DSEE_POS(4)
+    DSEE_POS(5)
 #undef DSEE_POS
   }
 
@@ -597,6 +654,9 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   }
 #endif
   };
+  if constexpr (DSEE_FUSED_SCHED & 4) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // (the younger half of the workgroup loses VALU arbitration by age otherwise)
+  }
   if (wave >= 4) body(ic<1>{}); else body(ic<0>{});
 #endif
 }
@@ -667,12 +727,13 @@ static int spade_fused_launch(bool packed, const void* V2, const void* U2, const
   const long ntile = (T / 64) * (rows / 64);
   DSEE_CHECK_ARG(ntile < 0x7FFFFFFF);
   const int np = packed ? (K + 63) / 64 : K / 32;
-  const size_t lds = (size_t)2 * np * 16384;   // ring of two positions: 2 * NP pieces of U and of V, 8 KB each
+  const int rd = packed ? 3 : 2;               // ring depth in positions (see the kernel): the packed operands are half the bytes
+  const size_t lds = (size_t)rd * np * 16384;  // ring of rd positions: rd * NP pieces of U and of V, 8 KB each
 #define DSEE_FUSED(NP, WS, PKD)                                                                                      \
   do {                                                                                                               \
     static bool attr_done = false;                                                                                   \
     if (!attr_done) {                                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_fwd_kernel<NP, WS, PKD>),       \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_fwd_kernel<NP, WS, PKD, (PKD ? 3 : 2)>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e != hipSuccess) {                                                                                         \
         dsee_set_error("hipFuncSetAttribute(%zu bytes of LDS): %s", lds, hipGetErrorString(e));                     \
@@ -680,7 +741,7 @@ static int spade_fused_launch(bool packed, const void* V2, const void* U2, const
       }                                                                                                              \
       attr_done = true;                                                                                              \
     }                                                                                                                \
-    spade_fused_fwd_kernel<NP, WS, PKD><<<(int)ntile, 512, lds, st>>>(a);                                            \
+    spade_fused_fwd_kernel<NP, WS, PKD, (PKD ? 3 : 2)><<<(int)ntile, 512, lds, st>>>(a);                             \
   } while (0)
   if (packed) {
     if (np == 3) {

@@ -101,7 +101,25 @@ class KernelPlan:
         return [f.name for f in dataclasses.fields(cls)]
 
 
-DEFAULT_PLAN = KernelPlan()
+def _env_overrides():
+    """DSEE_PLAN="field=value,field=value": overrides of the DEFAULT plan for a whole process (A/B runs of the test suite or of a
+    training script without touching its code); values are Python literals."""
+    import ast
+    import os
+    text = os.environ.get("DSEE_PLAN", "").strip()
+    if not text:
+        return {}
+    out = {}
+    for item in text.split(","):
+        k, _, v = item.partition("=")
+        k = k.strip()
+        if k not in KernelPlan.fields():
+            raise ValueError("DSEE_PLAN: unknown KernelPlan field %r (fields: %s)" % (k, ", ".join(KernelPlan.fields())))
+        out[k] = ast.literal_eval(v.strip())
+    return out
+
+
+DEFAULT_PLAN = KernelPlan(**_env_overrides())
 _tls = threading.local()
 
 

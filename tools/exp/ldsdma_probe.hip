@@ -18,7 +18,7 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, int PAT = 0>
 __global__ __launch_bounds__(512) void probe(const unsigned char* src, unsigned long long win, unsigned long long stride_blk,
                                              int iters, unsigned* sink, unsigned long long* cycles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -28,10 +28,20 @@ __global__ __launch_bounds__(512) void probe(const unsigned char* src, unsigned 
   const unsigned char* base = src + (unsigned long long)(stride_blk ? blockIdx.x : (blockIdx.x & 7)) * (stride_blk ? stride_blk : win);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)win, 0x00020000);
   unsigned char* my = smem + wave * (DEPTH * 1024);
-  const unsigned voff = lane * 16;
+  // PAT (mode 0): per-lane source pattern.  0: lane * 16 (1 KB contiguous).  1 / 2: the fused SPADE kernel's piece -- 8 rows x
+  // 64 B from each of two slabs half a window apart, lane -> (row l / 8, chunk cc = (l % 8) ^ ((row / 2) % 8)); 1 = the round-3/4
+  // assignment cc = 4 term + 2 slab + o (a quad of lanes straddles both slabs), 2 = round 5's cc = 4 slab + 2 term + o (a quad
+  // reads the 64 contiguous bytes of one row of one slab, permuted).
+  unsigned voff = lane * 16;
+  if constexpr (PAT != 0) {
+    const int row = lane >> 3, cc = (lane & 7) ^ (((8 * wave + row) >> 1) & 7);
+    const int slab = PAT == 1 ? ((cc >> 1) & 1) : (cc >> 2);
+    const int within = PAT == 1 ? (2 * (cc >> 2) + (cc & 1)) : (cc & 3);
+    voff = (unsigned)(row * 64 + within * 16) + (unsigned)slab * (unsigned)(win >> 1);
+  }
   u32x4 acc = {0, 0, 0, 0};
   u32x4 r[DEPTH];
-  const unsigned npieces = (unsigned)(win / 1024);
+  const unsigned npieces = (unsigned)(win / 1024);   // (PAT: a piece is 512 B in each half of the window)
   unsigned p = wave;   // wave w takes pieces w, w + nw, ...
   if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
@@ -42,7 +52,7 @@ __global__ __launch_bounds__(512) void probe(const unsigned char* src, unsigned 
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      const unsigned so = p * 1024u;
+      const unsigned so = PAT ? p * 512u : p * 1024u;
       p += nw;
       if (p >= npieces) p -= npieces;
       if constexpr (MODE == 0 || MODE == 3) {
@@ -72,19 +82,19 @@ __global__ __launch_bounds__(512) void probe(const unsigned char* src, unsigned 
   if (tid == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, int PAT = 0>
 static void run(const char* what, int waves, const unsigned char* src, size_t win, size_t stride, int iters, unsigned* sink,
                 unsigned long long* cyc) {
   const int blocks = 256;
   const size_t lds = 160 * 1024;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE, DEPTH, PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(a);
-    probe<MODE, DEPTH><<<blocks, waves * 64, lds>>>(src, win, stride, iters, sink, cyc);
+    probe<MODE, DEPTH, PAT><<<blocks, waves * 64, lds>>>(src, win, stride, iters, sink, cyc);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -112,6 +122,18 @@ int main() {
   hipMalloc(&sink, 4);
   hipMalloc(&cyc, 256 * 8);
   const int it = 2000;
+  if (getenv("PROBE_PATTERNS")) {   // round 5: does the lane -> address assignment change what the path delivers?
+    for (int waves : {4, 8})
+      for (size_t win : {(size_t)256 << 10, (size_t)2 << 20}) {
+        run<0, 4, 0>("lds-dma, 1 KB contiguous", waves, src, win, 0, it, sink, cyc);
+        run<0, 4, 1>("lds-dma, fused piece r3/r4 (quad straddles slabs)", waves, src, win, 0, it, sink, cyc);
+        run<0, 4, 2>("lds-dma, fused piece r5 (quad = 64 B)", waves, src, win, 0, it, sink, cyc);
+        run<0, 8, 0>("lds-dma, 1 KB contiguous", waves, src, win, 0, it, sink, cyc);
+        run<0, 8, 1>("lds-dma, fused piece r3/r4 (quad straddles slabs)", waves, src, win, 0, it, sink, cyc);
+        run<0, 8, 2>("lds-dma, fused piece r5 (quad = 64 B)", waves, src, win, 0, it, sink, cyc);
+      }
+    return 0;
+  }
   for (int waves : {4, 8}) {
     for (size_t win : {(size_t)256 << 10, (size_t)2 << 20}) {
       run<0, 4>("lds-dma", waves, src, win, 0, it, sink, cyc);
