@@ -67,6 +67,15 @@ class TrainerManager(BaseManager):
     the whole step, bit-identical results) but is OFF by default: capturing RCCL operations aborts intermittently inside the
     HIP runtime on this stack (tests/test_gpu_model.py::test_dp_collectives_captured_inside_the_graph_world1)."""
 
+    _live = None      # weak set of the managers of this process (close_all(): a host that builds many of them, a test suite)
+
+    @classmethod
+    def close_all(cls):
+        """close() every live manager of this process: captured graphs and their memory pools, static input buffers and the
+        C-ABI communicators are released now instead of whenever the garbage collector gets to them."""
+        for tm in list(cls._live):
+            tm.close()
+
     def __init__(self, opt):
         super().__init__(opt, create_model=True)
         assert opt.isTrain
@@ -88,6 +97,7 @@ class TrainerManager(BaseManager):
         import weakref
         ref = weakref.ref(self)
         atexit.register(lambda: ref() is not None and ref().close())
+        TrainerManager._live.add(self)
 
     def get_logs(self):
         return {**self.logs, **self.sr_model_on_one_gpu.get_logs()}
@@ -307,3 +317,8 @@ class TrainerManager(BaseManager):
                 g["lr"] = new_lr_g
             print("update learning rate: %f -> %f" % (self.old_lr, new_lr))
             self.old_lr = new_lr
+
+
+import weakref as _weakref
+
+TrainerManager._live = _weakref.WeakSet()

@@ -640,6 +640,28 @@ int dsee_comm_broadcast(void* comm, void* buf, long nbytes, int root, hipStream_
 int dsee_comm_allgather(void* comm, const void* send, void* recv, long nbytes_per_rank, hipStream_t stream);
 int dsee_comm_destroy(void* comm);
 
+/* ---- coarse entry points: whole-block ops for a host without the Python orchestration (deepsee_amd/csrc/coarse.cpp) --------
+ * dsee_sean_norm_fwd = ONE SPADE / SEAN normalisation + LeakyReLU of a SPADEResnetBlock, forward (normalization.py:107-120
+ * SPADE when table == NULL, :167-213 SEAN with the style half as per-image tables; architecture.py:92,114), i.e. what
+ * deepsee_amd/ops.py::SeanNormTable.forward enqueues on the fused fp32 path, bit-identical to it:
+ *   actv = ReLU(mlp_shared(one-hot(labels)))           dsee_onehot_conv3x3_pack / _fwd (+ the 32 one-hot channels with a table)
+ *   mean, invstd (training: batch statistics, running statistics updated; else from the running statistics)
+ *   V2 = split F(4x4,3x3) transform of [actv | one-hot], U2 = transform of the packed gamma|beta weights (+ per-image tables)
+ *   h = LeakyReLU((x - mean) invstd (gamma + add_one) + beta)     dsee_spade_fused_fwd: one kernel, M never reaches HBM
+ * labels uint8 [N][lab_h][lab_w], read at stride 2^shift (lab_h >> shift == H); w_shared [128][label_nc][3][3], b_shared [128];
+ * w2a [2C][128][3][3] and bias_packed [2C] in the packed gamma|beta row order of dsee_sean_pack_fwd; table [N][9][2C][32] or
+ * NULL; x, out_h [N][H][W][C]; out_scale (saved modulation factor), sign_mask ([C/32][N*H*W] words), amax_h (2048 floats,
+ * zeroed by the caller: receives max |h|) are optional; mean / invstd [C] are outputs.  C % 32 == 0, (H/4)*(W/4) % 64 == 0.
+ * The workspace (dsee_sean_norm_fwd_workspace bytes, caller-owned, 256-byte aligned) holds the embedding, the statistics
+ * partials, V2, U2 and three operand maxima; nothing is allocated and the stream is never synchronised. */
+size_t dsee_sean_norm_fwd_workspace(int N, int H, int W, int C, int label_nc, int has_table);
+int dsee_sean_norm_fwd(const uint8_t* labels, int lab_h, int lab_w, int shift, int label_nc, const float* w_shared,
+                       const float* b_shared, const float* w2a, const float* table, const float* bias_packed, const float* x,
+                       float* running_mean, float* running_var, int training, float eps, float momentum, float add_one,
+                       float slope, float* out_h, float* out_scale, uint32_t* sign_mask, float* mean, float* invstd,
+                       float* amax_h, int N, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                       hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,3 +15,21 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _release_device_state(request):
+    """GPU tests build dozens of TrainerManagers, each with captured hipGraphs, a private graph memory pool and static input
+    buffers: release them when the test that made them ends (DSEE_TEST_KEEP_MANAGERS=1 keeps the old behaviour: whenever the
+    garbage collector gets to them), so that the suite's device state does not grow with the number of tests run before."""
+    yield
+    if request.node.get_closest_marker("gpu") is None or os.environ.get("DSEE_TEST_KEEP_MANAGERS") == "1":
+        return
+    import gc
+    import torch
+    from deepsee_amd.managers import TrainerManager
+    TrainerManager.close_all()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()

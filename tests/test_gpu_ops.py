@@ -750,3 +750,69 @@ def test_rccl_communicator_behind_the_c_abi_world1():
             p.kill()
     assert ok
     assert rc != 0 and "root" in msg
+
+
+@pytest.mark.parametrize("kind", ["sean", "spade"])
+def test_coarse_sean_norm_fwd_is_the_autograd_path(kind):
+    """dsee_sean_norm_fwd (include/deepsee_hip.h, coarse entry points): ONE C call = the whole SPADE / SEAN normalisation
+    forward + LeakyReLU (embedding, batch statistics, operand transforms, fused gamma/beta kernel) from raw tensors in a
+    caller-owned workspace -- what a host without deepsee_amd/ops.py would call.  Fed with the very tensors
+    SeanNormTable.forward receives inside the module's forward, it must reproduce that forward bit for bit (h, the saved
+    modulation factor, mean / invstd, the updated running statistics), training and evaluation mode."""
+    import ctypes as C
+    from deepsee_amd import ops, lib as L, networks as Nw
+    N, Cc, R, Lc, S, H = 2, 64, 32, 19, 128, 64
+    g = gen(77)
+    label = F.interpolate(torch.randint(0, Lc, (N, 1, 8, 8), generator=g).float(), size=(H, H), mode="nearest")
+    style = (torch.rand(N, Lc, S, generator=g) * 2 - 1).cuda()
+    x = nhwc(torch.randn(N, Cc, R, R, generator=g) * 1.5 + 0.3)
+    mod = Nw.SpadeNorm(kind, Cc, Lc, S, 256)
+    mod.load_state_dict({k: O.recipe_tensor("coarse_" + kind, k, v.shape, 1.0) for k, v in mod.state_dict().items()})
+    mod.cuda()
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
+    assert ops._fused_norm_ok(N, R, R, Cc, 2 * Cc, 160 if kind == "sean" else 128)
+    for training in (True, False):
+        seen = {}
+        orig = ops.SeanNormTable._forward
+
+        def spy(ctx, x_, w_sh, b_sh, w2a, table, b2, rm, rv, labels_, shift, training_, add_one, grad_sink=None, cat_ups=0):
+            seen.update(w_sh=w_sh, b_sh=b_sh, w2a=w2a.contiguous(), table=None if table is None else table.contiguous(),
+                        b2=b2.contiguous(), rm=rm.clone(), rv=rv.clone(), shift=shift, add_one=add_one)
+            return orig(ctx, x_, w_sh, b_sh, w2a, table, b2, rm, rv, labels_, shift, training_, add_one, grad_sink, cat_ups)
+
+        call = L.call
+
+        def call_spy(name, *a):
+            if name == "spade_fused_fwd":     # (V2, U2, amax_cat, v_bound, amax_u, bias, x, mean, invstd, h, scale, ...)
+                seen.update(mean=a[7], invstd=a[8], scale=a[10])
+            return call(name, *a)
+
+        ops.SeanNormTable._forward = staticmethod(spy)
+        L.call = call_spy
+        try:
+            h = mod(x.clone().requires_grad_(), labels, style if kind == "sean" else None, training)
+        finally:
+            ops.SeanNormTable._forward = staticmethod(orig)
+            L.call = call
+        assert "scale" in seen, "the module's forward did not take the fused kernel"
+        st = mod.param_free_norm
+        has_t = seen["table"] is not None
+        assert has_t == (kind == "sean")
+        nbytes = L.lib().dsee_sean_norm_fwd_workspace(N, R, R, Cc, Lc, int(has_t))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        out, scale = torch.empty_like(x), torch.empty_like(x)
+        mean, invstd, hm = ops.new(Cc), ops.new(Cc), torch.zeros(2048, device="cuda")
+        rm, rv = seen["rm"].clone(), seen["rv"].clone()
+        L.call("sean_norm_fwd", labels.t, labels.h, labels.w, seen["shift"], Lc, seen["w_sh"].contiguous(),
+               seen["b_sh"].contiguous(), seen["w2a"], seen["table"], seen["b2"], x, rm, rv, int(training), 1e-5, 0.1,
+               float(seen["add_one"]), 0.2, out, scale, None, mean, invstd, hm, N, R, R, Cc, ws, nbytes)
+        torch.cuda.synchronize()
+        assert torch.equal(out, h.detach()), (kind, training, rel(out.cpu(), h.detach().cpu()))
+        assert torch.equal(scale, seen["scale"]) and torch.equal(mean, seen["mean"]) and torch.equal(invstd, seen["invstd"])
+        assert torch.equal(rm, st.running_mean) and torch.equal(rv, st.running_var)
+        assert float(hm.max()) == float(out.abs().max())
+    # the argument checks answer with DSEE_EINVAL and a message instead of launching anything
+    with pytest.raises(L.DseeError, match="workspace"):
+        L.call("sean_norm_fwd", labels.t, labels.h, labels.w, seen["shift"], Lc, seen["w_sh"].contiguous(),
+               seen["b_sh"].contiguous(), seen["w2a"], seen["table"], seen["b2"], x, rm, rv, 1, 1e-5, 0.1, 1.0, 0.2, out, None,
+               None, mean, invstd, None, N, R, R, Cc, ws, 1024)
