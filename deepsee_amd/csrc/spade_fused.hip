@@ -49,6 +49,12 @@
 #define DSEE_FUSED_SCHED 0
 #endif
 
+// Which form of the kernel a launch takes unless the environment says otherwise (DSEE_FUSED_W16): 0 = 8 waves of 256
+// registers, 1 = 16 waves of 128 (round 5, see spade_fused_fwd16_kernel).
+#ifndef DSEE_FUSED_W16_DEFAULT
+#define DSEE_FUSED_W16_DEFAULT 0
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -661,6 +667,361 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The 16-wave form (round 5).  Cycle stamps of the 8-wave kernel above (DSEE_FUSED_ABL & 32, tools/exp/fused_phases.py): a wave
+// spends about a quarter of a block each in fragment reads (34.8 k cycles: exactly the time the LDS array needs for ALL eight
+// waves' reads, 8.6 MB at 256 B/clk), LDS-DMA requests (31.1 k: the texture addresser takes 64 B/clk), fold / Y update (32.0 k)
+// and MFMAs (33.5 k), and 3 k waiting for its own requests to land: every phase saturates a pipe the waves share while it
+// runs, and with two in-order waves per SIMD at most two phases overlap -- the block takes ~140 k cycles against 46 - 57 k of
+// the busiest pipe.  Here the same 64 tile x 64 row block is owned by SIXTEEN waves of 128 registers, four per SIMD: a wave
+// owns ONE 16 x 16 block (16 gamma rows or the 16 beta rows of the same channels, 16 tiles): Y = 16 outputs x 4 = 64 AGPRs,
+// T = 16 registers, one MFMA accumulator, one set of four fragments; it issues ONE LDS-DMA instruction per piece (waves 0-7 the
+// U rows, 8-15 the V rows) instead of two.  Fragment reads per piece go from 48 to 64 KB per CU (a fragment is shared by fewer
+// blocks of the same wave); ring, swizzle, stage structure, fold, epilogue arithmetic and output bits are unchanged.
+template <int NP, bool WSCALE, bool PK = false, int RD = 2>
+__global__ __launch_bounds__(1024) void spade_fused_fwd16_kernel(FusedArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int PIECE = 8192;
+  constexpr int UREG = RD * NP * PIECE;
+  static_assert(RD == 2 || RD == 3, "a row of 6 positions is a whole number of ring turns");
+  static_assert(2 * UREG <= 160 * 1024 && 2 * UREG >= 65536, "ring fits the LDS and covers the epilogue's 64 KB");
+  static_assert(PK ? (NP == 2 || NP == 3) : (NP == 4 || NP == 5), "K = 128 or 160");
+  constexpr bool HALF_LAST = PK && NP == 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wb = wave >> 2, wt = wave & 3;     // row block (0, 1: gamma of channels 0-15 / 16-31; 2, 3: beta), tile quarter
+  const int wq = wb & 1;
+  const bool is_beta = wb >= 2;
+
+  const int rgn = a.rows >> 6;
+  const long tgn = a.T >> 6, ntile = tgn * rgn;
+  long l;
+  {
+    const long v = blockIdx.x, q = ntile >> 3, r = ntile & 7, xcd = v & 7, idx = v >> 3;
+    l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  long tg;
+  int rg;
+  if ((rgn & 7) == 0 && (tgn & 3) == 0) {
+    const long sup = l >> 5;
+    const int in = (int)(l & 31), rh = rgn >> 3;
+    tg = (sup / rh) * 4 + (in >> 3);
+    rg = (int)(sup % rh) * 8 + (in & 7);
+  } else {
+    tg = l / rgn;
+    rg = (int)(l % rgn);
+  }
+  const long t0 = tg * 64;
+  const int n = (int)(t0 / a.tpi);
+  const int g = a.G > 1 ? n : 0;
+
+  const float sv = dsee_pow2_scale(a.v_bound * dsee_amax_read(a.amax_v));
+  const float su = dsee_pow2_scale(dsee_amax_read(a.amax_u));
+  const float oscale = 1.f / (sv * su);
+
+  // ---- LDS-DMA: waves 0-7 fill the U pieces, 8-15 the V pieces, rows 8 (w % 8) .. + 7 of every piece (chunk assignment as above)
+  const bool dma_v = wave >= 8;
+  const int dw = wave & 7;
+  const int dr = 8 * dw + (lane >> 3);
+  const int dcc = (lane & 7) ^ ((dr >> 1) & 7);
+  const int dslab = dcc >> 2;
+  const unsigned dlo = (unsigned)(dr * 64 + (dcc & 3) * 16);
+  const unsigned slab_bytes = (unsigned)(dma_v ? a.v_slab_bytes : a.u_slab_bytes);
+  const unsigned voff = dlo + (unsigned)dslab * slab_bytes;
+  const unsigned voff_l = dslab ? 0xFFFFFFF0u : voff;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)uniform_ptr(dma_v ? a.V2 : a.U2), 0, (int)(dma_v ? a.v_bytes : a.u_bytes), 0x00020000);
+  const unsigned PP_ = dma_v ? (unsigned)(a.T * 64) : (unsigned)(a.G * a.u_group_bytes);   // per position
+  const unsigned QQ_ = 2 * slab_bytes;                                                      // per piece
+  const unsigned base_o = dma_v ? (unsigned)(t0 * 64) : (unsigned)((long)g * a.u_group_bytes + (long)rg * 4096);
+  unsigned char* const dbase = smem + (dma_v ? UREG : 0) + dw * 1024;
+  auto dma = [&](int par, int pc, unsigned opos) {
+    unsigned char* dst = dbase + (par * NP + pc) * PIECE;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16,
+                                             (HALF_LAST && pc == NP - 1) ? voff_l : voff, opos + pc * QQ_, 0, 0);
+  };
+
+  // ---- fragment addresses
+  const int fi = lane & 15, oc = lane >> 4;
+  auto foff = [&](int r, int t) {
+    const int chunk = PK ? 4 * t + oc : 4 * (oc >> 1) + 2 * t + (oc & 1);
+    return (unsigned)((8 * r + (chunk ^ ((r >> 1) & 7))) * 16);
+  };
+  const int rga = 16 * wb + fi, rtv = 16 * wt + fi;
+  const unsigned au0 = foff(rga, 0), au1 = foff(rga, 1);
+  const unsigned av0 = UREG + foff(rtv, 0), av1 = UREG + foff(rtv, 1);
+  struct Frag {
+    u32x4 a0, a1, v0, v1;
+  };
+  auto ldf = [&](Frag& f, auto par_c, auto pc_c) {
+    constexpr int so = (decltype(par_c)::value * NP + decltype(pc_c)::value) * PIECE;
+    constexpr bool hi = so >= 7 * PIECE;
+    constexpr int io = hi ? so - 7 * PIECE : so;
+    static_assert(io >= 0 && io + PIECE <= 65536, "window");
+    // (the second window's base is formed where it is used: one VALU add instead of four more live registers)
+    const unsigned w0 = hi ? 7 * PIECE : 0;
+    f.a0 = *reinterpret_cast<const u32x4*>(smem + (au0 + w0) + io);
+    f.a1 = *reinterpret_cast<const u32x4*>(smem + (au1 + w0) + io);
+    f.v0 = *reinterpret_cast<const u32x4*>(smem + (av0 + w0) + io);
+    f.v1 = *reinterpret_cast<const u32x4*>(smem + (av1 + w0) + io);
+  };
+  auto mm = [&](const Frag& f, f32x4& p) {
+    const f16x8 a0 = __builtin_bit_cast(f16x8, f.a0), a1 = __builtin_bit_cast(f16x8, f.a1);
+    const f16x8 v0 = __builtin_bit_cast(f16x8, f.v0), v1 = __builtin_bit_cast(f16x8, f.v1);
+    if constexpr (PK) {
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, v0, p, 0, 0, 0);
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, v1, p, 0, 0, 0);
+    } else {
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, v0, p, 0, 0, 0);
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, v1, p, 0, 0, 0);
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, v0, p, 0, 0, 0);
+    }
+  };
+
+  float Y[4][4][4];      // [output row i][output column j][4 channels]: 64 AGPRs
+  f32x4 T[4], P;
+  Frag F;
+  static_for<4>([&](auto i) {
+    static_for<4>([&](auto j) {
+      static_for<4>([&](auto e) {
+        float& yr = Y[decltype(i)::value][decltype(j)::value][decltype(e)::value];
+        asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(yr));
+      });
+    });
+  });
+#pragma unroll
+  for (int j = 0; j < 4; ++j) T[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NA = NP == 2 ? 1 : 2;
+  auto issue_stage = [&](int pos, int half) {
+    for (int k = half ? NA : 0; k < (half ? NP : NA); ++k) dma(pos % RD, k, base_o + pos * PP_);
+  };
+  for (int st = 0; st < 2 * RD - 1; ++st) issue_stage(st >> 1, st & 1);
+  // (stage 0 is waited for by the first position's own vmcnt + barrier)
+
+  auto y_update = [&](auto lo_c, auto hi_c, const float (&cf)[4]) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    static_for<HI - LO>([&](auto d) {
+      constexpr int ij = LO + decltype(d)::value, i = ij >> 2, j = ij & 3;
+      static_for<4>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        float y;
+        float& yr = Y[i][j][e];
+        const float cc = cf[i], tt = T[j][e];
+        asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_fmac_f32 %1, %2, %3\n\tv_accvgpr_write_b32 %0, %1"
+                     : "+a"(yr), "=&v"(y)
+                     : "s"(cc), "v"(tt));
+      });
+    });
+  };
+
+  auto position = [&](int pos, auto par_c, auto pp_c, auto&& fill) {
+    constexpr int PAR = decltype(par_c)::value;
+    P = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_for<2>([&](auto half_c) {
+      constexpr int half = decltype(half_c)::value;
+      const int pl = min(pos + RD - 1 + half, 35);
+      const unsigned oo = base_o + pl * PP_;
+      constexpr int LPAR = half ? PAR : (PAR + RD - 1) % RD;
+      constexpr int L0 = half ? 0 : NA, L1 = half ? NA : NP;
+      constexpr int C0 = half ? NA : 0, C1 = half ? NP : NA;
+      // stage s itself has landed (this wave's rows) when only the requests of the 2 RD - 2 younger stages -- RD - 1 whole
+      // positions -- are still in flight: its fragments are read after the barrier, none of the next stage's before the next one
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 1) * NP) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      static_for<C1 - C0>([&](auto p_c) {
+        constexpr int p = decltype(p_c)::value, k = C0 + p;
+        __builtin_amdgcn_sched_barrier(0);
+        // this piece's fragments (one set: with four waves per SIMD another wave's MFMAs cover their LDS latency), this piece's
+        // share of the look-ahead requests and of the fold work while they travel, then the MFMAs
+        ldf(F, ic<PAR>{}, ic<k>{});
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int a0 = L0 + p * (L1 - L0) / (C1 - C0), a1 = L0 + (p + 1) * (L1 - L0) / (C1 - C0);
+        static_for<a1 - a0>([&](auto d) { dma(LPAR, a0 + decltype(d)::value, oo); });
+        fill(ic<k>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm(F, P);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+  auto fold = [&](auto cp_c, const f32x4& m) {
+    constexpr int CP = decltype(cp_c)::value;
+    if constexpr (CP == 0) {
+      T[0] += m;
+    } else if constexpr (CP == 1) {
+      T[0] += m; T[1] += m; T[2] += m; T[3] += m;
+    } else if constexpr (CP == 2) {
+      T[0] += m; T[1] -= m; T[2] += m; T[3] -= m;
+    } else if constexpr (CP == 3) {
+      T[0] += m; T[1] += 2.f * m; T[2] += 4.f * m; T[3] += 8.f * m;
+    } else if constexpr (CP == 4) {
+      T[0] += m; T[1] -= 2.f * m; T[2] += 4.f * m; T[3] -= 8.f * m;
+    } else {
+      T[3] += m;
+    }
+  };
+
+#pragma unroll 1
+  for (int r = 0; r < 6; ++r) {
+    const int q = r - 1;
+    const float cf[4] = {q < 0 ? 0.f : 1.f, q <= 0 ? 0.f : (q == 1 ? 1.f : (q == 2 ? -1.f : (q == 3 ? 2.f : -2.f))),
+                         q <= 0 ? 0.f : (q < 3 ? 1.f : 4.f),
+                         q <= 0 ? 0.f : (q == 1 ? 1.f : (q == 2 ? -1.f : (q == 3 ? 8.f : -8.f)))};
+    position(r * 6, ic<0>{}, ic<0>{}, [&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      if constexpr (k >= 1) {
+        constexpr int NY = NP - 1, qq = k - 1, LO = qq * 16 / NY, HI = (qq + 1) * 16 / NY;
+        if constexpr (NP == 5) {
+          if (q > 0 || (q == 0 && qq == 0)) y_update(ic<LO>{}, ic<HI>{}, cf);
+        } else {
+          if (q >= 0) y_update(ic<LO>{}, ic<HI>{}, cf);
+        }
+        if constexpr (k == NP - 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) T[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    });
+    fold(ic<0>{}, P);
+#define DSEE_POS16(C)                                                  \
+  position(r * 6 + C, ic<C % RD>{}, ic<C % 2>{}, [&](auto) {});        \
+  fold(ic<C>{}, P);
+    DSEE_POS16(1)
+    DSEE_POS16(2)
+    DSEE_POS16(3)
+    DSEE_POS16(4)
+    DSEE_POS16(5)
+#undef DSEE_POS16
+  }
+
+  // ---- epilogue (as above, 1024 threads: 2 items per thread and pixel row)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int chunk_r = tid & 7;
+  const int cq = rg * 32 + chunk_r * 4;
+  unsigned boff[2];
+  f32x4 xr[4][2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int px = it * 128 + (tid >> 3);
+    const int tl = px >> 2, j = px & 3;
+    const int tin = (int)(t0 + tl - (long)n * a.tpi);
+    const int ty = tin / a.tw, tx = tin - ty * a.tw;
+    boff[it] = ((unsigned)((n * a.H + ty * 4) * a.W + tx * 4 + j) * (unsigned)a.C + (unsigned)cq) * 4u;
+  }
+  const unsigned np = (unsigned)(a.T * 16);
+  const unsigned rowbytes = (unsigned)(a.W * a.C) * 4u;
+  const char* const xb = reinterpret_cast<const char*>(a.x);
+  char* const ob = reinterpret_cast<char*>(a.out);
+  char* const sb = reinterpret_cast<char*>(a.scale);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      xr[k][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (boff[it] + k * rowbytes)));
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const float cf[4] = {0.f, 0.f, 0.f, 1.f};
+    y_update(ic<12>{}, ic<16>{}, cf);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float* const Gs = reinterpret_cast<float*>(smem);
+  float* const Bs = reinterpret_cast<float*>(smem + 32768);
+  float* const Ws = is_beta ? Bs : Gs;                    // this wave's half of the exchange
+  const int tl_w = 16 * wt + fi;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + cq), is = *reinterpret_cast<const f32x4*>(a.invstd + cq);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bg = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + rg * 64 + chunk_r * 4) : z4;
+  const f32x4 bb = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + rg * 64 + 32 + chunk_r * 4) : z4;
+  const int chw = ((wq * 4 + oc) ^ (tl_w & 7)) * 4;
+  float hmax = 0.f, xmax = 0.f;
+  static_for<4>([&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    static_for<4>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      const int px = tl_w * 4 + j;
+      f32x4 yv;
+      static_for<4>([&](auto e_c) {
+        constexpr int e = decltype(e_c)::value;
+        float y;
+        float& r_ = Y[k][j][e];
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y) : "a"(r_));
+        yv[e] = y;
+      });
+      *reinterpret_cast<f32x4*>(Ws + px * 32 + chw) = yv;
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int px = it * 128 + (tid >> 3);
+      const int tl = px >> 2;
+      unsigned off = boff[it];
+      asm volatile("" : "+v"(off));
+      off += k * rowbytes;
+      const int ch = (chunk_r ^ (tl & 7)) * 4;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(Gs + px * 32 + ch);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + px * 32 + ch);
+      const f32x4 xh = (xr[k][it] - mu) * is;
+      const f32x4 sc = gv * oscale + bg + a.add_one;
+      if constexpr (WSCALE && PK) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 sh = {(_Float16)sc[0], (_Float16)sc[1], (_Float16)sc[2], (_Float16)sc[3]};
+        __builtin_nontemporal_store(sh, reinterpret_cast<f16x4*>(sb + (off >> 1)));
+      } else if constexpr (WSCALE) {
+        __builtin_nontemporal_store(sc, reinterpret_cast<f32x4*>(sb + off));
+      }
+      f32x4 v = (xh * sc + bb) + bv * oscale;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ob + off));
+      if constexpr (WSCALE) {
+        const int pl = (tid >> 3) & 7;
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned long long b = __builtin_amdgcn_ballot_w64(v[e] > 0.f);
+          const unsigned half = (pl & 4) ? (unsigned)(b >> 32) : (unsigned)b;
+          m |= __builtin_amdgcn_ubfe(half, 8 * (pl & 3), 8) << (8 * e);
+        }
+        if (chunk_r == 0 && a.mask) a.mask[rg * np + (off >> a.cshift)] = m;
+      }
+      hmax = fmaxf(hmax, dsee_absmax4(v));
+      xmax = fmaxf(xmax, dsee_absmax4(xh));
+    }
+    if constexpr (k < 3) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  });
+  if (a.amax_h) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
+    if (lane == 0) {
+      unsigned* line = reinterpret_cast<unsigned*>(a.amax_h + ((blockIdx.x * 16 + wave) & (DSEE_AMAX_LINES - 1)) * DSEE_AMAX_STRIDE);
+      const unsigned bits = __builtin_bit_cast(unsigned, hmax);
+      if (bits > __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(line, bits);
+    }
+  }
+  if (a.amax_xhat) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+    if (lane == 0) {
+      unsigned* line = reinterpret_cast<unsigned*>(a.amax_xhat + ((blockIdx.x * 16 + wave) & (DSEE_AMAX_LINES - 1)) * DSEE_AMAX_STRIDE);
+      const unsigned bits = __builtin_bit_cast(unsigned, xmax);
+      if (bits > __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(line, bits);
+    }
+  }
+#endif
+}
+
 }  // namespace
 
 static float* g_fused_stamps = nullptr;
@@ -729,11 +1090,14 @@ static int spade_fused_launch(bool packed, const void* V2, const void* U2, const
   const int np = packed ? (K + 63) / 64 : K / 32;
   const int rd = packed ? 3 : 2;               // ring depth in positions (see the kernel): the packed operands are half the bytes
   const size_t lds = (size_t)rd * np * 16384;  // ring of rd positions: rd * NP pieces of U and of V, 8 KB each
-#define DSEE_FUSED(NP, WS, PKD)                                                                                      \
+  // DSEE_FUSED_W16 = 1 / 0 selects the 16-wave / 8-wave form (default: DSEE_FUSED_W16_DEFAULT)
+  const char* const w16_env = getenv("DSEE_FUSED_W16");      // (read per launch: a test can flip it inside one process)
+  const int w16 = w16_env ? atoi(w16_env) : DSEE_FUSED_W16_DEFAULT;
+#define DSEE_FUSED_K(KERNEL, THREADS, NP, WS, PKD)                                                                   \
   do {                                                                                                               \
     static bool attr_done = false;                                                                                   \
     if (!attr_done) {                                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_fwd_kernel<NP, WS, PKD, (PKD ? 3 : 2)>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<NP, WS, PKD, (PKD ? 3 : 2)>),         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e != hipSuccess) {                                                                                         \
         dsee_set_error("hipFuncSetAttribute(%zu bytes of LDS): %s", lds, hipGetErrorString(e));                     \
@@ -741,7 +1105,14 @@ static int spade_fused_launch(bool packed, const void* V2, const void* U2, const
       }                                                                                                              \
       attr_done = true;                                                                                              \
     }                                                                                                                \
-    spade_fused_fwd_kernel<NP, WS, PKD, (PKD ? 3 : 2)><<<(int)ntile, 512, lds, st>>>(a);                             \
+    KERNEL<NP, WS, PKD, (PKD ? 3 : 2)><<<(int)ntile, THREADS, lds, st>>>(a);                                         \
+  } while (0)
+#define DSEE_FUSED(NP, WS, PKD)                                                                                      \
+  do {                                                                                                               \
+    if (w16)                                                                                                         \
+      DSEE_FUSED_K(spade_fused_fwd16_kernel, 1024, NP, WS, PKD);                                                     \
+    else                                                                                                             \
+      DSEE_FUSED_K(spade_fused_fwd_kernel, 512, NP, WS, PKD);                                                        \
   } while (0)
   if (packed) {
     if (np == 3) {
@@ -755,6 +1126,7 @@ static int spade_fused_launch(bool packed, const void* V2, const void* U2, const
     if (out_scale) DSEE_FUSED(4, true, false); else DSEE_FUSED(4, false, false);
   }
 #undef DSEE_FUSED
+#undef DSEE_FUSED_K
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

@@ -26,10 +26,14 @@ def _release_device_state(request):
     if request.node.get_closest_marker("gpu") is None or os.environ.get("DSEE_TEST_KEEP_MANAGERS") == "1":
         return
     import gc
-    import torch
     from deepsee_amd.managers import TrainerManager
     TrainerManager.close_all()
     gc.collect()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+
+
+def pytest_runtest_logreport(report):
+    """DSEE_TEST_DURATIONS=<file>: one line per finished test phase (a crash of the interpreter loses --durations)."""
+    path = os.environ.get("DSEE_TEST_DURATIONS")
+    if path and report.when == "call":
+        with open(path, "a") as f:
+            f.write("%8.2f  %s  %s\n" % (report.duration, report.outcome, report.nodeid))

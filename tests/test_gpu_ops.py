@@ -761,7 +761,7 @@ def test_coarse_sean_norm_fwd_is_the_autograd_path(kind):
     modulation factor, mean / invstd, the updated running statistics), training and evaluation mode."""
     import ctypes as C
     from deepsee_amd import ops, lib as L, networks as Nw
-    N, Cc, R, Lc, S, H = 2, 64, 32, 19, 128, 64
+    N, Cc, R, Lc, S, H = 2, 64, 64, 19, 128, 128      # (per-image tables: whole 128-tile GEMM tiles per image)
     g = gen(77)
     label = F.interpolate(torch.randint(0, Lc, (N, 1, 8, 8), generator=g).float(), size=(H, H), mode="nearest")
     style = (torch.rand(N, Lc, S, generator=g) * 2 - 1).cuda()
