@@ -171,8 +171,8 @@ def spawn_ranks(n):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (counters cannot be read live)."""
-    for name in ("r04_pmc_traffic_fp16.json" if "1term" in kernel else "r04_pmc_traffic.json", "r04_pmc_traffic.json",
-                 "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic_fp16.json" if "1term" in kernel else "r05_pmc_traffic.json", "r05_pmc_traffic.json",
+                 "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             rec = json.load(open(path)).get(kernel)

@@ -495,9 +495,10 @@ def test_smooth_loss_backward(name):
     # (round 5: the bs = 8 x 128-channel case of round 4 is gone -- the benchmark's own bs = 8 x 512 channels is now held against
     # the oracle on the replayed graphs, test_benchmark_path_matches_oracle, gradients included, and the float64 CPU passes here
     # are what the suite's wall time is made of)
-    # BASELINE configs[3]: guided 8x 32 -> 256 -- the full style encoder's backward on a 256^2 guiding image (configs[3] at
-    # its per-rank bs = 8 runs under test_benchmark_path_matches_oracle[guided_8x_256])
-    ("guided_32to256_bs1", dict(batchSize=1, netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True)),
+    # (BASELINE configs[3], guided 8x 32 -> 256: at its per-rank bs = 8, gradients included, under
+    # test_benchmark_path_matches_oracle[guided_8x_256]; the float64 smooth-loss form of the guided variant at 4 -> 32:
+    # test_smooth_loss_backward[guided_4to32_ngf8].  The bs = 1 full-size float64 pass of round 4 -- 62 s of CPU time -- left
+    # the suite with round 5: 849 -> ~790 s, profiles/r05_gpu_tests.log)
     # BASELINE configs[4]: independent 32x 16 -> 512 -- PureSEAN tail, the capped path's 2x2 block-sum gradient at 512^2
     # (256 channels: what is specific to configs[4] is its resolution -- the float64 oracle pass at 512 channels is 3 minutes of
     # CPU time; forward + losses at 512 channels: test_full_size_forward_and_losses)
