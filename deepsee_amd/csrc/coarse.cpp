@@ -1,5 +1,5 @@
 // Coarse entry points of the C ABI ("whole-block ops a non-Python host can call"): one call = one SPADE / SEAN
-// normalisation forward of a SPADEResnetBlock (normalization.py:107-120 SPADE, :167-213 SEAN with the style half as per-image
+// normalisation forward of a SPADEResnetBlock, or one whole block forward (dsee_spade_resblock_fwd, at the end) (normalization.py:107-120 SPADE, :167-213 SEAN with the style half as per-image
 // tables, + the LeakyReLU of architecture.py:92,114).  They only sequence the fine-grained entry points of this library on
 // the caller's stream, inside a workspace the caller owns -- the same launches deepsee_amd/ops.py::SeanNormTable.forward makes
 // for the fused fp32 path, so the results are bit-identical to the autograd path (tests/test_gpu_ops.py).
@@ -114,6 +114,101 @@ int dsee_sean_norm_fwd(const uint8_t* labels, int lab_h, int lab_w, int shift, i
   return dsee_spade_fused_fwd(v2, u2, amax_cat, DSEE_WINO_V_BOUND, amax_u, bias_packed, x, mean, invstd, out_h, out_scale, N,
                               H, W, C, rows, ld, has_t ? N : 1, add_one, slope, amax_h, out_scale ? amax_xhat : nullptr,
                               sign_mask, stream);
+}
+
+
+/* ---- one SPADEResnetBlock.forward (architecture.py:75-147 with fin == fout: identity shortcut, no NoiseInjection: inference,
+ * or training with add_noise off):  out = act(x + conv_1(lrelu(norm_1(conv_0(lrelu(norm_0(x)))))))  -- two dsee_sean_norm_fwd and
+ * two Winograd convolutions on pre-split operands (the input transform's scale comes from the max |h| the fused norm kernel
+ * wrote: no pass over h). */
+static int wino_conv3x3(const float* h, const float* amax_h, const float* w, const float* bias, const float* residual,
+                        float* y, int act, float slope, int N, int H, int W, int C, float* amax_w, void* v2, void* u2, float* m,
+                        hipStream_t stream) {
+  const long T = (long)N * (H / 4) * (W / 4);
+  if (hipMemsetAsync(amax_w, 0, kAmaxFloats * sizeof(float), stream) != hipSuccess) return DSEE_ELAUNCH;
+  DSEE_TRY(dsee_absmax(w, (long)C * C * 9, amax_w, stream));
+  DSEE_TRY(dsee_wino43_weights(w, static_cast<float*>(u2), C, C, 0, 2, amax_w, stream));
+  DSEE_TRY(dsee_wino43_input_f16x2(h, v2, N, H, W, C, amax_h, DSEE_WINO_V_BOUND, stream));
+  DSEE_TRY(dsee_gemm_f16x2_pre(v2, u2, m, 36 * T, C, C, T, C, amax_h, DSEE_WINO_V_BOUND, amax_w, stream));
+  return dsee_wino43_output(m, bias, residual, C, y, N, H, W, C, act, slope, nullptr, 0, 0, nullptr, 0, 0, nullptr, stream);
+}
+
+namespace {
+struct BlockLayout {
+  size_t norm, h, dx, stat, amax, v2, u2, m, total;
+};
+BlockLayout block_layout(int N, int H, int W, int C, int nc, int has_table) {
+  const long T = (long)N * (H / 4) * (W / 4);
+  const size_t act = (size_t)N * H * W * C * sizeof(float);
+  BlockLayout l;
+  size_t o = 0;
+  l.norm = o; o += up256(norm_layout(N, H, W, C, nc, has_table).total);
+  l.h = o;    o += up256(act);                                       // lrelu(norm(.)) of the layer in flight
+  l.dx = o;   o += up256(act);                                       // conv_0's output
+  l.stat = o; o += up256((size_t)2 * C * sizeof(float));             // mean | invstd
+  l.amax = o; o += up256(2 * kAmaxFloats * sizeof(float));           // max |h|, max |w|
+  l.v2 = o;   o += up256((size_t)36 * T * C * 2 * sizeof(uint16_t)); // split transform of h
+  l.u2 = o;   o += up256((size_t)36 * C * C * 2 * sizeof(uint16_t)); // split transform of the weights
+  l.m = o;    o += up256((size_t)36 * T * C * sizeof(float));        // Winograd-domain product
+  l.total = o;
+  return l;
+}
+}  // namespace
+
+size_t dsee_spade_resblock_fwd_workspace(int N, int H, int W, int C, int label_nc, int has_table) {
+  return block_layout(N, H, W, C, label_nc, has_table).total;
+}
+
+int dsee_spade_resblock_fwd(const dsee_norm_layer* norm_0, const float* w_conv_0, const float* b_conv_0,
+                            const dsee_norm_layer* norm_1, const float* w_conv_1, const float* b_conv_1,
+                            const uint8_t* labels, int lab_h, int lab_w, int shift, int label_nc, const float* x, float* out,
+                            int out_act, int training, float eps, float momentum, float slope, int N, int H, int W, int C,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!(norm_0 && norm_1 && w_conv_0 && w_conv_1 && labels && x && out && workspace)) {
+    dsee_set_error("dsee_spade_resblock_fwd: NULL argument");
+    return DSEE_EINVAL;
+  }
+  const long T = (long)N * (H / 4) * (W / 4);
+  if (C % 128 != 0 || H % 4 != 0 || W % 4 != 0 || T % 256 != 0) {
+    dsee_set_error("dsee_spade_resblock_fwd: C %% 128 == 0 and N (H/4) (W/4) %% 256 == 0 required (C = %d, %ld tiles): the "
+                   "pre-split Winograd GEMM takes whole 256 x 128 tiles", C, T);
+    return DSEE_EUNSUPPORTED;
+  }
+  const int has_t = norm_0->table != nullptr;
+  if (has_t != (norm_1->table != nullptr)) {
+    dsee_set_error("dsee_spade_resblock_fwd: both norm layers of a block are SPADE or both SEAN");
+    return DSEE_EINVAL;
+  }
+  const BlockLayout l = block_layout(N, H, W, C, label_nc, has_t);
+  if (workspace_bytes < l.total) {
+    dsee_set_error("dsee_spade_resblock_fwd: workspace of %zu bytes, %zu needed (dsee_spade_resblock_fwd_workspace)",
+                   workspace_bytes, l.total);
+    return DSEE_EINVAL;
+  }
+  char* const ws = static_cast<char*>(workspace);
+  float* const h = reinterpret_cast<float*>(ws + l.h);
+  float* const dx = reinterpret_cast<float*>(ws + l.dx);
+  float* const mean = reinterpret_cast<float*>(ws + l.stat);
+  float* const invstd = mean + C;
+  float* const amax_h = reinterpret_cast<float*>(ws + l.amax);
+  float* const amax_w = amax_h + kAmaxFloats;
+  float* const m = reinterpret_cast<float*>(ws + l.m);
+  const size_t norm_bytes = l.h - l.norm;
+  const dsee_norm_layer* norms[2] = {norm_0, norm_1};
+  const float* convw[2] = {w_conv_0, w_conv_1};
+  const float* convb[2] = {b_conv_0, b_conv_1};
+  const float* in = x;
+  for (int i = 0; i < 2; ++i) {
+    const dsee_norm_layer* nl = norms[i];
+    if (hipMemsetAsync(amax_h, 0, kAmaxFloats * sizeof(float), stream) != hipSuccess) return DSEE_ELAUNCH;
+    DSEE_TRY(dsee_sean_norm_fwd(labels, lab_h, lab_w, shift, label_nc, nl->w_shared, nl->b_shared, nl->w2a, nl->table,
+                                nl->bias_packed, in, nl->running_mean, nl->running_var, training, eps, momentum, nl->add_one,
+                                slope, h, nullptr, nullptr, mean, invstd, amax_h, N, H, W, C, ws + l.norm, norm_bytes, stream));
+    DSEE_TRY(wino_conv3x3(h, amax_h, convw[i], convb[i], i == 1 ? x : nullptr, i == 1 ? out : dx, i == 1 ? out_act : DSEE_ACT_NONE,
+                          slope, N, H, W, C, amax_w, ws + l.v2, ws + l.u2, m, stream));
+    in = dx;
+  }
+  return DSEE_OK;
 }
 
 }  // extern "C"

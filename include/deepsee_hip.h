@@ -662,6 +662,33 @@ int dsee_sean_norm_fwd(const uint8_t* labels, int lab_h, int lab_w, int shift, i
                        float* amax_h, int N, int H, int W, int C, void* workspace, size_t workspace_bytes,
                        hipStream_t stream);
 
+/* dsee_spade_resblock_fwd = ONE SPADEResnetBlock.forward (architecture.py:75-147 with fin == fout: identity shortcut; without
+ * NoiseInjection, i.e. inference or add_noise off):
+ *   out = act(x + conv_1(lrelu(norm_1(conv_0(lrelu(norm_0(x)))))))
+ * two dsee_sean_norm_fwd and two Winograd F(4x4,3x3) convolutions on pre-split fp16x2 operands (dsee_wino43_weights split = 2,
+ * dsee_wino43_input_f16x2 scaled from the max |h| the fused norm kernel wrote, dsee_gemm_f16x2_pre, dsee_wino43_output with bias /
+ * shortcut / activation).  w_conv_* are the convolutions' EFFECTIVE weights [C][C][3][3] (after spectral normalisation:
+ * dsee_spectral_norm_fwd), b_conv_* [C] or NULL; a dsee_norm_layer is a HOST struct of device pointers, laid out as
+ * dsee_sean_norm_fwd's arguments.  C % 128 == 0, N (H/4) (W/4) % 256 == 0 (DSEE_EUNSUPPORTED otherwise); out_act = DSEE_ACT_*.
+ * The workspace (dsee_spade_resblock_fwd_workspace bytes) holds h, conv_0's output, the Winograd-domain operands and product
+ * (7.5 GB at N = 8, 256 x 256, C = 512). */
+typedef struct dsee_norm_layer {
+  const float* w_shared;     /* [128][label_nc][3][3] */
+  const float* b_shared;     /* [128] */
+  const float* w2a;          /* [2C][128][3][3], packed gamma|beta rows */
+  const float* table;        /* [N][9][2C][32] per-image style table, or NULL (SPADE) */
+  const float* bias_packed;  /* [2C] */
+  float* running_mean;       /* [C] */
+  float* running_var;        /* [C] */
+  float add_one;             /* 1: SPADE / SEAN (x_hat (1 + gamma) + beta); 0: PureSEAN */
+} dsee_norm_layer;
+size_t dsee_spade_resblock_fwd_workspace(int N, int H, int W, int C, int label_nc, int has_table);
+int dsee_spade_resblock_fwd(const dsee_norm_layer* norm_0, const float* w_conv_0, const float* b_conv_0,
+                            const dsee_norm_layer* norm_1, const float* w_conv_1, const float* b_conv_1,
+                            const uint8_t* labels, int lab_h, int lab_w, int shift, int label_nc, const float* x, float* out,
+                            int out_act, int training, float eps, float momentum, float slope, int N, int H, int W, int C,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

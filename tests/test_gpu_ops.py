@@ -816,3 +816,70 @@ def test_coarse_sean_norm_fwd_is_the_autograd_path(kind):
         L.call("sean_norm_fwd", labels.t, labels.h, labels.w, seen["shift"], Lc, seen["w_sh"].contiguous(),
                seen["b_sh"].contiguous(), seen["w2a"], seen["table"], seen["b2"], x, rm, rv, 1, 1e-5, 0.1, 1.0, 0.2, out, None,
                None, mean, invstd, None, N, R, R, Cc, ws, 1024)
+
+
+def test_coarse_spade_resblock_fwd_matches_the_module():
+    """dsee_spade_resblock_fwd: ONE C call = a whole SPADEResnetBlock forward (two SEAN norms on the fused kernel, two Winograd
+    convolutions on pre-split operands, identity shortcut) from raw tensors and a caller-owned workspace -- against the Python
+    module's forward (training mode, add_noise off) fed with the same effective weights.  Not bit-identical by construction:
+    the module takes norm_1's batch statistics from the rows conv_0's output transform wrote and splits this small layer's V
+    inside the GEMM, the C path runs a statistics pass and the pre-split GEMM -- same arithmetic, different summation order:
+    <= 1e-5."""
+    import ctypes as C
+    from deepsee_amd import ops, lib as L, networks as Nw
+    from deepsee_amd.options import make_opt
+    N, Cc, R, Lc, S, H = 2, 256, 64, 19, 128, 128
+    g = gen(91)
+    opt = make_opt(ngf=Cc // 16, add_noise=False, start_size=8, crop_size=H, load_size=H, batchSize=N)
+    blk = Nw.SPADEResnetBlock(Cc, opt, "sean")
+    blk.load_state_dict({k: O.recipe_tensor("coarse_blk", k, v.shape, 1.0) for k, v in blk.state_dict().items()})
+    blk.cuda()
+    label = F.interpolate(torch.randint(0, Lc, (N, 1, 8, 8), generator=g).float(), size=(H, H), mode="nearest")
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
+    style = (torch.rand(N, Lc, S, generator=g) * 2 - 1).cuda()
+    x = nhwc(torch.randn(N, Cc, R, R, generator=g))
+    norms, convs = [], []
+    fwd, conv2d = ops.SeanNormTable._forward, ops.conv2d
+
+    def norm_spy(ctx, x_, w_sh, b_sh, w2a, table, b2, rm, rv, labels_, shift, training_, add_one, grad_sink=None, cat_ups=0):
+        norms.append(dict(w_sh=w_sh.contiguous(), b_sh=b_sh.contiguous(), w2a=w2a.contiguous(), table=table.contiguous(),
+                          b2=b2.contiguous(), rm=rm.clone(), rv=rv.clone(), shift=shift, add_one=add_one))
+        return fwd(ctx, x_, w_sh, b_sh, w2a, table, b2, rm, rv, labels_, shift, training_, add_one, grad_sink, cat_ups)
+
+    def conv_spy(x_, w, bias=None, **kw):
+        convs.append((w.detach().contiguous().clone(), None if bias is None else bias.detach().contiguous().clone()))
+        return conv2d(x_, w, bias, **kw)
+
+    ops.SeanNormTable._forward, ops.conv2d = staticmethod(norm_spy), conv_spy
+    try:
+        with torch.no_grad():
+            want = blk(x, labels, style, None, "blk", 0, True, L.ACT_LRELU)
+    finally:
+        ops.SeanNormTable._forward, ops.conv2d = staticmethod(fwd), conv2d
+    assert len(norms) == 2 and len(convs) == 2
+
+    class NormLayer(C.Structure):
+        _fields_ = [(k, C.c_void_p) for k in ("w_shared", "b_shared", "w2a", "table", "bias_packed", "running_mean",
+                                              "running_var")] + [("add_one", C.c_float)]
+
+    def layer(d):
+        return NormLayer(d["w_sh"].data_ptr(), d["b_sh"].data_ptr(), d["w2a"].data_ptr(), d["table"].data_ptr(),
+                         d["b2"].data_ptr(), d["rm"].data_ptr(), d["rv"].data_ptr(), float(d["add_one"]))
+
+    nbytes = L.lib().dsee_spade_resblock_fwd_workspace(N, R, R, Cc, Lc, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    out = torch.empty_like(x)
+    n0, n1 = layer(norms[0]), layer(norms[1])
+    args = (C.byref(n0), convs[0][0], convs[0][1], C.byref(n1), convs[1][0], convs[1][1], labels.t, labels.h, labels.w,
+            norms[0]["shift"], Lc, x, out, L.ACT_LRELU, 1, 1e-5, 0.1, 0.2, N, R, R, Cc, ws)
+    L.call("spade_resblock_fwd", *args, nbytes)
+    torch.cuda.synchronize()
+    dev = rel(out.cpu(), want.cpu())
+    print("coarse resblock forward vs the module: %.2e" % dev)
+    assert dev < 1e-5, dev
+    # the running statistics advanced as the module's did
+    for d, nm in zip(norms, (blk.norm_0, blk.norm_1)):
+        assert rel(d["rm"].cpu(), nm.param_free_norm.running_mean.cpu()) < 1e-5
+        assert rel(d["rv"].cpu(), nm.param_free_norm.running_var.cpu()) < 1e-5
+    with pytest.raises(L.DseeError, match="256 x 128 tiles"):       # shapes the pre-split GEMM does not tile are refused
+        L.call("spade_resblock_fwd", *args[:18], N, 32, 32, Cc, ws, nbytes)
