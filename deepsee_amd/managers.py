@@ -86,8 +86,6 @@ class TrainerManager(BaseManager):
         self.g_losses, self.d_losses = {}, {}
         self.use_graphs = bool(getattr(opt, "hip_graphs", True))
         self.dp_in_graph = bool(getattr(opt, "dp_graph_collectives", False))
-        import os
-        self.keep_graph = bool(getattr(opt, "keep_hip_graph", os.environ.get("DSEE_KEEP_GRAPH", "0") == "1"))
         self._graphs, self._seen, self._static, self._pool = {}, {}, {}, None
         # batch-shape signatures that own graphs / static buffers, least recently used first; at most `max_graph_shapes` are
         # kept (a loader with many distinct shapes would otherwise grow device memory without bound)
@@ -207,17 +205,13 @@ class TrainerManager(BaseManager):
             pinned = optim.staging()
             state = (noise.step, noise.offset)
             torch.cuda.synchronize()
-            # keep_graph: the hipGraph_t the capture produced stays alive next to its executable (torch destroys it after
-            # instantiation otherwise) -- opt.keep_hip_graph / DSEE_KEEP_GRAPH=1, see plan.branch_streams
-            g = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             ops.begin_capture()
             # thread-local capture mode: RCCL's watchdog thread (event queries, in a data-parallel run) must not
             # invalidate a capture in progress on this thread
             eager_opt = multi and not self.dp_in_graph       # all-reduce + Adam outside the graph
             with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
                 losses, generated = step_fn(sd, pinned=pinned, opt_step=not eager_opt)
-            if self.keep_graph:
-                g.instantiate()
             ops.begin_capture()                   # (pools created on the capture stream belong to the graph)
             noise.step, noise.offset = state      # the capture ran the Python side once; the replay below is the real step
             # tensors the forward leaves in model.logs live in the shared graph pool as well: copied out after every replay

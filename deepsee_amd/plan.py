@@ -80,7 +80,8 @@ class KernelPlan:
     # worth ~1-2 ms of the 88 ms step, but OFF by default: replaying a graph WITH parallel branches segfaults inside the HIP
     # runtime (hip::Graph::UpdateStreams <- hip::GraphExec::Run <- hipGraphLaunch, ROCm 7.0.2) late in a long-lived process
     # -- deterministically at the first replay of the 34th test of tests/test_gpu_model.py, never in any subset of it, nor in
-    # 40 managers x capture / replay cycles (tools/exp/graph_churn.py); rocgdb backtrace in profiles/r05_graph_branch_segv.txt.
+    # 40 managers x capture / replay cycles (tools/exp/graph_churn.py), also with the captured hipGraph_t kept alive
+    # (CUDAGraph(keep_graph=True)); rocgdb backtrace in profiles/r05_graph_branch_segv.txt.
     # Single-stream graphs (rounds 3-4) never did.
     branch_streams: bool = False
     # direct (non-Winograd) convolutions with at least this much work run their MFMAs on fp16x2-split operands; 0 disables
