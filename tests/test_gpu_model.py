@@ -28,10 +28,10 @@ CASES = {
                                  max_fm_size=64),
     "clip_nottur_4to32": dict(start_size=4, crop_size=32, load_size=32, batchSize=2, ngf=8, add_noise=False,
                               no_TTUR=True, gradient_clip=0.01),
-    # the benchmark's geometry (32 -> 256, 5 resolutions) with a batch > 1 on the EAGER path -- BatchNorm over several images,
-    # per-image style-table groups, the Winograd chunking of a batch -- at 128 channels so the CPU oracle stays cheap (the
-    # benchmark's own bs = 8 x 512 channels: test_benchmark_path_matches_oracle)
-    "indep_32to256_bs4_ngf8": dict(batchSize=4, ngf=8),
+    # (the benchmark's geometry with a batch > 1 -- BatchNorm over several images, per-image style-table groups, the Winograd
+    # chunking of a batch -- is held against the oracle at the benchmark's own bs = 8 x 512 channels by
+    # test_benchmark_path_matches_oracle, whose first occurrence of every graph is this eager path; the 128-channel bs = 4 case of
+    # round 4 left the suite with round 5: 45 - 60 s of CPU oracle time, profiles/r05_gpu_tests.log)
 }
 
 
@@ -164,26 +164,8 @@ def test_train_step_matches_oracle(name):
     print("G-grad rel err: median %.2e max %.2e; D-grad max %.2e" % (errs[len(errs) // 2], errs[-1], derrs[-1]))
 
 
-def test_full_size_step_matches_oracle():
-    """BASELINE.json configs[1] at its full size (independent 8x 32 -> 256, 512-channel generator, every Winograd /
-    bf16x3 / per-image-table kernel at the shapes the benchmark runs) with bs = 1 against the CPU oracle: one G step +
-    one D step on identical weights, inputs, noise and branch decisions (~10 s of oracle time on the host cores)."""
-    over = dict(batchSize=1)
-    orc, tm, out = run_case(over, seed=4242)
-    r = out[0]
-    for k, v in r["gl"].items():
-        assert abs(r["hgl"][k] - v) <= 1e-4 * abs(v), (k, r["hgl"][k], v)
-    dev = rel(r["hfake"], r["fake"])
-    assert dev < 1e-4, dev
-    assert r["touched_g"] == set(r["ggrads"])
-    gmax = max(float(v.norm()) for v in r["ggrads"].values())
-    errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
-                  for k, v in r["ggrads"].items())
-    assert errs[len(errs) // 2] < GRAD_MEDIAN_BOUND and errs[-1] < GRAD_MAX_BOUND, (errs[len(errs) // 2], errs[-1])
-    for k, v in r["dl"].items():
-        assert abs(r["hdl"][k] - v) <= 2e-3 * abs(v), (k, r["hdl"][k], v)
-    print("full size: |fake - oracle| / |oracle| = %.2e, G-grad rel err median %.2e max %.2e, losses %s"
-          % (dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
+# (round 5: test_full_size_step_matches_oracle -- configs[1] at full size, bs = 1, eager with an explicit noise tape, 33 s -- is
+# superseded by test_benchmark_path_matches_oracle below: the same comparison at bs = 8 on the replayed graphs)
 
 
 class _TapedNoise:
@@ -831,7 +813,7 @@ def test_dp_collectives_captured_inside_the_graph_world1():
     assert a[1] == b[1] and a[2] == b[2] and len(a[1]) > 1000      # the flat G / D parameter buffers, byte for byte
 
 
-@pytest.mark.parametrize("sync_bn", [False, True])
+@pytest.mark.parametrize("sync_bn", [True])      # (False -- a subset of the exchanges, two more child processes -- left with round 5)
 def test_data_parallel_through_the_c_abi_communicator_world1(sync_bn):
     """opt.dp_comm = "capi": the gradient all-reduce (per chunk, on the communicator's side stream, each chunk followed by its
     Adam launch), the start-state broadcast and -- with opt.sync_bn -- the SyncBN statistics all-gather / sum all-reduce go
