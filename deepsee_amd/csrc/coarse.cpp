@@ -65,6 +65,10 @@ int dsee_sean_norm_fwd(const uint8_t* labels, int lab_h, int lab_w, int shift, i
                    shift, H, W);
     return DSEE_EINVAL;
   }
+  if (C % 64 != 0) {     // (dsee_sean_pack_fwd packs gamma|beta in groups of 64 channels: rows == 2 C only then)
+    dsee_set_error("dsee_sean_norm_fwd: C %% 64 == 0 required (C = %d)", C);
+    return DSEE_EUNSUPPORTED;
+  }
   if (!training && !(running_mean && running_var)) {
     dsee_set_error("dsee_sean_norm_fwd: evaluation mode needs the running statistics");
     return DSEE_EINVAL;

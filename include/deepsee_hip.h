@@ -651,7 +651,7 @@ int dsee_comm_destroy(void* comm);
  * labels uint8 [N][lab_h][lab_w], read at stride 2^shift (lab_h >> shift == H); w_shared [128][label_nc][3][3], b_shared [128];
  * w2a [2C][128][3][3] and bias_packed [2C] in the packed gamma|beta row order of dsee_sean_pack_fwd; table [N][9][2C][32] or
  * NULL; x, out_h [N][H][W][C]; out_scale (saved modulation factor), sign_mask ([C/32][N*H*W] words), amax_h (2048 floats,
- * zeroed by the caller: receives max |h|) are optional; mean / invstd [C] are outputs.  C % 32 == 0, (H/4)*(W/4) % 64 == 0.
+ * zeroed by the caller: receives max |h|) are optional; mean / invstd [C] are outputs.  C % 64 == 0, (H/4)*(W/4) % 64 == 0.
  * The workspace (dsee_sean_norm_fwd_workspace bytes, caller-owned, 256-byte aligned) holds the embedding, the statistics
  * partials, V2, U2 and three operand maxima; nothing is allocated and the stream is never synchronised. */
 size_t dsee_sean_norm_fwd_workspace(int N, int H, int W, int C, int label_nc, int has_table);
