@@ -767,7 +767,7 @@ def test_hip_graphs_default_on_partial_batches_and_shape_eviction():
             assert float((x - y).abs().mean()) <= 5e-5, float((x - y).abs().mean())
 
 
-def _child_result(p, q, timeout=240):
+def _child_result(p, q, timeout=420):
     """The result a child process puts into `q`, or None as soon as the child is dead without having delivered one (a child
     that aborts must not cost the suite the whole timeout)."""
     import queue
