@@ -37,6 +37,30 @@ def test_capi_library_loads_and_exports_header_symbols():
     assert rc == -1 and b"argument check failed" in so.dsee_last_error()
 
 
+def test_coarse_entry_points_validate_before_they_launch():
+    """The coarse entry points (csrc/coarse.cpp) size their caller-owned workspace on the host and refuse bad arguments with an
+    error code and a message before any HIP call (so this runs without a GPU)."""
+    from deepsee_amd import lib as L
+    so = L.lib()
+    n1 = so.dsee_sean_norm_fwd_workspace(8, 256, 256, 512, 19, 1)
+    n0 = so.dsee_sean_norm_fwd_workspace(8, 256, 256, 512, 19, 0)
+    t = 8 * 64 * 64
+    # embedding + V2 + U2 dominate: [N,H,W,160] fp32, 36 T 160 two fp16 terms, 36 N 1024 160 two fp16 terms
+    assert n1 >= 8 * 256 * 256 * 160 * 4 + 36 * t * 160 * 4 + 36 * 8 * 1024 * 160 * 4 and n1 < 2.2e9
+    assert n0 < n1 and n0 >= 8 * 256 * 256 * 128 * 4 + 36 * t * 128 * 4
+    nb = so.dsee_spade_resblock_fwd_workspace(8, 256, 256, 512, 19, 1)
+    assert nb >= n1 + 2 * 8 * 256 * 256 * 512 * 4 + 2 * 36 * t * 512 * 4 and nb < 9e9
+    args = [None] * 24 + [8, 256, 256, 512, None, 0]
+    assert len(args) + 1 == len(so.dsee_sean_norm_fwd.argtypes)
+    args[1:5] = [256, 256, 0, 19]
+    args[13:18] = [1, 1e-5, 0.1, 1.0, 0.2]
+    rc = so.dsee_sean_norm_fwd(*args, None)
+    assert rc == -1 and b"NULL argument" in so.dsee_last_error()
+    rc = so.dsee_spade_resblock_fwd(*([None] * 6), None, 256, 256, 0, 19, None, None, 0, 1, 1e-5, 0.1, 0.2, 8, 256, 256, 512, None,
+                                    0, None)
+    assert rc == -1 and b"NULL argument" in so.dsee_last_error()
+
+
 def test_ctypes_prototypes_come_from_the_header():
     """deepsee_amd.lib binds every entry point with the argtypes / restype parsed from include/deepsee_hip.h: a call with
     the wrong arity, or a float where the header says int, raises instead of corrupting the stack; long / size_t /
