@@ -673,7 +673,7 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
 // spends about a quarter of a block each in fragment reads (34.8 k cycles: exactly the time the LDS array needs for ALL eight
 // waves' reads, 8.6 MB at 256 B/clk), LDS-DMA requests (31.1 k: the texture addresser takes 64 B/clk), fold / Y update (32.0 k)
 // and MFMAs (33.5 k), and 3 k waiting for its own requests to land: every phase saturates a pipe the waves share while it
-// runs, and with two in-order waves per SIMD at most two phases overlap -- the block takes ~140 k cycles against 46 - 57 k of
+// runs, and with two in-order waves per SIMD at most two phases overlap -- the block takes ~140 k cycles against ~46 k of
 // the busiest pipe.  Here the same 64 tile x 64 row block is owned by SIXTEEN waves of 128 registers, four per SIMD: a wave
 // owns ONE 16 x 16 block (16 gamma rows or the 16 beta rows of the same channels, 16 tiles): Y = 16 outputs x 4 = 64 AGPRs,
 // T = 16 registers, one MFMA accumulator, one set of four fragments; it issues ONE LDS-DMA instruction per piece (waves 0-7 the
