@@ -51,6 +51,13 @@
 
 // Which form of the kernel a launch takes unless the environment says otherwise (DSEE_FUSED_W16): 0 = 8 waves of 256
 // registers, 1 = 16 waves of 128 (round 5, see spade_fused_fwd16_kernel).
+// Shape of the set of 32 workgroups that co-run on one XCD: DSEE_FUSED_SET_A tile groups x 32 / A row groups (a set fetches A V
+// strips + 32 / A U strips; 4 x 8 and 8 x 4 are the optimum, measurement builds vary it to check the traffic model of DESIGN 3.12)
+#ifndef DSEE_FUSED_SET_A
+#define DSEE_FUSED_SET_A 4
+#endif
+#define DSEE_FUSED_SET_B (32 / DSEE_FUSED_SET_A)
+
 #ifndef DSEE_FUSED_W16_DEFAULT
 #define DSEE_FUSED_W16_DEFAULT 0
 #endif
@@ -139,11 +146,11 @@ __global__ __launch_bounds__(512) void spade_fused_fwd_kernel(FusedArgs a) {
   }
   long tg;
   int rg;
-  if ((rgn & 7) == 0 && (tgn & 3) == 0) {
+  if ((rgn % DSEE_FUSED_SET_B) == 0 && (tgn % DSEE_FUSED_SET_A) == 0) {
     const long sup = l >> 5;
-    const int in = (int)(l & 31), rh = rgn >> 3;
-    tg = (sup / rh) * 4 + (in >> 3);
-    rg = (int)(sup % rh) * 8 + (in & 7);
+    const int in = (int)(l & 31), rh = rgn / DSEE_FUSED_SET_B;
+    tg = (sup / rh) * DSEE_FUSED_SET_A + (in / DSEE_FUSED_SET_B);
+    rg = (int)(sup % rh) * DSEE_FUSED_SET_B + (in % DSEE_FUSED_SET_B);
   } else {
     tg = l / rgn;
     rg = (int)(l % rgn);
@@ -704,11 +711,11 @@ __global__ __launch_bounds__(1024) void spade_fused_fwd16_kernel(FusedArgs a) {
   }
   long tg;
   int rg;
-  if ((rgn & 7) == 0 && (tgn & 3) == 0) {
+  if ((rgn % DSEE_FUSED_SET_B) == 0 && (tgn % DSEE_FUSED_SET_A) == 0) {
     const long sup = l >> 5;
-    const int in = (int)(l & 31), rh = rgn >> 3;
-    tg = (sup / rh) * 4 + (in >> 3);
-    rg = (int)(sup % rh) * 8 + (in & 7);
+    const int in = (int)(l & 31), rh = rgn / DSEE_FUSED_SET_B;
+    tg = (sup / rh) * DSEE_FUSED_SET_A + (in / DSEE_FUSED_SET_B);
+    rg = (int)(sup % rh) * DSEE_FUSED_SET_B + (in % DSEE_FUSED_SET_B);
   } else {
     tg = l / rgn;
     rg = (int)(l % rgn);
