@@ -516,8 +516,13 @@ def main():
         out["hip_graphs"] = {"enabled": bool(tm.use_graphs), "captured": sorted("/".join(map(str, k[:3])) for k in tm._graphs),
                              "extra_warmup_steps": extra_warmup,
                              "timed_half_steps_replayed": tm.graph_stats["replayed"] - replays_before, "timed_half_steps": 2 * args.steps,
+                             "parallel_branches": bool(tm.sr_model.plan.branch_streams),
                              "note": "G and D step replayed as hipGraphs (one per encoder-branch variant; first occurrence "
-                                     "eager, second captured); host_enqueue_ms_per_step is the Python time per step"}
+                                     "eager, second captured); host_enqueue_ms_per_step is the Python time per step.  "
+                                     "parallel_branches (the two D scales and VGG fake / real as parallel graph branches, "
+                                     "--plan branch_streams=True: ~1.5 ms per step, profiles/r05_bench_branch_streams.json) is off "
+                                     "by default: replaying such graphs segfaults inside the HIP runtime late in a long-lived "
+                                     "process (profiles/r05_graph_branch_segv.txt)"}
         if fused and not fused_is_r3:
             # 16-bit mode / --arith bf16x3: the norms take the round-2 path (gamma/beta GEMM, then this fused output transform)
             g = fused["gb"] / (fused["ms"] / 1e3)
