@@ -494,6 +494,15 @@ def _presplit_ok(xc, t, t_g, r_s, k_s=0, keep=False):
             and (36 * t // 256) * (r_s // 256) >= 512 and (not keep or k_s == 160 or k_s % 128 == 0))
 
 
+def _gemm_pre(name, k_s, r_s):
+    """Entry point of a pre-split NT GEMM: the one-wave-per-SIMD kernel (csrc/gemm_w4.hip, round 6) where its shape rules hold --
+    whole 256-column tiles and an even number of 64-byte-row slabs -- else the 8-wave ping-pong kernel."""
+    slab = 32 if name == "gemm_f16p_pre" else 16
+    if P().gemm_w4 and r_s % 256 == 0 and k_s % (2 * slab) == 0:
+        return name + "_w4"
+    return name
+
+
 def _pk_ok(xc, t_g, r_s, k_s):
     """16-bit storage mode (plan.half): the layer takes the packed one-term kernels (dsee_wino43_input_f16p ->
     dsee_gemm_f16p_pre -> fp16 product) when the input's maximum was written by its producer, every GEMM group is whole
@@ -519,7 +528,7 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
         L.call("wino43_input_f16p", xc, v1, nb, h, wd, k_s, ax, FUSED_V_BOUND)
         with _timed("winograd_gemm_f16_1term_packed", 2.0 * 36 * t * k_s * r_s,
                     2.0 * 36 * t * k_s + 2.0 * groups * rows * k_s + 2.0 * 36 * t * r_s):
-            L.call("gemm_f16p_pre", v1, u, m, 36 * t, r_s, k_s, t_g, rows, ax, FUSED_V_BOUND, u_amax, ms)
+            L.call(_gemm_pre("gemm_f16p_pre", k_s, r_s), v1, u, m, 36 * t, r_s, k_s, t_g, rows, ax, FUSED_V_BOUND, u_amax, ms)
         if keep is not None:
             keep.append((v1, ax, "pk"))     # (packed one-term V, max |x|, marker): the weight gradient's Q operand as it is
     elif split == 3:
@@ -536,7 +545,7 @@ def _wino_vgemm(xc, nb, h, wd, k_s, u, r_s, rows, kp, per_image, split, keep=Non
         v2 = _i16(36 * t * k_s * 2)
         L.call("wino43_input_f16x2", xc, v2, nb, h, wd, k_s, ax, FUSED_V_BOUND)
         with _timed(_gemm_name(2), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, groups, rows, 2)):
-            L.call("gemm_f16x2_pre", v2, u, m, 36 * t, r_s, k_s, t_g, rows, ax, FUSED_V_BOUND, u_amax)
+            L.call(_gemm_pre("gemm_f16x2_pre", k_s, r_s), v2, u, m, 36 * t, r_s, k_s, t_g, rows, ax, FUSED_V_BOUND, u_amax)
         if keep is not None:
             keep.append((v2, ax, True))      # (pre-split V, max |x|, marker): the weight gradient's Q operand as it is
     elif split == 2:
@@ -734,9 +743,9 @@ def _wino_dgrad_from_dm(dm, u_t, nb, h, wd, k_s, r_s, rows, mask=None, mask_ld=0
     dvs = amax_slot() if split in (3, 4) else None
     with _timed(_gemm_name(split), 2.0 * 36 * t * k_s * r_s, _gemm_bytes(t, k_s, r_s, 36, rows, split)):
         if split == 4:
-            L.call("gemm_f16p_pre", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, dm[1], DM_BOUND, u_t[1], dvs)
+            L.call(_gemm_pre("gemm_f16p_pre", k_s, r_s), dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, dm[1], DM_BOUND, u_t[1], dvs)
         elif len(dm) == 3:
-            L.call("gemm_f16x2_pre", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, dm[1], DM_BOUND, u_t[1])
+            L.call(_gemm_pre("gemm_f16x2_pre", k_s, r_s), dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, dm[1], DM_BOUND, u_t[1])
         elif split == 3:
             L.call("gemm_f16_af32", dm[0], u_t[0], dv, 36 * t, r_s, k_s, t, rows, 0, dm[1], u_t[1], 1, dvs)
         elif split == 2:

@@ -47,6 +47,9 @@ class KernelPlan:
     half_norms: bool = True
     # A operand of a forward Winograd GEMM written pre-split by the input transform (False: fp32 V, split inside the GEMM)
     presplit_a: bool = True
+    # the pre-split NT GEMMs (forward / adjoint data gradient of the wide convolutions) on the one-wave-per-SIMD kernel of
+    # csrc/gemm_w4.hip (128 x 128 wave tiles, one barrier per slab; round 6).  False: the 8-wave ping-pong kernel of rounds 2-5
+    gemm_w4: bool = True
     # A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
     presplit_dm: bool = True
     # ... and the gamma/beta gradient of a SPADE/SEAN norm as well (False: fp32 dM from the norm backward's reduce pass)

@@ -146,6 +146,15 @@ int dsee_gemm_f16x2_af32(const float* A, const void* B2, float* C, long M, int N
  * (forward convolutions), the adjoint data gradients. */
 int dsee_gemm_f16x2_pre(const void* A2, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
                         const float* amax_a, float a_bound, const float* amax_b, hipStream_t stream);
+/* Round 6: the same two GEMMs (dsee_gemm_f16x2_pre / dsee_gemm_f16p_pre: same operand images, scales, products and output) on
+ * the one-wave-per-SIMD kernel of csrc/gemm_w4.hip -- 4 waves x (128 x 128) accumulator tiles per 256 x 256 block (8 instead of
+ * 12 KB of LDS fragment reads per 24 MFMAs), one barrier per slab, fragment reads and LDS-DMA requests issued between the
+ * MFMAs, a five-stage XOR-swizzled LDS ring (160 KB).  N % 256 == 0 and an even number of 64-byte-row slabs (K % 32 == 0
+ * two-term, K % 64 == 0 packed); the hosts fall back to the 8-wave kernels otherwise. */
+int dsee_gemm_f16x2_pre_w4(const void* A2, const void* B2, float* C, long M, int N, int K, long rows_per_group, int b_rows,
+                           const float* amax_a, float a_bound, const float* amax_b, hipStream_t stream);
+int dsee_gemm_f16p_pre_w4(const void* A1, const void* B1, void* C16, long M, int N, int K, long rows_per_group, int b_rows,
+                          const float* amax_a, float a_bound, const float* amax_b, float* cscale, hipStream_t stream);
 int dsee_gemm_f16x2_tn_f32(const float* P, const float* Q, float* C, int groups, long T, int rows_p, int rows_q, int ldc,
                            int splits, const float* amax_p, const float* amax_q, hipStream_t stream);
 /* ... and with Q pre-split (round 3): Q2 = the V2 [rows_q/16][groups*T][2][16] fp16 dsee_wino43_input_f16x2 wrote for the

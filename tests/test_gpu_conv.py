@@ -330,14 +330,19 @@ def test_gemm_f16x2_is_fp32_accurate(groups, tg, n, k, tile, spread):
     assert float(slot.max()) == am_a
 
 
+@pytest.mark.parametrize("kernel", ["w8", "w4"])
 @pytest.mark.parametrize("groups,tg,n,k,bound", [(3, 256, 256, 160, 1.0), (2, 512, 512, 512, 100.0), (36, 256, 256, 32, 8.0),
-                                                 (1, 8192, 512, 128, 100.0)])
-def test_gemm_f16x2_pre_split_a(groups, tg, n, k, bound):
+                                                 (1, 8192, 512, 128, 100.0), (5, 768, 768, 64, 100.0), (300, 256, 256, 96, 2.0)])
+def test_gemm_f16x2_pre_split_a(groups, tg, n, k, bound, kernel):
     """dsee_gemm_f16x2_pre: the NT GEMM with BOTH operands pre-split (A rows in the layout dsee_wino43_input_f16x2 writes,
     scaled with a bound known before the producer ran -- `bound` x the true maximum, i.e. log2(bound) bits of headroom
     given away) against float64: fp32-level accuracy (the two-term split still carries 22 - log2(bound) bits), every launch
     on NaN-poisoned LDS and bit-identical."""
     from deepsee_amd import lib as L
+    # kernel = "w4": the one-wave-per-SIMD form (csrc/gemm_w4.hip, round 6; five-stage swizzled ring, requests four slabs
+    # ahead, fragments of the next slab read between the MFMAs): same operands, and -- slabs in order, products smallest
+    # first -- the same fp32 accumulation order, so the two kernels must agree bit for bit
+    entry = "gemm_f16x2_pre_w4" if kernel == "w4" else "gemm_f16x2_pre"
     g = torch.Generator().manual_seed(groups * 100 + k)
     a = torch.randn(groups * tg, k, generator=g)
     b = torch.randn(groups, n, k, generator=g)
@@ -350,14 +355,18 @@ def test_gemm_f16x2_pre_split_a(groups, tg, n, k, bound):
     for it in range(3):
         L.call("selftest_lds_poison", sink)
         c = torch.full((groups * tg, n), float("nan"), device="cuda")
-        L.call("gemm_f16x2_pre", a2, b2, c, groups * tg, n, k, tg, n, _amax(am_a), float(bound), _amax(am_b))
+        L.call(entry, a2, b2, c, groups * tg, n, k, tg, n, _amax(am_a), float(bound), _amax(am_b))
         torch.cuda.synchronize()
         assert torch.isfinite(c).all()
         first = c.clone() if first is None else first
         assert torch.equal(c, first)
     err = ((first.cpu().double() - ref).norm() / ref.norm()).item()
-    print("pre-split A, bound %g: vs f64 %.2e" % (bound, err))
+    print("pre-split A (%s), bound %g: vs f64 %.2e" % (kernel, bound, err))
     assert err < (5e-7 if bound <= 8 else 4e-6)
+    if kernel == "w4":
+        c8 = torch.empty_like(first)
+        L.call("gemm_f16x2_pre", a2, b2, c8, groups * tg, n, k, tg, n, _amax(am_a), float(bound), _amax(am_b))
+        assert torch.equal(c8, first), "the two kernels accumulate in the same order"
 
 
 def test_gemm_f16x2_tn_long_chain_accuracy():
@@ -864,14 +873,18 @@ def _unpack1_rows(img, rows, k):
     return img.view(torch.float16).view(k // 32, rows, 32).permute(1, 0, 2).reshape(rows, k).float()
 
 
+@pytest.mark.parametrize("kernel", ["w8", "w4"])
 @pytest.mark.parametrize("groups,tg,n,k,bound", [(3, 256, 256, 160, 1.0), (2, 512, 512, 512, 100.0), (36, 256, 256, 32, 8.0),
-                                                 (1, 8192, 128, 1024, 225.0), (4, 256, 384, 96, 100.0)])
-def test_gemm_f16p_pre_packed_one_term(groups, tg, n, k, bound):
+                                                 (1, 8192, 128, 1024, 225.0), (4, 256, 384, 96, 100.0), (40, 512, 512, 128, 100.0)])
+def test_gemm_f16p_pre_packed_one_term(groups, tg, n, k, bound, kernel):
     """dsee_gemm_f16p_pre (16-bit storage mode): both operands ONE scaled fp16 term per element in the packed image, one
     MFMA product per multiply-add, product written as scaled fp16 with its inverse scale in *cscale.  Against float64 on the
     SAME rounded operands the only errors are the fp32 accumulation and the fp16 rounding of the result (2^-11); against the
     unrounded operands the fp16 operand rounding shows (~3e-4).  NaN-poisoned LDS, bit-identical launches."""
     from deepsee_amd import lib as L
+    if kernel == "w4" and (n % 256 or k % 64):
+        pytest.skip("gemm_w4: whole 256-column tiles and an even number of 32-k slabs")
+    entry = "gemm_f16p_pre_w4" if kernel == "w4" else "gemm_f16p_pre"
     g = torch.Generator().manual_seed(groups * 100 + k)
     a = torch.randn(groups * tg, k, generator=g)
     b = torch.randn(groups, n, k, generator=g)
@@ -889,7 +902,7 @@ def test_gemm_f16p_pre_packed_one_term(groups, tg, n, k, bound):
         L.call("selftest_lds_poison", sink)
         c = torch.full((groups * tg, n), float("nan"), dtype=torch.float16, device="cuda")
         cs = torch.zeros(64 * 32, device="cuda")
-        L.call("gemm_f16p_pre", a1, b1, c, groups * tg, n, k, tg, n, _amax(am_a), float(bound), _amax(am_b), cs)
+        L.call(entry, a1, b1, c, groups * tg, n, k, tg, n, _amax(am_a), float(bound), _amax(am_b), cs)
         torch.cuda.synchronize()
         assert torch.isfinite(c).all()
         got = c.float() * cs[0]

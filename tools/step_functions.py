@@ -5,7 +5,7 @@ from deepsee_amd import ops
 from deepsee_amd.managers import TrainerManager
 from deepsee_amd.options import make_opt
 from bench import synthetic_batch
-opt = make_opt("independent_8x_256", batchSize=8, seed=0)
+opt = make_opt("independent_8x_256", batchSize=8, seed=0, hip_graphs=False)   # eager: the timers are events between launches
 random.seed(1234)
 tm = TrainerManager(opt)
 batch = synthetic_batch(opt, 8, 1234, "cuda")

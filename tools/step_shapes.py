@@ -5,7 +5,7 @@ from deepsee_amd import ops
 from deepsee_amd.managers import TrainerManager
 from deepsee_amd.options import make_opt
 from bench import synthetic_batch
-opt = make_opt("independent_8x_256", batchSize=8, seed=0)
+opt = make_opt("independent_8x_256", batchSize=8, seed=0, hip_graphs=False)   # eager: the timers are events between launches
 random.seed(1234)
 tm = TrainerManager(opt)
 batch = synthetic_batch(opt, 8, 1234, "cuda")
@@ -17,9 +17,9 @@ def det(geom, modulate=False):
     return "%s N%d %dx%d C%d -> %dx%d C%d k%d mul%d ds%d ups%d" % (orig(geom, modulate), geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Ho, geom.Wo, geom.Cout, geom.KH, geom.mul, geom.dshift, geom.ups)
 ops._variant = det
 _wr = ops.wgrad_raw
-def wr(x, dout, geom, cout, cin, kh, kw, cin_first=0):
+def wr(x, dout, geom, cout, cin, kh, kw, cin_first=0, **kw_):
     ops._wg = "wgrad N%d %dx%d C%d -> %dx%d C%d k%d mul%d" % (geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Ho, geom.Wo, geom.Cout, geom.KH, geom.mul)
-    return _wr(x, dout, geom, cout, cin, kh, kw, cin_first)
+    return _wr(x, dout, geom, cout, cin, kh, kw, cin_first, **kw_)
 ops.wgrad_raw = wr
 _t = ops._timed
 class T(_t):
