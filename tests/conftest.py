@@ -8,8 +8,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False,
+                     help="also run the cases marked slow (minutes of float64 CPU oracle each); DSEE_RUN_SLOW=1 does the same")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size float64 oracle cases kept out of the default run (--runslow / DSEE_RUN_SLOW=1: "
+                                       "the nightly form of the suite)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow") or os.environ.get("DSEE_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow case: run with --runslow or DSEE_RUN_SLOW=1")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -107,7 +107,10 @@ GRAD_MEDIAN_BOUND, GRAD_MAX_BOUND = 6e-3, 2.5e-2
 # (observed on the MI355X: median 9.8e-2 / max 2.7e-1 at bs = 1 with a forward deviation d = 6e-3 -- the LeakyReLU / ReLU
 # branch of a fraction ~d of the activations flips and every gradient downstream moves by ~sqrt(d) = 8e-2, the floor DESIGN 4
 # measures for the fp32 path at d = 5e-6; any 16-bit operand format sits on that floor, bf16 operands 3x higher)
-HALF_GRAD_MEDIAN_BOUND, HALF_GRAD_MAX_BOUND = 2e-1, 6e-1
+# Round 6: the kink-free check of the 16-bit kernels is test_benchmark_shape_{conv,norm}_vs_float64's 16-bit leg (every gradient
+# <= 1e-2 / 8e-3 against float64); these model-level bounds sit 1.5x above the worst observed value (bs = 1: 9.8e-2 / 2.7e-1;
+# bs = 8 on the replayed graph: 4.2e-2 / 1.8e-1)
+HALF_GRAD_MEDIAN_BOUND, HALF_GRAD_MAX_BOUND = 1.5e-1, 4.2e-1
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -164,8 +167,29 @@ def test_train_step_matches_oracle(name):
     print("G-grad rel err: median %.2e max %.2e; D-grad max %.2e" % (errs[len(errs) // 2], errs[-1], derrs[-1]))
 
 
-# (round 5: test_full_size_step_matches_oracle -- configs[1] at full size, bs = 1, eager with an explicit noise tape, 33 s -- is
-# superseded by test_benchmark_path_matches_oracle below: the same comparison at bs = 8 on the replayed graphs)
+@pytest.mark.slow
+def test_full_size_step_matches_oracle():
+    """BASELINE.json configs[1] at its full size with bs = 1, EAGER with an explicit noise tape, against the CPU oracle (one G step
+    + one D step).  The default run holds the same comparison at bs = 8 on the replayed graphs
+    (test_benchmark_path_matches_oracle); this is the nightly check of the eager path beyond its first occurrence before capture
+    (ADVICE r5)."""
+    over = dict(batchSize=1)
+    orc, tm, out = run_case(over, seed=4242)
+    r = out[0]
+    for k, v in r["gl"].items():
+        assert abs(r["hgl"][k] - v) <= 1e-4 * abs(v), (k, r["hgl"][k], v)
+    dev = rel(r["hfake"], r["fake"])
+    assert dev < 1e-4, dev
+    assert r["touched_g"] == set(r["ggrads"])
+    gmax = max(float(v.norm()) for v in r["ggrads"].values())
+    errs = sorted(float((r["hg"][k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax)
+                  for k, v in r["ggrads"].items())
+    assert errs[len(errs) // 2] < GRAD_MEDIAN_BOUND and errs[-1] < GRAD_MAX_BOUND, (errs[len(errs) // 2], errs[-1])
+    for k, v in r["dl"].items():
+        assert abs(r["hdl"][k] - v) <= 2e-3 * abs(v), (k, r["hdl"][k], v)
+    print("full size: |fake - oracle| / |oracle| = %.2e, G-grad rel err median %.2e max %.2e, losses %s"
+          % (dev, errs[len(errs) // 2], errs[-1], {k: round(v, 5) for k, v in r["hgl"].items()}))
+
 
 
 class _TapedNoise:
@@ -220,7 +244,8 @@ def test_benchmark_path_matches_oracle(preset):
     captured graphs; its state is snapshotted; the replayed G step runs; every Philox draw of that step is regenerated with
     dsee_rng_fill at the same (seed, offset, epoch) into a tape; the oracle runs the same step from the snapshot on that tape.
     Losses <= 1e-4, generated image <= 1e-4, G gradients (the flat buffer the in-graph Adam consumed) within the model-level
-    bounds; then the D replay from the oracle's post-G state: losses <= 2e-3, D gradients <= 5e-3.  The oracle needs ~60 GB of
+    bounds; then the D replay from the oracle's post-G state: losses <= 2e-3, D gradients <= 5e-3 -- for both presets (round 6:
+    configs[3]'s D half is compared as well).  The oracle needs ~60 GB of
     host memory at bs = 8; on a smaller host the test drops to bs = 4 and says so."""
     import os
     import warnings
@@ -275,8 +300,10 @@ def test_benchmark_path_matches_oracle(preset):
     else:
         pytest.fail("no replayable G + D pair after 48 iterations: %r" % (tm.graph_stats,))
     torch.cuda.synchronize()
+    warm_iters = it
     snap = {net: {k: v.detach().cpu().clone() for k, v in getattr(m, "net" + net).state_dict().items()} for net in ("SR", "D", "E")}
     snap["VGG"] = states["VGG"]
+    noise_before_g = m.noise.state_dict()          # (forward index, device epoch) the replayed G step starts from
     # ---- the replayed G step and its tape
     kg2, replayed = half("G")
     assert replayed and kg2 == kg
@@ -305,33 +332,44 @@ def test_benchmark_path_matches_oracle(preset):
     report = ("%s at bs = %d, REPLAYED graphs + Philox tape (%d draws, host RAM %.0f GB): |fake - oracle| / |oracle| = %.2e, "
               "G-grad rel err median %.2e max %.2e, losses %s" % (preset, bs, len(tape), ram_gb, dev, errs[len(errs) // 2],
                                                                   errs[-1], {k: round(v, 5) for k, v in hgl.items()}))
-    if preset != "independent_8x_256":
-        # (configs[3]: the G half only -- the oracle's D step at bs = 8 is another ~30 s of CPU time that the independent case
-        # already spends on the same discriminator kernels)
-        print(report)
-        tm.close()
-        return
-    # ---- BASELINE configs[2]'s per-rank workload on the SAME oracle pass: the 16-bit storage mode (eager, the tape replayed)
-    # from the same snapshot -- generated image within SURVEY 8(d)'s 3e-2, losses within 5 %, gradients within HALF_GRAD_*
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        th = TrainerManager(make_opt(preset, batchSize=bs, seed=0, precision="fp16", hip_graphs=False))
-    assert th.sr_model.plan.half and th.sr_model.plan.half_norms
-    th.sr_model.load_states(snap)
-    th.sr_model.noise = N.ReplayNoise(tape)
-    th.run_generator_one_step(feed())
-    torch.cuda.synchronize()
-    hdev = rel(th.get_latest_generated().detach().cpu(), fake.detach())
-    assert hdev < 3e-2, hdev
-    for k, v in gl.items():
-        w = float(th.g_losses[k])
-        assert abs(w - float(v.detach())) <= 0.05 * abs(float(v.detach())) + 1e-3, (k, w, float(v.detach()))
-    hh = {nm: _grad_or_zero(p) for nm, p in zip(th.optimizer_G.names, th.optimizer_G.params)}
-    herrs = sorted(float((hh[k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax) for k, v in ggrads.items())
-    report += (" | 16-bit mode from the same state: fake %.2e, G-grad rel err median %.2e, 90 %% %.2e, max %.2e"
-               % (hdev, herrs[len(herrs) // 2], herrs[int(0.9 * (len(herrs) - 1))], herrs[-1]))
-    assert herrs[len(herrs) // 2] < HALF_GRAD_MEDIAN_BOUND and herrs[-1] < HALF_GRAD_MAX_BOUND, (herrs[len(herrs) // 2], herrs[-1])
-    del th
+    if preset == "independent_8x_256":
+        # ---- BASELINE configs[2]'s per-rank workload on the SAME oracle pass, and on the path `bench.py --dtype fp16` times (round
+        # 6, VERDICT r5 #4b): a second manager in the 16-bit storage mode with the manager's defaults -- hipGraph replay, DeviceNoise
+        # in registers -- is stepped through the same number of iterations (same seed: the same branch coins, the same capture
+        # schedule, the same graph keys), given the fp32 model's snapshot and Philox position (forward index, device epoch), and
+        # REPLAYS its captured G graph: it draws exactly the numbers of the tape the oracle ran on.  Generated image within SURVEY
+        # 8(d)'s 3e-2, losses within 5 %, gradients (the flat buffer the in-graph Adam consumed) within HALF_GRAD_*.
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            th = TrainerManager(make_opt(preset, batchSize=bs, seed=0, precision="fp16"))
+        assert th.use_graphs and th.sr_model.plan.half and th.sr_model.plan.half_norms
+        mh = th.sr_model
+        mh.load_states(states)
+        mh.noise = N.DeviceNoise(0)                 # the same Philox seed and coin sequence as the fp32 model's Taped(0)
+        for _ in range(warm_iters):
+            th.run_generator_one_step(feed())
+            th.run_discriminator_one_step(feed())
+        torch.cuda.synchronize()
+        assert mh.noise.state_dict() == noise_before_g, (mh.noise.state_dict(), noise_before_g)
+        kgh = ("G",) + tuple(mh.encoder_branch(False, step=mh.noise.step + 1)) + (th._shape_signature(batch), mh.plan)
+        assert kgh in th._graphs and kgh[:-1] == kg[:-1]
+        mh.load_states(snap)
+        before = th.graph_stats["replayed"]
+        th.run_generator_one_step(feed())
+        torch.cuda.synchronize()
+        assert th.graph_stats["replayed"] == before + 1          # the captured graph ran, nothing was enqueued from Python
+        hdev = rel(th.get_latest_generated().detach().cpu(), fake.detach())
+        assert hdev < 3e-2, hdev
+        for k, v in gl.items():
+            w = float(th.g_losses[k])
+            assert abs(w - float(v.detach())) <= 0.05 * abs(float(v.detach())) + 1e-3, (k, w, float(v.detach()))
+        hh = {nm: th.optimizer_G.grad_view(nm).detach().cpu().clone() for nm in th.optimizer_G.names}
+        herrs = sorted(float((hh[k].double() - v.double()).norm()) / max(float(v.norm()), 1e-3 * gmax) for k, v in ggrads.items())
+        report += (" | 16-bit mode, REPLAYED graph + the same Philox draws, from the same state: fake %.2e, G-grad rel err median "
+                   "%.2e, 90 %% %.2e, max %.2e" % (hdev, herrs[len(herrs) // 2], herrs[int(0.9 * (len(herrs) - 1))], herrs[-1]))
+        assert herrs[len(herrs) // 2] < HALF_GRAD_MEDIAN_BOUND and herrs[-1] < HALF_GRAD_MAX_BOUND, (herrs[len(herrs) // 2], herrs[-1])
+        th.close()
+        del th, mh
     # ---- the replayed D step from the oracle's post-G state (both sides identical weights / buffers again)
     load_oracle_state(tm, orc)
     kd2, replayed = half("D")
@@ -472,6 +510,12 @@ def test_smooth_loss_backward(name):
     assert med(ehs) <= max(3 * med(eps_), 20 * med(ecs), 3e-4), (med(ehs), med(eps_), med(ecs))
 
 
+# tensors that sit ON the conditioning boundary of test_full_size_smooth_loss_backward (perturbed fp32 oracle 2.8e-4 of float64
+# against the 3e-4 class boundary; HIP 1.1e-3 against the well-conditioned class's 1e-3): named, not silently re-classed
+BORDERLINE = {"indep_16to512_bs1_ngf16": ("D.discriminator_0.model1.0.0.weight_orig",),
+              "indep_16to512_bs1": ("D.discriminator_0.model1.0.0.weight_orig",)}
+
+
 @pytest.mark.parametrize("name,over", [
     ("config1_32to256_bs1", dict(batchSize=1)),                       # BASELINE configs[1] geometry, 512 channels
     # (round 5: the bs = 8 x 128-channel case of round 4 is gone -- the benchmark's own bs = 8 x 512 channels is now held against
@@ -485,6 +529,13 @@ def test_smooth_loss_backward(name):
     # (256 channels: what is specific to configs[4] is its resolution -- the float64 oracle pass at 512 channels is 3 minutes of
     # CPU time; forward + losses at 512 channels: test_full_size_forward_and_losses)
     ("indep_16to512_bs1_ngf16", dict(batchSize=1, ngf=16, start_size=16, crop_size=512, load_size=512, add_noise=False)),
+    # ---- the nightly form (--runslow / DSEE_RUN_SLOW=1): the cases rounds 4-5 took out of the default run for their
+    # float64 CPU time, not for their content
+    pytest.param("guided_32to256_bs1", dict(batchSize=1, netE="fullstyle", noisy_style_scale=0.05, guiding_style_image=True),
+                 marks=pytest.mark.slow),                                # BASELINE configs[3] at full size, float64 (62 s)
+    pytest.param("indep_16to512_bs1", dict(batchSize=1, start_size=16, crop_size=512, load_size=512, add_noise=False),
+                 marks=pytest.mark.slow),                                # BASELINE configs[4] backward at 512 channels (3 min)
+    pytest.param("indep_32to256_bs8_ngf8", dict(batchSize=8, ngf=8), marks=pytest.mark.slow),   # bs = 8 at 128 channels
 ])
 def test_full_size_smooth_loss_backward(name, over):
     """Gradients of the whole path at the BENCHMARK shapes (512 channels, 32 -> 256: the 256x256 / 256x160 bf16x3 GEMM
@@ -493,17 +544,22 @@ def test_full_size_smooth_loss_backward(name, over):
     this depth: its unperturbed median error is ~7e-4 and, with its input image scaled by (1 + 6e-6) -- the size of
     HIP's forward deviation -- ~2e-3 on almost every tensor (a forward deviation d flips the ReLU / LeakyReLU branch of a
     fraction ~d of the activations in G, D and VGG; every gradient downstream moves by ~sqrt(d)).  So:
-      * a tensor is WELL CONDITIONED when the perturbed fp32 oracle stays within 2e-4 of float64: HIP must be within 1e-3
-        (round 5: 2e-4, was 3e-4 -- the classes met at a cliff, bound 1e-3 below it and 3e-3 above, and a tensor the perturbed
-        oracle itself moves by 2.8e-4 is not well conditioned: D.discriminator_0.model1 at 16 -> 512 sat there);
+      * a tensor is WELL CONDITIONED when the perturbed fp32 oracle stays within 3e-4 of float64: HIP must be within 1e-3.
+        (Round 5 had moved the boundary to 2e-4 for one tensor; ADVICE r5: the boundary is 3e-4 again and that tensor is named
+        in BORDERLINE below -- D.discriminator_0.model1 at 16 -> 512, which the perturbed oracle itself moves by 2.8e-4: it is
+        held to the other class's rule, <= 5x its own perturbed-oracle error, and the test prints that it was.)
       * every other tensor is held to the oracle's own behaviour under the equal-size perturbation: <= 5x its error
         (floor 3e-3), and HIP's median over all tensors <= 1.5x the perturbed oracle's median.
     The kink-free check of the same kernels at the same shapes to 1e-3 is tests/test_gpu_ops.py::
     test_benchmark_shape_conv_vs_float64 / test_benchmark_shape_norm_vs_float64."""
     rows, dev, pert = smooth_loss_errors(over, seed=777, plain_f32=False)
     med, q90, ehs, ecs, eps_ = _summ(rows)
-    well = [r for r in rows if r[3] <= 2e-4]
-    ill = [r for r in rows if r[3] > 2e-4]
+    borderline = BORDERLINE.get(name, ())
+    well = [r for r in rows if r[3] <= 3e-4 and r[0] not in borderline]
+    ill = [r for r in rows if r[3] > 3e-4 or r[0] in borderline]
+    for r in rows:
+        if r[0] in borderline:
+            print("%s: borderline tensor %s held to the ill-conditioned rule: HIP %.2e, perturbed oracle %.2e" % (name, r[0], r[1], r[3]))
     worst = max(well, key=lambda r: r[1]) if well else ("-", 0.0)
     worst_ill = max(ill, key=lambda r: r[1] / r[3]) if ill else ("-", 0.0, 0.0, 1.0)
     print("%s: fake deviation %.1e | all %d tensors: HIP median %.2e, oracle-f32 median %.2e, perturbed oracle-f32 median "
@@ -813,7 +869,7 @@ def test_dp_collectives_captured_inside_the_graph_world1():
     assert a[1] == b[1] and a[2] == b[2] and len(a[1]) > 1000      # the flat G / D parameter buffers, byte for byte
 
 
-@pytest.mark.parametrize("sync_bn", [True])      # (False -- a subset of the exchanges, two more child processes -- left with round 5)
+@pytest.mark.parametrize("sync_bn", [True, pytest.param(False, marks=pytest.mark.slow)])   # (False: a subset of the exchanges, two more child processes)
 def test_data_parallel_through_the_c_abi_communicator_world1(sync_bn):
     """opt.dp_comm = "capi": the gradient all-reduce (per chunk, on the communicator's side stream, each chunk followed by its
     Adam launch), the start-state broadcast and -- with opt.sync_bn -- the SyncBN statistics all-gather / sum all-reduce go
@@ -971,7 +1027,7 @@ def test_half_mode_tracks_fp32():
         assert abs(ma - mb) <= tol, (lo, hi, k, ma, mb, my)
 
 
-@pytest.mark.parametrize("bs", [1])
+@pytest.mark.parametrize("bs", [1, pytest.param(8, marks=pytest.mark.slow)])
 def test_half_mode_vs_oracle(bs):
     """The 16-bit mode against the CPU ORACLE (not only against the fp32 HIP path): one G step of BASELINE configs[1]'s
     geometry on identical weights, inputs, noise and branch decisions at bs = 1 (the benchmark's bs = 8 shares the oracle pass

@@ -66,6 +66,8 @@ for l in open('gpurun_out/r06_bench_power_${BENCH_TAG:-default}.txt'):
         timeout 600 python tools/step_functions.py 60 2>&1 | grep -v "amdgpu.ids\|Warning\|self.sr_model\|^lr G"; } > $out 2>&1 ;;
     alternate)  # the GEMM back to back vs alternating with light kernels (power-state transitions)
       { timeout 300 python tools/exp/gemm_alternate.py gemm_f16x2_pre_w4; timeout 300 python tools/exp/gemm_alternate.py gemm_f16x2_pre; } 2>&1 | grep -v amdgpu.ids > $out ;;
+    pytest)     # PYTEST_ARGS: a selection of the GPU suite
+      DSEE_TEST_DURATIONS=gpurun_out/r06_durations.txt timeout ${PYTEST_TIMEOUT:-1500} python -m pytest $PYTEST_ARGS 2>&1 | grep -v amdgpu.ids | tail -${PYTEST_TAIL:-60} > $out ;;
     bench)      # the driver's command
       timeout 900 python bench.py --steps 20 --warmup 5 > $out 2>gpurun_out/r06_bench.err ;;
     bench_quick)
