@@ -145,20 +145,23 @@ constexpr int NWALK = 1024;  // row-segment walkers of the weight gradient (4 pe
 // ---- the same layer as a 1x1 GEMM + a 9-point gather (round 3): z[p][tap*Cout + co] = sum_c x[p][c] w[co][c][tap] is a
 // plain [pixels x C] x [C x 9 Cout] product (fp32 MFMA implicit-GEMM kernel, reads x ONCE at HBM rate), and
 // out[p][co] = act(bias[co] + sum_tap z[p + d(tap)][tap*Cout + co]) with zero padding outside the image.
+// (round 6: KH x KW taps, padding P, output Ho x Wo = H + 2 P - KH + 1 -- the discriminator's last layer, 256 -> 1 channels, 4 x 4,
+// padding 2 (discriminator.py:78-96), goes the same way: as an implicit GEMM it filled 1 of 32 MFMA columns at 2-4 TFLOP/s)
 __global__ __launch_bounds__(256) void thin_gather_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                               float* __restrict__ out, int N, int H, int W, int ldz,
-                                                              int Cout, int act, float slope) {
-  const long total = (long)N * H * W;
+                                                              int Cout, int act, float slope, int KH, int KW, int P, int Ho,
+                                                              int Wo) {
+  const long total = (long)N * Ho * Wo;
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(p % W);
-    const long r = p / W;
-    const int y = (int)(r % H);
+    const int x = (int)(p % Wo);
+    const long r = p / Wo;
+    const int y = (int)(r % Ho);
+    const long n = r / Ho;
     float acc[TCO] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    for (int t = 0; t < KH * KW; ++t) {
+      const int yy = y + t / KW - P, xx = x + t % KW - P;
       if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const float* zp = z + (p + (long)(t / 3 - 1) * W + (t % 3 - 1)) * ldz + t * Cout;
+        const float* zp = z + ((n * H + yy) * W + xx) * ldz + t * Cout;
 #pragma unroll
         for (int co = 0; co < TCO; ++co)
           if (co < Cout) acc[co] += zp[co];
@@ -205,22 +208,23 @@ __global__ __launch_bounds__(256) void thin_gather_fwd_tile_kernel(const float* 
   *reinterpret_cast<f32x4*>(out + (((size_t)n * H + by * 16 + ty) * W + bx * 16 + tx) * TCO) = o;
 }
 
-// dz[p][tap*Cout + co] = g[p - d(tap)][co], g = dout * act'(out)   (every element of dz is written, padding columns 0)
+// dz[p][tap*Cout + co] = g[p - d(tap)][co], g = dout * act'(out)   (every element of dz is written, padding columns 0);
+// p over the H x W input pixels, g over the Ho x Wo outputs
 __global__ __launch_bounds__(256) void thin_gather_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                               float* __restrict__ dz, int N, int H, int W, int ldz, int Cout,
-                                                              int act, float slope) {
+                                                              int act, float slope, int KH, int KW, int P, int Ho, int Wo) {
   const long total = (long)N * H * W;
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
     const int x = (int)(p % W);
     const long r = p / W;
     const int y = (int)(r % H);
+    const long n = r / H;
     float* zp = dz + p * ldz;
-    for (int k = 9 * Cout; k < ldz; ++k) zp[k] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const long q = p - (long)(t / 3 - 1) * W - (t % 3 - 1);
+    for (int k = KH * KW * Cout; k < ldz; ++k) zp[k] = 0.f;
+    for (int t = 0; t < KH * KW; ++t) {
+      const int yy = y - (t / KW - P), xx = x - (t % KW - P);
+      const bool ok = yy >= 0 && yy < Ho && xx >= 0 && xx < Wo;
+      const long q = (n * Ho + yy) * Wo + xx;
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
       if (ok) {
         g = *reinterpret_cast<const f32x4*>(dout + q * TCO);
@@ -414,7 +418,7 @@ int dsee_thin_gather_fwd(const float* z, const float* bias, float* out, int N, i
     return DSEE_OK;
   }
   thin_gather_fwd_kernel<<<(int)min(8192L, ((long)N * H * W + 255) / 256), 256, 0, st>>>(z, bias, out, N, H, W, ldz, Cout,
-                                                                                         act, slope);
+                                                                                         act, slope, 3, 3, 1, H, W);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -423,7 +427,31 @@ int dsee_thin_gather_bwd(const float* dout, const float* out, float* dz, int N, 
                          float slope, hipStream_t st) {
   DSEE_CHECK_ARG(dout && out && dz && Cout >= 1 && Cout <= TCO && ldz >= 9 * Cout);
   thin_gather_bwd_kernel<<<(int)min(8192L, ((long)N * H * W + 255) / 256), 256, 0, st>>>(dout, out, dz, N, H, W, ldz, Cout,
-                                                                                         act, slope);
+                                                                                         act, slope, 3, 3, 1, H, W);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+/* The general form (round 6): KH x KW taps, stride 1, padding `pad`; z [N,H,W,ldz] (ldz >= KH*KW*Cout), out / dout
+ * [N,Ho,Wo,4] with Ho = H + 2 pad - KH + 1.  The discriminator's last layer (256 -> 1, 4 x 4, padding 2: discriminator.py:78-96). */
+int dsee_thin_gather_k_fwd(const float* z, const float* bias, float* out, int N, int H, int W, int ldz, int Cout, int KH, int KW,
+                           int pad, int act, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(z && out && Cout >= 1 && Cout <= TCO && KH >= 1 && KW >= 1 && pad >= 0 && ldz >= KH * KW * Cout);
+  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+  DSEE_CHECK_ARG(Ho > 0 && Wo > 0);
+  thin_gather_fwd_kernel<<<(int)min(8192L, ((long)N * Ho * Wo + 255) / 256), 256, 0, st>>>(z, bias, out, N, H, W, ldz, Cout,
+                                                                                           act, slope, KH, KW, pad, Ho, Wo);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+int dsee_thin_gather_k_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int ldz, int Cout, int KH,
+                           int KW, int pad, int act, float slope, hipStream_t st) {
+  DSEE_CHECK_ARG(dout && out && dz && Cout >= 1 && Cout <= TCO && KH >= 1 && KW >= 1 && pad >= 0 && ldz >= KH * KW * Cout);
+  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+  DSEE_CHECK_ARG(Ho > 0 && Wo > 0);
+  thin_gather_bwd_kernel<<<(int)min(8192L, ((long)N * H * W + 255) / 256), 256, 0, st>>>(dout, out, dz, N, H, W, ldz, Cout,
+                                                                                         act, slope, KH, KW, pad, Ho, Wo);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

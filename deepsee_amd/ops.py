@@ -1003,33 +1003,43 @@ def _fusable_noise(x, w, stride, pad, ups, eps):
 
 class ThinGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z, bias, co, act):
+    def forward(ctx, z, bias, co, act, kh=3, kw=3, pad=1):
         n, h, w, ldz = z.shape
-        out = new(n, h, w, 4)
-        L.call("thin_gather_fwd", z, bias, out, n, h, w, ldz, co, act, LRELU_SLOPE)
+        ho, wo = h + 2 * pad - kh + 1, w + 2 * pad - kw + 1
+        out = new(n, ho, wo, 4)
+        if (kh, kw, pad) == (3, 3, 1):
+            L.call("thin_gather_fwd", z, bias, out, n, h, w, ldz, co, act, LRELU_SLOPE)
+        else:
+            L.call("thin_gather_k_fwd", z, bias, out, n, h, w, ldz, co, kh, kw, pad, act, LRELU_SLOPE)
         ctx.save_for_backward(out)
-        ctx.meta = (co, act, ldz, bias is not None)
+        ctx.meta = (co, act, ldz, bias is not None, kh, kw, pad, h, w)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (out,) = ctx.saved_tensors
-        co, act, ldz, has_bias = ctx.meta
-        n, h, w, _ = out.shape
+        co, act, ldz, has_bias, kh, kw, pad, h, w = ctx.meta
+        n = out.shape[0]
         dout = dout.contiguous()
         dz = new(n, h, w, ldz)
-        L.call("thin_gather_bwd", dout, out, dz, n, h, w, ldz, co, act, LRELU_SLOPE)
+        if (kh, kw, pad) == (3, 3, 1):
+            L.call("thin_gather_bwd", dout, out, dz, n, h, w, ldz, co, act, LRELU_SLOPE)
+        else:
+            L.call("thin_gather_k_bwd", dout, out, dz, n, h, w, ldz, co, kh, kw, pad, act, LRELU_SLOPE)
         db = None
         if has_bias and ctx.needs_input_grad[1]:
             g = torch.empty_like(dout)
             L.call("act_bwd", dout, out, g, C.c_long(dout.numel()), act, LRELU_SLOPE)
             db = channel_dot(g, None, co).clone()
-        return dz, db, None, None
+        return dz, db, None, None, None, None, None
 
 
 def _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
+    """Layers with <= 4 output channels as a (KH KW Cout)-output 1x1 GEMM + a gather: the to-RGB layer (3 x 3, padding 1) and --
+    round 6 -- the discriminator's last layer (4 x 4, padding 2: 16 outputs, within dsee_thin1x1_bwd's 32 rows)."""
     co, ci, kh, kw = w.shape
-    return (P().thin_gemm and kh == 3 and kw == 3 and stride == 1 and pad == 1 and ups == 0 and co <= 4 and res is None
+    shape_ok = (kh, kw, pad) == (3, 3, 1) or ((kh, kw, pad) == (4, 4, 2) and co * 16 <= 32)
+    return (P().thin_gemm and shape_ok and stride == 1 and ups == 0 and co <= 4 and res is None
             and noise is None and res_noise is None and x.shape[3] >= 128 and x.shape[3] % 32 == 0)
 
 
@@ -1046,9 +1056,10 @@ def conv2d(x, w, bias=None, res=None, stride=1, pad=1, ups=0, act=L.ACT_NONE, no
         in_act = 0
     if _thin_ok(x, w, res, stride, pad, ups, noise, res_noise):
         co, ci = w.shape[0], w.shape[1]
-        w27 = w.permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1)          # row tap*co_n + co (55 KB of parameter glue)
+        kh, kw = w.shape[2], w.shape[3]
+        w27 = w.permute(2, 3, 0, 1).reshape(kh * kw * co, ci, 1, 1)    # row tap*co_n + co (55 KB of parameter glue)
         z = Conv2d.apply(x, w27, None, None, 1, 0, 0, L.ACT_NONE, None, None, None, None, None, True, False, in_act)
-        return ThinGather.apply(z, bias, co, act)
+        return ThinGather.apply(z, bias, co, act, kh, kw, pad)
     if res_noise is not None and not _fusable_noise(x, w, stride, pad, ups, res_noise[1]):
         # (the shortcut's own node must see its gradient: no sink)
         res, res_noise, res_sink = UpNoise.apply(res, res_noise[0], res_noise[1], 0), None, None

@@ -323,6 +323,13 @@ int dsee_thin_gather_fwd(const float* z, const float* bias, float* out, int N, i
                          float slope, hipStream_t stream);
 int dsee_thin_gather_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int ldz, int Cout, int act,
                          float slope, hipStream_t stream);
+/* round 6: the general gather -- KH x KW taps, stride 1, padding `pad`, out / dout [N,Ho,Wo,4], Ho = H + 2 pad - KH + 1 -- so that
+ * the discriminator's last layer (256 -> 1 channels, 4 x 4, padding 2; discriminator.py:78-96, one of 32 MFMA columns as an
+ * implicit GEMM) runs as a 16-output 1x1 GEMM + a 16-point gather; its backward is dsee_thin1x1_bwd + this adjoint. */
+int dsee_thin_gather_k_fwd(const float* z, const float* bias, float* out, int N, int H, int W, int ldz, int Cout, int KH, int KW,
+                           int pad, int act, float slope, hipStream_t stream);
+int dsee_thin_gather_k_bwd(const float* dout, const float* out, float* dz, int N, int H, int W, int ldz, int Cout, int KH,
+                           int KW, int pad, int act, float slope, hipStream_t stream);
 /* Backward of the 27-output 1x1 GEMM the to-RGB layer runs as (y [M][ldz] = x [M][C] . w^T, w [K][C], K <= 32; sr.py:65,94):
  * dx [M][C] = dz w (NULL: skipped), dw [K][C] = dz^T x (NULL: skipped).  Laid out along the C input channels (a thread owns 4
  * channels, dz of a pixel is block-uniform): exact fp32 FMAs at HBM speed where the implicit-GEMM kernels fill 27 of 128 tile

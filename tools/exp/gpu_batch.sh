@@ -68,6 +68,11 @@ for l in open('gpurun_out/r06_bench_power_${BENCH_TAG:-default}.txt'):
       { timeout 300 python tools/exp/gemm_alternate.py gemm_f16x2_pre_w4; timeout 300 python tools/exp/gemm_alternate.py gemm_f16x2_pre; } 2>&1 | grep -v amdgpu.ids > $out ;;
     pytest)     # PYTEST_ARGS: a selection of the GPU suite
       DSEE_TEST_DURATIONS=gpurun_out/r06_durations.txt timeout ${PYTEST_TIMEOUT:-1500} python -m pytest $PYTEST_ARGS 2>&1 | grep -v amdgpu.ids | tail -${PYTEST_TAIL:-60} > $out ;;
+    mfma_power) # dense 16-bit MFMA rate the socket power cap allows (operands in registers, no memory traffic), rocm-smi beside it
+      { for a in "fp16 random" "bf16 random" "bf16 zeros"; do
+          ( sleep 2.5; rocm-smi -P -c 2>/dev/null | grep -E "Power \(W\)|sclk" | tr '\n' ' '; echo ) &
+          timeout 60 tools/exp/mfma_power_probe $a 4; wait
+        done; } > $out 2>&1 ;;
     bench)      # the driver's command
       timeout 900 python bench.py --steps 20 --warmup 5 > $out 2>gpurun_out/r06_bench.err ;;
     bench_quick)
