@@ -513,19 +513,31 @@ class NLayerD(nn.Module):
             attach(self, "model%d.0.0" % n, SNConvP(nf, prev, 4, False))
         attach(self, "model%d.0" % self.nl, ConvP(1, nf, 4))
 
-    def forward(self, x, training):
-        outs = []
+    def forward(self, x, training, x_detached=None):
+        """`x_detached` (round 6): a second batch segment that needs no gradient -- the real images of the GENERATOR step, whose
+        features enter the feature-matching loss detached (sr_model.py:547-564).  The reference stacks it on N behind the
+        generated images (sr_model.py:655-668); the discriminator has no batch statistics (InstanceNorm is per sample, SURVEY
+        B-8), so running it as its own no-grad pass on the SAME weights of this forward (one spectral-norm power iteration) gives
+        the same numbers and spares the backward pass the data gradients of a batch half whose upstream gradient is zero."""
         m0 = self.model0._modules["0"]
-        x = ops.conv2d(x, m0.weight, m0.bias, stride=2, pad=2, act=L.ACT_LRELU)
-        outs.append(x)
-        for n in range(1, self.nl):
-            m = getattr(self, "model%d" % n)._modules["0"]._modules["0"]
-            x = ops.conv2d(x, m.weight(training), None, stride=1 if n == self.nl - 1 else 2, pad=2)
-            x = ops.InstNormAct.apply(x, L.ACT_LRELU)
-            outs.append(x)
+        mids = [getattr(self, "model%d" % n)._modules["0"]._modules["0"].weight(training) for n in range(1, self.nl)]
         ml = getattr(self, "model%d" % self.nl)._modules["0"]
-        outs.append(ops.conv2d(x, ml.weight, ml.bias, stride=1, pad=2))
-        return outs
+
+        def run(x):
+            outs = []
+            x = ops.conv2d(x, m0.weight, m0.bias, stride=2, pad=2, act=L.ACT_LRELU)
+            outs.append(x)
+            for n in range(1, self.nl):
+                x = ops.conv2d(x, mids[n - 1], None, stride=1 if n == self.nl - 1 else 2, pad=2)
+                x = ops.InstNormAct.apply(x, L.ACT_LRELU)
+                outs.append(x)
+            outs.append(ops.conv2d(x, ml.weight, ml.bias, stride=1, pad=2))
+            return outs
+        if x_detached is None:
+            return run(x)
+        with torch.no_grad():
+            det = run(x_detached)
+        return run(x), det
 
 
 class MultiscaleDiscriminator(nn.Module):
@@ -538,21 +550,30 @@ class MultiscaleDiscriminator(nn.Module):
         for i in range(opt.num_D):
             self.add_module("discriminator_%d" % i, NLayerD(opt))
 
-    def forward(self, x, training):
+    def forward(self, x, training, x_detached=None):
+        """Returns the per-scale feature lists; with `x_detached` a pair (features of x, features of x_detached): see NLayerD."""
         if self._sn is None:
             self._sn = ops.SNGroup([getattr(getattr(self, "discriminator_%d" % i), "model%d" % n)._modules["0"]._modules["0"]
                                     for i in range(self.num_d)
                                     for n in range(1, getattr(self, "discriminator_%d" % i).nl)])
         self._sn.run(training)
         # the scales are independent given x (and its pooled copies): one branch per scale (ops.branches)
-        xs = [x]
+        xs, ds = [x], [x_detached]
         for i in range(1, self.num_d):
             xs.append(ops.AvgPool3s2.apply(xs[-1]))
+            if x_detached is not None:
+                with torch.no_grad():
+                    ds.append(ops.AvgPool3s2.apply(ds[-1]))
+            else:
+                ds.append(None)
         # (tensors made on this stream that the side branches read, forward and backward: the pooled inputs and the
         # spectral-normalised weights W / sigma of this forward)
-        shared = xs[1:] + list(self._sn.last)          # (SNGroup.last: the buffer all W / sigma are slices of + their maxima)
-        return ops.branches(*[(lambda i=i: getattr(self, "discriminator_%d" % i)(xs[i], training)) for i in range(self.num_d)],
-                            inputs=shared)
+        shared = xs[1:] + [t for t in ds[1:] if t is not None] + list(self._sn.last)   # (SNGroup.last: the buffer all W / sigma are slices of + their maxima)
+        res = ops.branches(*[(lambda i=i: getattr(self, "discriminator_%d" % i)(xs[i], training, ds[i])) for i in range(self.num_d)],
+                           inputs=shared)
+        if x_detached is None:
+            return res
+        return [r[0] for r in res], [r[1] for r in res]
 
 
 # ------------------------------------------------------------------------------------ VGG19 perceptual taps

@@ -299,15 +299,15 @@ class SRModel(nn.Module):
         else:
             pred, fx, fy = (ops.branches(*parts, inputs=[fake, d["image_hr"]]) + [None, None])[:3]
         n = fake.shape[0]
+        pred, pred_real = pred      # (the generated half with its graph, the real half without: discriminate(train_d=False))
         gan = 0
         for p in pred:
             gan = gan + ops.mean_loss(p[-1], None, ops.MODE_NEG, 1.0 / len(pred), valid_c=1, lo=0, hi=n)
         losses["GAN"] = gan
         if not opt.no_ganFeat_loss:
             terms = []
-            for p in pred:
-                for f in p[:-1]:
-                    real = f[n:].detach()
+            for p, pr in zip(pred, pred_real):
+                for f, real in zip(p[:-1], pr[:-1]):
                     terms.append(ops.mean_loss(f, real, ops.MODE_L1, opt.lambda_feat / len(pred), lo=0, hi=n))
             losses["GAN_Feat"] = _sum_terms(terms)
         if use_vgg:
@@ -332,14 +332,19 @@ class SRModel(nn.Module):
     def discriminate(self, labels, fake, real, train_d):
         """sr_model.py:655-683: one D pass over cat([fake; real]) on N.  In the generator step the D weights only
         need data gradients (their .grad is zeroed before use), so they enter detached."""
-        x = ops.DInput.apply(labels, fake, real)
         if train_d:
-            return self.netD(x, self.training)
+            return self.netD(ops.DInput.apply(labels, fake, real), self.training)
+        # generator step (round 6): the real half enters the losses detached (sr_model.py:547-564) -- it runs as a no-grad pass of
+        # its own on the same weights (networks.NLayerD.forward), and the data gradients of the backward pass cover the generated
+        # half only.  Returns (features of the generated images, features of the real images).
+        x = ops.DInput.apply(labels, fake)
+        with torch.no_grad():
+            xr = ops.DInput.apply(labels, real)
         req = [p.requires_grad for p in self.netD.parameters()]
         for p in self.netD.parameters():
             p.requires_grad_(False)
         try:
-            return self.netD(x, self.training)
+            return self.netD(x, self.training, xr)
         finally:
             for p, r in zip(self.netD.parameters(), req):
                 p.requires_grad_(r)
