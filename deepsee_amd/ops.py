@@ -310,6 +310,32 @@ def tensor_amax(t, cache=None):
     return a
 
 
+def _s2_parity_ok(geom, kh, kw):
+    return (P().dgrad_s2_parity and geom.mul == 2 and kh == 4 and kw == 4 and geom.off == -2 and geom.ups == 0 and geom.kdir == 1)
+
+
+def _dgrad_stride2_parity(g, w, geom, ci, amax_cache=None, exact=False):
+    """Data gradient of a 4 x 4 / stride 2 / padding 2 convolution (the discriminator's down-sampling layers,
+    discriminator.py:78-96) by output parity (round 6).  dx[2a + py] = dy[a + 1] w[py] + dy[a] w[py + 2] per dimension: each of
+    the four (py, px) classes of input pixels is a dense 2 x 2 / stride 1 convolution over dy with its own quarter of the taps,
+    all four with the SAME source window -- so they run as ONE convolution with 4 Cin output columns (K = 4 Cout instead of 16
+    Cout of which three quarters multiplied zeros: the general kernel reached 15-20 TFLOP/s of useful work) followed by a
+    depth-to-space copy."""
+    co = w.shape[0]
+    cin_s, n, h, wd = geom.Cin, geom.N, geom.Hi, geom.Wi
+    ha, wa = (h + 1) // 2, (wd + 1) // 2
+    wq = w if ci == cin_s else torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_s - ci))
+    # [co][c][a][py][b][px] -> [co][(py, px, c)][a][b]: tap (a, b) of parity class (py, px) is the forward tap (2 a + py, 2 b + px)
+    w4 = wq.reshape(co, cin_s, 2, 2, 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * cin_s, 2, 2)
+    if getattr(w, "dsee_amax", None) is not None:
+        w4.dsee_amax = w.dsee_amax                    # (a permutation of w: same maximum)
+    korder = 1 if geom.Cout % 32 == 0 else 0
+    gd = L.ConvGeom(n, geom.Ho, geom.Wo, geom.Cout, ha, wa, 4 * cin_s, 2, 2, 1, 1, -1, 0, 0, korder)
+    z = conv_raw(g, _pack_dgrad(w4, geom.Cout, korder), gd, amax_cache=amax_cache, exact=exact)
+    dx = z.view(n, ha, wa, 2, 2, cin_s).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * ha, 2 * wa, cin_s)
+    return dx[:, :h, :wd].contiguous() if (2 * ha != h or 2 * wa != wd) else dx.contiguous()
+
+
 def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0, amax_cache=None, exact=False):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
     if not exact and P().gemm_split and P().gemm_f16x2 and P().conv_f16x2_min_flop > 0 and _flops(geom) >= P().conv_f16x2_min_flop:
@@ -918,6 +944,8 @@ class Conv2d(torch.autograd.Function):
             dw, dx = _wino_wgrad(x, g, geom.N, geom.Hi, geom.Wi, geom.Cin, geom.Cout, co, ci, vkeep, w_for_dx=w, sums=sums)
         elif ctx.needs_input_grad[0] and ctx.wino:
             dx = _wino_conv(g, w, geom.N, geom.Ho, geom.Wo, geom.Cin, geom.Cout, True)
+        elif ctx.needs_input_grad[0] and not thin1 and _s2_parity_ok(geom, kh, kw):
+            dx = _dgrad_stride2_parity(g, w, geom, ci, amax_cache=getattr(ctx, "amax_cache", None), exact=ctx.exact)
         elif ctx.needs_input_grad[0] and not thin1:
             gd = L.geom_dgrad(geom)
             dxl = conv_raw(g, _pack_dgrad(w, geom.Cout, gd.korder), gd, amax_cache=getattr(ctx, "amax_cache", None),

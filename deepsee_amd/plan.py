@@ -50,6 +50,9 @@ class KernelPlan:
     # the pre-split NT GEMMs (forward / adjoint data gradient of the wide convolutions) on the one-wave-per-SIMD kernel of
     # csrc/gemm_w4.hip (128 x 128 wave tiles, one barrier per slab; round 6).  False: the 8-wave ping-pong kernel of rounds 2-5
     gemm_w4: bool = True
+    # data gradient of the 4x4 / stride-2 convolutions by output parity: one dense 2x2 convolution with 4 Cin output columns + a
+    # depth-to-space copy (False: the general strided-gather kernel, three quarters of whose MFMAs multiply zeros)
+    dgrad_s2_parity: bool = True
     # A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
     presplit_dm: bool = True
     # ... and the gamma/beta gradient of a SPADE/SEAN norm as well (False: fp32 dM from the norm backward's reduce pass)

@@ -484,6 +484,44 @@ def test_device_input_pipeline_kernels_bit_exact():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("n,cin,cout,h,k,stride,pad,bias", [
+    (2, 22, 32, 17, 4, 2, 2, True),       # the discriminator's first layer (19 + 3 channels stored as 24), odd size
+    (2, 32, 64, 19, 4, 2, 2, False),
+    (3, 64, 128, 33, 4, 2, 2, False),     # 33 -> 17: the two parity classes have 17 and 16 rows
+    (2, 64, 128, 64, 4, 2, 2, False),     # even size
+    (2, 256, 1, 10, 4, 1, 2, True),       # the discriminator's last layer: 16-output 1x1 GEMM + 16-point gather
+    (3, 256, 1, 35, 4, 1, 2, True)])
+def test_discriminator_layer_paths(n, cin, cout, h, k, stride, pad, bias):
+    """Round 6: the two special forms of the discriminator's convolutions (discriminator.py:78-96) through ops.conv2d against
+    F.conv2d autograd in float64 -- the data gradient of the 4 x 4 / stride-2 layers by output parity (one dense 2 x 2
+    convolution with 4 Cin output columns + depth-to-space; KernelPlan.dgrad_s2_parity) and the 1-channel last layer as a
+    (16 Cout)-output 1x1 GEMM + gather (dsee_thin_gather_k_fwd / _bwd + dsee_thin1x1_bwd).  Output, dx, dw, db <= 2e-5."""
+    from deepsee_amd import ops
+    g = gen(n * 1000 + cin + h)
+    x = torch.randn(n, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    x6, w6 = x.double().requires_grad_(), w.double().requires_grad_()
+    b6 = b.double().requires_grad_() if bias else None
+    y6 = F.conv2d(x6, w6, b6, stride=stride, padding=pad)
+    gy = torch.randn(y6.shape, generator=g)
+    y6.backward(gy.double())
+    xd = nhwc(x).requires_grad_()
+    wd = w.cuda().requires_grad_()
+    bd = b.cuda().requires_grad_() if bias else None
+    ops.PROFILE = prof = {}
+    y = ops.conv2d(xd, wd, bd, stride=stride, pad=pad)
+    y.backward(nhwc(gy))
+    torch.cuda.synchronize()
+    ops.PROFILE = None
+    assert tuple(y.shape[1:3]) == tuple(y6.shape[2:])
+    errs = {"y": rel(nchw(y.detach(), cout), y6.detach()), "dx": rel(nchw(xd.grad, cin), x6.grad), "dw": rel(wd.grad.cpu(), w6.grad)}
+    if bias:
+        errs["db"] = rel(bd.grad.cpu()[:cout], b6.grad)
+    print(errs, sorted(prof))
+    assert max(errs.values()) < 2e-5, errs
+
+
 def test_benchmark_shape_conv_vs_float64():
     """north_star's 1e-3 on outputs AND gradients at the benchmark's layer shape: the 512 -> 512 3x3 convolution at
     128^2 (Winograd F(4x4,3x3) + bf16x3: gemm3a 256x256 tiles forward / data gradient, gemm3t 256x128 tiles weight
