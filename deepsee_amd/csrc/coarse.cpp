@@ -69,6 +69,15 @@ int dsee_sean_norm_fwd(const uint8_t* labels, int lab_h, int lab_w, int shift, i
     dsee_set_error("dsee_sean_norm_fwd: C %% 64 == 0 required (C = %d)", C);
     return DSEE_EUNSUPPORTED;
   }
+  if (N <= 0 || H % 4 != 0 || W % 4 != 0 || ((H / 4) * (W / 4)) % 64 != 0) {
+    dsee_set_error("dsee_sean_norm_fwd: H and W multiples of 4 with (H/4) (W/4) %% 64 == 0 required (the fused kernel owns blocks of "
+                   "64 Winograd tiles of one image): N = %d, H = %d, W = %d", N, H, W);
+    return DSEE_EUNSUPPORTED;
+  }
+  if (label_nc < 1 || (table != nullptr && label_nc > 32)) {
+    dsee_set_error("dsee_sean_norm_fwd: label_nc = %d (the style-table path stores the one-hot label in 32 channels)", label_nc);
+    return DSEE_EUNSUPPORTED;
+  }
   if (!training && !(running_mean && running_var)) {
     dsee_set_error("dsee_sean_norm_fwd: evaluation mode needs the running statistics");
     return DSEE_EINVAL;
@@ -129,7 +138,10 @@ static int wino_conv3x3(const float* h, const float* amax_h, const float* w, con
                         float* y, int act, float slope, int N, int H, int W, int C, float* amax_w, void* v2, void* u2, float* m,
                         hipStream_t stream) {
   const long T = (long)N * (H / 4) * (W / 4);
-  if (hipMemsetAsync(amax_w, 0, kAmaxFloats * sizeof(float), stream) != hipSuccess) return DSEE_ELAUNCH;
+  if (hipMemsetAsync(amax_w, 0, kAmaxFloats * sizeof(float), stream) != hipSuccess) {
+    dsee_set_error("dsee_spade_resblock_fwd: hipMemsetAsync (max |w|) failed");
+    return DSEE_ELAUNCH;
+  }
   DSEE_TRY(dsee_absmax(w, (long)C * C * 9, amax_w, stream));
   DSEE_TRY(dsee_wino43_weights(w, static_cast<float*>(u2), C, C, 0, 2, amax_w, stream));
   DSEE_TRY(dsee_wino43_input_f16x2(h, v2, N, H, W, C, amax_h, DSEE_WINO_V_BOUND, stream));
@@ -204,7 +216,10 @@ int dsee_spade_resblock_fwd(const dsee_norm_layer* norm_0, const float* w_conv_0
   const float* in = x;
   for (int i = 0; i < 2; ++i) {
     const dsee_norm_layer* nl = norms[i];
-    if (hipMemsetAsync(amax_h, 0, kAmaxFloats * sizeof(float), stream) != hipSuccess) return DSEE_ELAUNCH;
+    if (hipMemsetAsync(amax_h, 0, kAmaxFloats * sizeof(float), stream) != hipSuccess) {
+      dsee_set_error("dsee_spade_resblock_fwd: hipMemsetAsync (max |h|) failed");
+      return DSEE_ELAUNCH;
+    }
     DSEE_TRY(dsee_sean_norm_fwd(labels, lab_h, lab_w, shift, label_nc, nl->w_shared, nl->b_shared, nl->w2a, nl->table,
                                 nl->bias_packed, in, nl->running_mean, nl->running_var, training, eps, momentum, nl->add_one,
                                 slope, h, nullptr, nullptr, mean, invstd, amax_h, N, H, W, C, ws + l.norm, norm_bytes, stream));

@@ -22,6 +22,10 @@
 #endif
 // interleave pattern of the memory work between the MFMAs (0: none, the compiler's own order; 1: DMA first, then reads;
 // 2: reads first, then DMA)
+// start-up stagger of the blocks of an XCD, in 64ths of a tile (0: none)
+#ifndef DSEE_W4_STAGGER
+#define DSEE_W4_STAGGER 0
+#endif
 #ifndef DSEE_W4_SCHED
 #define DSEE_W4_SCHED 1
 #endif
@@ -211,6 +215,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(W4Args a) {
     }
   };
 
+#if DSEE_W4_STAGGER
+  // Every block walks tiles of the same length, so without this all 256 CUs reach their tile stores in the same microsecond and
+  // the 64 MB burst queues behind the fabric (10 k cycles per tile against 4 k at a CU's own store rate).  Blocks of an XCD start
+  // up to DSEE_W4_STAGGER/64 of a tile apart (block b runs on XCD b % 8; 32 phases).
+  {
+    const int phase = (blockIdx.x >> 3) & 31;
+    const int units = phase * a.nk * DSEE_W4_STAGGER / 64;     // units of ~1 k cycles (a slab is ~2.1 k cycles)
+    for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   // ---- prologue: slabs 0 .. 4 requested, slab 0 landed and published, its fragments requested
   set_base();
 #pragma unroll

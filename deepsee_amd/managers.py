@@ -73,8 +73,14 @@ class TrainerManager(BaseManager):
     def close_all(cls):
         """close() every live manager of this process: captured graphs and their memory pools, static input buffers and the
         C-ABI communicators are released now instead of whenever the garbage collector gets to them."""
+        errors = []
         for tm in list(cls._live):
-            tm.close()
+            try:
+                tm.close()
+            except Exception as e:           # (one manager's failing communicator must not keep the others' graphs alive)
+                errors.append(e)
+        if errors:
+            raise errors[0]
 
     def __init__(self, opt):
         super().__init__(opt, create_model=True)
@@ -93,11 +99,7 @@ class TrainerManager(BaseManager):
         self.max_graph_shapes = int(getattr(opt, "max_graph_shapes", 4))
         self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0, "evicted_shapes": 0}
         self.dp_comm = None
-        import atexit
-        import weakref
-        ref = weakref.ref(self)
-        atexit.register(lambda: ref() is not None and ref().close())
-        TrainerManager._live.add(self)
+        TrainerManager._live.add(self)       # (closed by the ONE module-level atexit hook below: close_all)
 
     def get_logs(self):
         return {**self.logs, **self.sr_model_on_one_gpu.get_logs()}
@@ -187,6 +189,11 @@ class TrainerManager(BaseManager):
         noise = model.noise
         if not hasattr(noise, "step"):            # (a replayed oracle tape: no graphs)
             return step_fn(data)
+        if multi and model.plan.sync_bn is not None and not self.dp_in_graph:
+            # opt.sync_bn in a multi-rank run: the SyncBN all-gather / all-reduce sit INSIDE the step function, i.e. they would be
+            # captured into the hipGraph -- and capturing RCCL operations is what dp_graph_collectives is off for (intermittent
+            # abort inside the HIP runtime on this stack).  Such a run stays eager.
+            return step_fn(data)
         sig = self._shape_signature(data)
         self._touch_signature(sig)
         # (the plan is part of the key: a graph replays the kernels chosen under the plan it was captured with)
@@ -219,7 +226,6 @@ class TrainerManager(BaseManager):
             rec = {"graph": g, "losses": losses, "generated": generated, "pinned": pinned, "eager_opt": eager_opt,
                    "grads": [p.grad for p in optim.params], "full": model.last_encoded_style_is_full,
                    "noisy": model.last_encoded_style_is_noisy,
-                   "out_losses": {k: torch.empty_like(v) for k, v in losses.items()},
                    "out_generated": None if generated is None else torch.empty_like(generated),
                    "logs": logged, "out_logs": {k: torch.empty_like(v) for k, v in logged.items()}}
             self._graphs[key] = rec
@@ -234,8 +240,13 @@ class TrainerManager(BaseManager):
             for p, g in zip(optim.params, rec["grads"]):   # the gradient tensors this graph writes (static addresses)
                 p.grad = g
             optim.step(clip=self.opt.gradient_clip)
-        for k, v in rec["losses"].items():
-            rec["out_losses"][k].copy_(v)
+        # The loss scalars are handed out as FRESH tensors every step, like the reference's (a caller that accumulates or keeps
+        # them across iterations must not see a later replay's values): one stacked copy + views, not one per term.
+        # The generated image (and the logged tensors) stay in the per-graph buffers out_generated / out_logs, overwritten by the
+        # next replay of the same graph key -- the aliasing contract INTEGRATION.md states; clone() what must outlive a step.
+        keys = list(rec["losses"])
+        fresh = torch.stack([rec["losses"][k].reshape(()) for k in keys]) if keys else None
+        out_losses = {k: fresh[i].reshape(rec["losses"][k].shape) for i, k in enumerate(keys)}
         if rec["generated"] is not None:
             rec["out_generated"].copy_(rec["generated"])
         for k, v in rec["logs"].items():
@@ -243,7 +254,7 @@ class TrainerManager(BaseManager):
             if hasattr(v, "dsee_layout"):
                 rec["out_logs"][k].dsee_layout = v.dsee_layout
             model.logs[k] = rec["out_logs"][k]
-        return rec["out_losses"], rec["out_generated"]
+        return out_losses, rec["out_generated"]
 
     def _touch_signature(self, sig):
         """LRU bookkeeping of the batch shapes that own graphs: a shape beyond `max_graph_shapes` evicts the least recently
@@ -322,3 +333,15 @@ class TrainerManager(BaseManager):
 import weakref as _weakref
 
 TrainerManager._live = _weakref.WeakSet()
+
+
+def _close_all_at_exit():
+    try:
+        TrainerManager.close_all()
+    except Exception as e:      # (interpreter shutdown: report, do not raise into atexit's own traceback printer)
+        import sys
+        print("deepsee_amd: closing the managers at exit failed: %r" % (e,), file=sys.stderr)
+
+
+import atexit as _atexit
+_atexit.register(_close_all_at_exit)
