@@ -705,6 +705,63 @@ int dsee_spade_resblock_fwd(const dsee_norm_layer* norm_0, const float* w_conv_0
                             int out_act, int training, float eps, float momentum, float slope, int N, int H, int W, int C,
                             void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+/* ---- round 6: the TRAINING pair of the hot block (SURVEY 7 "whole resblock fwd/bwd"; architecture.py:75-147 as configs[1] trains
+ * it: norm_0 -> LeakyReLU -> conv_0 -> noise_middle -> norm_1 -> LeakyReLU -> conv_1, + the shortcut x + noise_skip(x); x is what
+ * noise_in / the upsample in front of the block left -- dsee_upsample_noise_rng_fwd).
+ *   dsee_spade_resblock_train_fwd  runs the forward and keeps what the backward needs in `saved` (dsee_spade_resblock_saved_bytes:
+ *       per norm the embedding, the modulation factor, the LeakyReLU sign mask, statistics, the split transform of the embedding
+ *       and four operand maxima; conv_0's output; the split transforms of both convolutions' inputs -- 0.64 GB at N = 8, 64 x 64,
+ *       C = 512).  NoiseInjection draws are Philox streams (seed, offset) regenerated in registers by the output transforms
+ *       (dsee_rng_set_epoch applies); noise == NULL or a NULL weight: no injection.  norm_1's batch statistics come from the rows
+ *       conv_0's output transform writes (dsee_wino43_output_stats): no pass over conv_0's output.
+ *   dsee_spade_resblock_bwd  runs the whole backward pass from `saved`: dout [N,H,W,C] = dL/d(out) with its maximum amax_dout
+ *       (2048-float slot: dsee_absmax, or the amax_dx of the block behind), -> dx and max |dx| (amax_dx, 2048 floats), and every
+ *       parameter gradient whose pointer in `grads` is not NULL: the convolutions' EFFECTIVE weights (apply
+ *       dsee_spectral_norm_bwd for weight_orig) and biases, the two NoiseInjection weights, per norm mlp_shared (dw_shared,
+ *       db_shared: give both or neither for SPADE), the packed gamma|beta weights dw2a [2C][128][3][3], the style table dtable
+ *       [N][9][2C][32] (SEAN), and dgamma_beta_sums [2][C] = the per-channel sums of the gamma / beta gradients (the bias
+ *       gradient in channel order; dsee_sean_pack_bwd maps it to the packed rows).
+ * Both sequence the launches deepsee_amd/ops.py makes on the pre-split fp32 path (same kernels, same operands, same order): the
+ * results are bit-identical to the Python module's (tests/test_gpu_ops.py::test_coarse_resblock_training_pair).  Shapes the pre-split
+ * kernels do not tile are refused (DSEE_EUNSUPPORTED): C a power of two >= 256, N (H/4) (W/4) % 256 == 0, (H/4) (W/4) % 64 == 0,
+ * (36 T / 256) (C / 256) >= 512.  Nothing is allocated, the stream is never synchronised. */
+typedef struct dsee_block_noise {
+  const float* w_middle;  /* [C] noise_middle.weight (architecture.py:111-112) or NULL */
+  uint64_t seed_middle, offset_middle;
+  const float* w_skip;    /* [C] noise_skip.weight (architecture.py:133-134) or NULL */
+  uint64_t seed_skip, offset_skip;
+} dsee_block_noise;
+typedef struct dsee_norm_grads {
+  float* dw_shared;        /* [128][label_nc][3][3] */
+  float* db_shared;        /* [128] */
+  float* dw2a;             /* [2C][128][3][3], packed rows */
+  float* dtable;           /* [N][9][2C][32] (SEAN) */
+  float* dgamma_beta_sums; /* [2][C] */
+} dsee_norm_grads;
+typedef struct dsee_block_grads {
+  dsee_norm_grads norm_0, norm_1;
+  float* dw_conv_0;        /* [C][C][3][3] */
+  float* db_conv_0;        /* [C] */
+  float* dw_conv_1;
+  float* db_conv_1;
+  float* dw_noise_middle;  /* [C] */
+  float* dw_noise_skip;    /* [C] */
+} dsee_block_grads;
+size_t dsee_spade_resblock_saved_bytes(int N, int H, int W, int C, int label_nc, int has_table);
+size_t dsee_spade_resblock_train_fwd_workspace(int N, int H, int W, int C, int label_nc, int has_table);
+int dsee_spade_resblock_train_fwd(const dsee_norm_layer* norm_0, const float* w_conv_0, const float* b_conv_0,
+                                  const dsee_norm_layer* norm_1, const float* w_conv_1, const float* b_conv_1,
+                                  const dsee_block_noise* noise, const uint8_t* labels, int lab_h, int lab_w, int shift,
+                                  int label_nc, const float* x, float* out, float eps, float momentum, float slope, int N, int H,
+                                  int W, int C, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                  hipStream_t stream);
+size_t dsee_spade_resblock_bwd_workspace(int N, int H, int W, int C, int label_nc, int has_table, int lab_h, int lab_w, int shift);
+int dsee_spade_resblock_bwd(const dsee_norm_layer* norm_0, const float* w_conv_0, const dsee_norm_layer* norm_1,
+                            const float* w_conv_1, const dsee_block_noise* noise, const uint8_t* labels, int lab_h, int lab_w,
+                            int shift, int label_nc, const float* x, const float* dout, const float* amax_dout,
+                            const dsee_block_grads* grads, float* dx, float* amax_dx, float slope, int N, int H, int W, int C,
+                            const void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

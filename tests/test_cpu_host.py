@@ -59,6 +59,19 @@ def test_coarse_entry_points_validate_before_they_launch():
     rc = so.dsee_spade_resblock_fwd(*([None] * 6), None, 256, 256, 0, 19, None, None, 0, 1, 1e-5, 0.1, 0.2, 8, 256, 256, 512, None,
                                     0, None)
     assert rc == -1 and b"NULL argument" in so.dsee_last_error()
+    # round 6: the training pair -- saved area and workspaces sized on the host, NULL / shape validation before any HIP call
+    sb = so.dsee_spade_resblock_saved_bytes(8, 64, 64, 512, 19, 1)
+    t64 = 8 * 16 * 16
+    assert sb >= 3 * 8 * 64 * 64 * 512 * 4 + 2 * 36 * t64 * 512 * 4 + 2 * 36 * t64 * 160 * 4 and sb < 0.7e9
+    assert so.dsee_spade_resblock_saved_bytes(8, 64, 64, 512, 19, 0) < sb
+    assert so.dsee_spade_resblock_train_fwd_workspace(8, 64, 64, 512, 19, 1) > 36 * t64 * 512 * 4
+    assert so.dsee_spade_resblock_bwd_workspace(8, 64, 64, 512, 19, 1, 256, 256, 2) > 36 * t64 * 1024 * 4
+    assert len(so.dsee_spade_resblock_train_fwd.argtypes) == 26 and len(so.dsee_spade_resblock_bwd.argtypes) == 26
+    rc = so.dsee_spade_resblock_train_fwd(*([None] * 8), 256, 256, 2, 19, None, None, 1e-5, 0.1, 0.2, 8, 64, 64, 512, None, 0, None, 0,
+                                          None)
+    assert rc == -1 and b"NULL argument" in so.dsee_last_error()
+    rc = so.dsee_spade_resblock_bwd(*([None] * 6), 256, 256, 2, 19, *([None] * 6), 0.2, 8, 64, 64, 512, None, 0, None, 0, None)
+    assert rc == -1 and b"NULL argument" in so.dsee_last_error()
 
 
 def test_ctypes_prototypes_come_from_the_header():

@@ -975,3 +975,154 @@ def test_coarse_spade_resblock_fwd_matches_the_module():
         assert rel(d["rv"].cpu(), nm.param_free_norm.running_var.cpu()) < 1e-5
     with pytest.raises(L.DseeError, match="256 x 128 tiles"):       # shapes the pre-split GEMM does not tile are refused
         L.call("spade_resblock_fwd", *args[:18], N, 32, 32, Cc, ws, nbytes)
+
+
+@pytest.mark.parametrize("kind", ["sean", "spade"])
+def test_coarse_resblock_training_pair(kind):
+    """Round 6 (SURVEY 7 "whole resblock fwd/bwd"): dsee_spade_resblock_train_fwd + dsee_spade_resblock_bwd -- two C calls run the
+    hot block of configs[1] as it trains (architecture.py:75-147: two SPADE / SEAN norms on the fused kernel, two Winograd
+    convolutions on pre-split operands, noise_middle in conv_0's output transform, the shortcut x + noise_skip(x) in conv_1's)
+    forward AND backward, from raw tensors, a caller-owned `saved` area and workspaces -- against the Python module's own
+    launches at the benchmark's channel count (512 channels, 64 x 64, N = 8: the shapes at which ops.py takes the pre-split
+    path): output, dx and every parameter gradient BIT-IDENTICAL (same kernels, same operands, same order), running statistics
+    advanced alike."""
+    import ctypes as C
+    from deepsee_amd import ops, lib as L, networks as Nw
+    from deepsee_amd.options import make_opt
+    N, Cc, R, Lc, S, H = 8, 512, 64, 19, 128, 128
+    g = gen(17 + len(kind))
+    opt = make_opt(ngf=Cc // 16, add_noise=True, start_size=8, crop_size=H, load_size=H, batchSize=N)
+    blk = Nw.SPADEResnetBlock(Cc, opt, kind)
+    blk.load_state_dict({k: O.recipe_tensor("coarse_train_" + kind, k, v.shape, 1.0) for k, v in blk.state_dict().items()})
+    blk.cuda()
+    label = F.interpolate(torch.randint(0, Lc, (N, 1, 8, 8), generator=g).float(), size=(H, H), mode="nearest")
+    labels = ops.Labels(ops.label_to_u8(label.cuda()), Lc)
+    style = (torch.rand(N, Lc, S, generator=g) * 2 - 1).cuda()
+    x = nhwc(torch.randn(N, Cc, R, R, generator=g)).requires_grad_()
+    gout = nhwc(torch.randn(N, Cc, R, R, generator=g))
+    noise = Nw.DeviceNoise(5)
+    noise.begin_step()
+    shp = (N, R, R, Cc)
+    eps_mid, eps_skip = noise.normal_nhwc(shp, "blk.noise_middle"), noise.normal_nhwc(shp, "blk.noise_skip")
+    w_mid = torch.randn(Cc, generator=g).cuda().requires_grad_()
+    w_skip = torch.randn(Cc, generator=g).cuda().requires_grad_()
+    w0 = blk.conv_0.weight(True).detach().clone().requires_grad_()
+    w1 = blk.conv_1.weight(True).detach().clone().requires_grad_()
+    b0, b1 = blk.conv_0.bias, blk.conv_1.bias
+    norms = []
+    fwd = ops.SeanNormTable._forward
+
+    def norm_spy(ctx, x_, w_sh, b_sh, w2a, table, b2, rm, rv, labels_, shift, training_, add_one, grad_sink=None, cat_ups=0):
+        for t in (w2a, table, b2):
+            if t is not None and t.requires_grad:
+                t.retain_grad()
+        norms.append(dict(w_sh=w_sh, b_sh=b_sh, w2a=w2a, table=table, b2=b2, rm=rm.clone(), rv=rv.clone(), shift=shift,
+                          add_one=add_one, mod_rm=rm, mod_rv=rv))
+        return fwd(ctx, x_, w_sh, b_sh, w2a, table, b2, rm, rv, labels_, shift, training_, add_one, grad_sink, cat_ups)
+
+    ops.SeanNormTable._forward = staticmethod(norm_spy)
+    try:
+        # SPADEResnetBlock.forward from the block's (already noised / upsampled) input on, with leaf effective weights
+        sink = ops.GradSink()
+        h = blk.norm_0(x, labels, style, True, sink)
+        dxm = ops.conv2d(h, w0, b0, noise=(w_mid, eps_mid), stats=True)
+        h = blk.norm_1(dxm, labels, style, True)
+        want = ops.conv2d(h, w1, b1, res=x, act=L.ACT_NONE, res_noise=(w_skip, eps_skip), res_sink=sink)
+    finally:
+        ops.SeanNormTable._forward = staticmethod(fwd)
+    assert len(norms) == 2
+    ops.tag_amax(gout, ops.tensor_amax(gout))
+    want.backward(gout)
+    torch.cuda.synchronize()
+
+    class NormLayer(C.Structure):
+        _fields_ = [(k, C.c_void_p) for k in ("w_shared", "b_shared", "w2a", "table", "bias_packed", "running_mean",
+                                              "running_var")] + [("add_one", C.c_float)]
+
+    class BlockNoise(C.Structure):
+        _fields_ = [("w_middle", C.c_void_p), ("seed_middle", C.c_uint64), ("offset_middle", C.c_uint64),
+                    ("w_skip", C.c_void_p), ("seed_skip", C.c_uint64), ("offset_skip", C.c_uint64)]
+
+    class NormGrads(C.Structure):
+        _fields_ = [(k, C.c_void_p) for k in ("dw_shared", "db_shared", "dw2a", "dtable", "dgamma_beta_sums")]
+
+    class BlockGrads(C.Structure):
+        _fields_ = [("norm_0", NormGrads), ("norm_1", NormGrads)] + [(k, C.c_void_p) for k in
+                    ("dw_conv_0", "db_conv_0", "dw_conv_1", "db_conv_1", "dw_noise_middle", "dw_noise_skip")]
+
+    has_t = norms[0]["table"] is not None
+    keep = []
+
+    def dev(t):
+        t = t.detach().contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    def layer(d):
+        return NormLayer(dev(d["w_sh"]), dev(d["b_sh"]), dev(d["w2a"]), dev(d["table"]) if has_t else None, dev(d["b2"]),
+                         d["rm"].data_ptr(), d["rv"].data_ptr(), float(d["add_one"]))
+
+    n0, n1 = layer(norms[0]), layer(norms[1])
+    bn = BlockNoise(w_mid.data_ptr(), eps_mid.seed, eps_mid.offset, w_skip.data_ptr(), eps_skip.seed, eps_skip.offset)
+    lib = L.lib()
+    sbytes = lib.dsee_spade_resblock_saved_bytes(N, R, R, Cc, Lc, int(has_t))
+    fbytes = lib.dsee_spade_resblock_train_fwd_workspace(N, R, R, Cc, Lc, int(has_t))
+    shift = norms[0]["shift"]
+    bbytes = lib.dsee_spade_resblock_bwd_workspace(N, R, R, Cc, Lc, int(has_t), labels.h, labels.w, shift)
+    saved = torch.empty(sbytes, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(fbytes, bbytes), dtype=torch.uint8, device="cuda")
+    out = torch.empty_like(x)
+    xd = x.detach()
+    w0d, w1d = w0.detach(), w1.detach()
+    eps_mid.bind()
+    L.call("spade_resblock_train_fwd", C.byref(n0), w0d, b0.detach(), C.byref(n1), w1d, b1.detach(), C.byref(bn), labels.t, labels.h,
+           labels.w, shift, Lc, xd, out, 1e-5, 0.1, 0.2, N, R, R, Cc, saved, C.c_size_t(sbytes), ws, C.c_size_t(ws.numel()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, want.detach()), rel(out.cpu(), want.detach().cpu())
+    for d in norms:
+        assert torch.equal(d["rm"], d["mod_rm"]) and torch.equal(d["rv"], d["mod_rv"])
+    # ---- backward
+    rows = norms[0]["w2a"].shape[0]
+
+    def ngrads(d):
+        z = dict(dw_sh=torch.full_like(d["w_sh"].detach(), float("nan")), db_sh=torch.full_like(d["b_sh"].detach(), float("nan")),
+                 dw2a=torch.full((rows, 128, 3, 3), float("nan"), device="cuda"),
+                 dtable=torch.full((N, 9, rows, 32), float("nan"), device="cuda") if has_t else None,
+                 dsum=torch.full((2, Cc), float("nan"), device="cuda"))
+        keep.append(z)
+        return z, NormGrads(z["dw_sh"].data_ptr(), z["db_sh"].data_ptr(), z["dw2a"].data_ptr(),
+                            z["dtable"].data_ptr() if has_t else None, z["dsum"].data_ptr())
+
+    g0, ng0 = ngrads(norms[0])
+    g1, ng1 = ngrads(norms[1])
+    cg = {k: torch.full_like(v, float("nan")) for k, v in dict(dw0=w0d, db0=b0.detach(), dw1=w1d, db1=b1.detach(), dwm=w_mid.detach(),
+                                                              dws=w_skip.detach()).items()}
+    bg = BlockGrads(ng0, ng1, cg["dw0"].data_ptr(), cg["db0"].data_ptr(), cg["dw1"].data_ptr(), cg["db1"].data_ptr(),
+                    cg["dwm"].data_ptr(), cg["dws"].data_ptr())
+    dx = torch.full_like(xd, float("nan"))
+    amax_dx = torch.zeros(2048, device="cuda")
+    L.call("spade_resblock_bwd", C.byref(n0), w0d, C.byref(n1), w1d, C.byref(bn), labels.t, labels.h, labels.w, shift, Lc, xd, gout,
+           gout.dsee_amax, C.byref(bg), dx, amax_dx, 0.2, N, R, R, Cc, saved, C.c_size_t(sbytes), ws, C.c_size_t(ws.numel()))
+    torch.cuda.synchronize()
+    checks = {"dx": (dx, x.grad), "dw_conv_0": (cg["dw0"], w0.grad), "dw_conv_1": (cg["dw1"], w1.grad),
+              "db_conv_0": (cg["db0"], b0.grad), "db_conv_1": (cg["db1"], b1.grad),
+              "dw_noise_middle": (cg["dwm"], w_mid.grad), "dw_noise_skip": (cg["dws"], w_skip.grad)}
+    idx, _ = ops.packed_perm(Cc, "cuda")
+    for i, (d, z) in enumerate(zip(norms, (g0, g1))):
+        checks["norm_%d.dw_shared" % i] = (z["dw_sh"], d["w_sh"].grad)
+        checks["norm_%d.db_shared" % i] = (z["db_sh"], d["b_sh"].grad)
+        checks["norm_%d.dw2a" % i] = (z["dw2a"], d["w2a"].grad)
+        if has_t:
+            checks["norm_%d.dtable" % i] = (z["dtable"], d["table"].grad)
+        packed = torch.cat([z["dsum"].reshape(-1), torch.zeros(1, device="cuda")]).index_select(0, idx)
+        checks["norm_%d.dbias_packed" % i] = (packed, d["b2"].grad)
+    bad = {k: rel(a.cpu(), b.cpu()) for k, (a, b) in checks.items() if b is None or not torch.equal(a, b)}
+    print("coarse training pair (%s): %d tensors compared, not bit-identical: %s" % (kind, len(checks), bad))
+    assert not bad, bad
+    assert float(amax_dx.max()) == float(x.grad.abs().max())
+    blk.zero_grad()
+    # shapes the pre-split kernels do not tile are refused, not mis-computed
+    with pytest.raises(L.DseeError, match="pre-split training path"):
+        L.call("spade_resblock_train_fwd", C.byref(n0), w0d, b0.detach(), C.byref(n1), w1d, b1.detach(), C.byref(bn), labels.t,
+               labels.h, labels.w, shift + 1, Lc, xd, out, 1e-5, 0.1, 0.2, N, 32, 32, Cc, saved, C.c_size_t(sbytes), ws,
+               C.c_size_t(ws.numel()))
