@@ -1760,7 +1760,7 @@ class SeanNormTable(torch.autograd.Function):
                 # keeps the backward pass on `out`)
                 smask = (torch.empty(n * h * w * (c // 32), dtype=torch.int32, device=x.device)
                          if (need_scale and P().sign_mask and (c & (c - 1)) == 0) else None)
-                L.call("spade_fused_fwd_f16p" if pk else "spade_fused_fwd", v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
+                L.call("spade_fused_fwd_f16p" if pk else ("spade_fused_fwd_w4" if P().fused_w4 else "spade_fused_fwd"), v2, u, ac, FUSED_V_BOUND, ua, b2.contiguous(), x, mean, invstd, out,
                        scale if need_scale else None, n, h, w, c, rows, ld, n if has_t else 1, float(add_one), LRELU_SLOPE,
                        hm, xm, smask)
                 tag_amax(out, hm)

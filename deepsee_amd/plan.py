@@ -75,6 +75,14 @@ class KernelPlan:
     fuse_dm: bool = True
     # the fused SPADE / SEAN forward (dsee_spade_fused_fwd; False: GEMM + wino43_output_modulate)
     fused_norm: bool = True
+    # ... on the one-wave-per-SIMD kernel (csrc/spade_fused_w4.hip, round 6: 4 waves x four 16x16 blocks, every MFMA followed by its
+    # share of the fragment reads / LDS-DMA requests / fold work in program order, piece-granular ring with 2 NP - 1 pieces in
+    # flight).  Bit-identical to the 8-wave kernel of rounds 3-5 and measured at the SAME speed stand-alone (2.22 vs 2.23 ms at
+    # N = 8, 256^2, K = 160; 1.83 vs 1.87 at K = 128) and in the step (88.1 ms either way): with a different issue structure AND a
+    # three times deeper request window the time does not move, removing the requests takes 0.8 ms off both -- the kernel is bound
+    # by what the L2 -> LDS path delivers to a 64 x 64 block, not by how the block issues it (profiles/r06_fused_w4*.txt).  Off by
+    # default (the 8-wave kernel also serves the 16-bit storage mode); kept under the same tests.
+    fused_w4: bool = False
     # the fused forward also writes the LeakyReLU branch of h as a bit mask ([pixel][C/32] words) and the two passes of the norm
     # backward read it instead of h (False: they read h, 32x the bytes, for its sign)
     sign_mask: bool = True

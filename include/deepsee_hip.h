@@ -186,6 +186,13 @@ int dsee_modulate_bwd_reduce_wino_f16p(const float* dh, const float* h, const fl
                                        int H, int W, int C, float slope, float* workspace, const float* amax_g, float bound,
                                        const uint32_t* sign_mask,
         hipStream_t stream);
+/* round 6: dsee_spade_fused_fwd on the one-wave-per-SIMD kernel of csrc/spade_fused_w4.hip (4 waves x four 16 x 16 blocks, every
+ * MFMA followed by its share of the fragment reads, LDS-DMA requests and the fold / Y-update VALU work; 256 AGPR-resident output
+ * accumulators per lane): same arguments, bit-identical results.  Two-term fp16x2 operands, K = 128 or 160. */
+int dsee_spade_fused_fwd_w4(const void* V2, const void* U2, const float* amax_cat, float v_bound, const float* amax_u,
+                            const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
+                            float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,
+                            float slope, float* amax_h, float* amax_xhat, uint32_t* sign_mask, hipStream_t stream);
 int dsee_spade_fused_fwd_f16p(const void* V1, const void* U1, const float* amax_cat, float v_bound, const float* amax_u,
                               const float* bias_packed, const float* x, const float* mean, const float* invstd, float* out_h,
                               float* out_scale, int N, int H, int W, int C, int rows, int K, int groups, float add_one,

@@ -687,7 +687,7 @@ def test_pipelined_gemms_with_poisoned_lds(mode):
             assert torch.equal(out, first)
 
 
-@pytest.mark.parametrize("waves", [8, 16])
+@pytest.mark.parametrize("waves", [8, 16, 4])
 @pytest.mark.parametrize("packed", [False, True], ids=["f16x2", "f16p"])
 @pytest.mark.parametrize("n,h,c,per_image,with_scale", [(2, 32, 64, True, True), (1, 64, 128, False, True),
                                                         (3, 32, 128, True, False), (2, 64, 64, False, False)])
@@ -706,6 +706,8 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale, packed, 
     DSEE_FUSED_W16=1, read per launch) -- measured 6 % slower than the shipped 8-wave form and therefore not the default, kept
     under the same test."""
     from deepsee_amd import lib as L, ops
+    if waves == 4 and packed:
+        pytest.skip("the one-wave-per-SIMD kernel takes the two-term operands only")
     monkeypatch.setenv("DSEE_FUSED_W16", "1" if waves == 16 else "0")
     g = torch.Generator().manual_seed(100 * n + h + c)
     K, rows, ca = (160 if per_image else 128), 2 * c, 128
@@ -764,7 +766,8 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale, packed, 
         out.fill_(float("nan"))
         hm, xm = ops.amax_slot(), ops.amax_slot()
         mask = torch.full((n * h * h * (c // 32),), 0x5a5a5a5a, dtype=torch.int32, device="cuda") if with_scale else None
-        L.call("spade_fused_fwd_f16p" if packed else "spade_fused_fwd", v2, u, ac, 100.0, ua, b2.cuda(), xd, mean.cuda(),
+        entry = "spade_fused_fwd_f16p" if packed else ("spade_fused_fwd_w4" if waves == 4 else "spade_fused_fwd")
+        L.call(entry, v2, u, ac, 100.0, ua, b2.cuda(), xd, mean.cuda(),
                invstd.cuda(), out, sc, n, h, h, c, rows, K, n if per_image else 1, add_one, 0.2, hm, xm, mask)
         torch.cuda.synchronize()
         if mask is not None:            # the LeakyReLU branch of h for the backward pass, one bit per element
@@ -776,6 +779,13 @@ def test_spade_fused_forward_vs_float64(n, h, c, per_image, with_scale, packed, 
         if first is None:
             first = out.clone()
         assert torch.equal(out, first)
+    if waves == 4:
+        # round 6: the one-wave-per-SIMD kernel (csrc/spade_fused_w4.hip) keeps the 8-wave kernel's arithmetic order: bit-identical
+        o8, s8 = torch.empty_like(out), (torch.empty_like(sc) if with_scale else None)
+        L.call("spade_fused_fwd", v2, u, ac, 100.0, ua, b2.cuda(), xd, mean.cuda(), invstd.cuda(), o8, s8, n, h, h, c, rows, K,
+               n if per_image else 1, add_one, 0.2, ops.amax_slot(), ops.amax_slot(), None)
+        torch.cuda.synchronize()
+        assert torch.equal(o8, out) and (not with_scale or torch.equal(s8, sc))
     e_h = rel(out.cpu().double().permute(0, 3, 1, 2), ref)
     print("fused SPADE forward N=%d %dx%d C=%d K=%d %s vs float64: h %.1e" % (n, h, h, c, K, "packed one-term" if packed else "", e_h))
     assert e_h < (8e-3 if packed else 2e-6)

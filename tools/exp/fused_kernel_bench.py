@@ -31,7 +31,7 @@ def bench(n, h, c, ld, per_image, reps=20, scale=True, mask=False, packed=False)
     for i in range(reps + 2):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        L.call("spade_fused_fwd_f16p" if packed else "spade_fused_fwd", v2, u, ac, 100.0, ua, b2, x, mean, invstd, out, sc if scale else None, n, h, h, c, rows, ld,
+        L.call("spade_fused_fwd_f16p" if packed else os.environ.get("FUSED_ENTRY", "spade_fused_fwd"), v2, u, ac, 100.0, ua, b2, x, mean, invstd, out, sc if scale else None, n, h, h, c, rows, ld,
                n if per_image else 1, 1.0, 0.2, None, None, mk)
         e.record()
         torch.cuda.synchronize()
@@ -39,12 +39,12 @@ def bench(n, h, c, ld, per_image, reps=20, scale=True, mask=False, packed=False)
     return sorted(ts[2:])[reps // 2]
 
 if __name__ == "__main__":
-    tag = os.environ.get("DSEE_LIB", "shipped")
+    tag = os.environ.get("DSEE_LIB", "shipped") + " " + os.environ.get("FUSED_ENTRY", "spade_fused_fwd")
     pk = "--packed" in sys.argv
     if pk:
         tag += " f16p"
     bench(8, 256, 512, 160, True, reps=5)       # (clocks / caches warm before the first reported number)
     for (n, h, c, ld, pi) in [(8, 256, 512, 160, True), (8, 256, 512, 128, False), (8, 128, 512, 160, True)]:
         print("%s: N=%d %dx%d C=%d K=%d per_image=%d: %.3f ms (scale + sign mask written), %.3f ms (scale written), %.3f ms (neither)" % (
-            tag, n, h, h, c, ld, pi, bench(n, h, c, ld, pi, mask="DSEE_LIB" not in os.environ or "fabl" in tag or "fvar" in tag, packed=pk),
+            tag, n, h, h, c, ld, pi, bench(n, h, c, ld, pi, mask=True, packed=pk),
             bench(n, h, c, ld, pi, packed=pk), bench(n, h, c, ld, pi, scale=False, packed=pk)), flush=True)

@@ -73,6 +73,10 @@ for l in open('gpurun_out/r06_bench_power_${BENCH_TAG:-default}.txt'):
           ( sleep 2.5; rocm-smi -P -c 2>/dev/null | grep -E "Power \(W\)|sclk" | tr '\n' ' '; echo ) &
           timeout 60 tools/exp/mfma_power_probe $a 4; wait
         done; } > $out 2>&1 ;;
+    fused_bench) # the fused SPADE / SEAN forward alone: 8-wave kernel vs the one-wave-per-SIMD kernel (FUSED_LIBS: measurement builds)
+      { timeout 300 python tools/exp/fused_kernel_bench.py
+        FUSED_ENTRY=spade_fused_fwd_w4 timeout 300 python tools/exp/fused_kernel_bench.py
+        for l in ${FUSED_LIBS:-}; do DSEE_LIB=tools/exp/$l.so FUSED_ENTRY=spade_fused_fwd_w4 timeout 300 python tools/exp/fused_kernel_bench.py; done; } 2>&1 | grep -v amdgpu.ids > $out ;;
     bench)      # the driver's command
       timeout 900 python bench.py --steps 20 --warmup 5 > $out 2>gpurun_out/r06_bench.err ;;
     bench_quick)
