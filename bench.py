@@ -45,6 +45,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Round 6 (profiles/r06_mfma_power_cap.txt, r06_gemm_ablation.md): what the 1 400 W socket cap leaves of the dense 16-bit matrix
+# peak when the operands toggle -- v_mfma_f32_32x32x16_f16 back to back on random operands RESIDENT IN REGISTERS (no LDS, L2 or
+# HBM traffic): 1 646 TFLOP/s at ~1.67 GHz (all-zero operands: 2 460 at 2.395 GHz).  The Winograd-domain GEMMs run on this limit
+# (socket at 1 378-1 403 W, shader clock 1.54-1.64 GHz), so their roofline carries it next to the datasheet peak.
+F16_MFMA_POWER_CAP_TFLOPS = 1646.5
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2516.6   # dense bf16 / fp16 MFMA (same guide)
 HBM_PEAK_GBPS = 8000.0          # HBM3E spec (same guide; ~6.3 TB/s achievable by a float4 copy)
@@ -171,7 +176,8 @@ def spawn_ranks(n):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (counters cannot be read live)."""
-    for name in ("r05_pmc_traffic_fp16.json" if "1term" in kernel else "r05_pmc_traffic.json", "r05_pmc_traffic.json",
+    for name in ("r06_pmc_traffic_fp16.json" if "1term" in kernel else "r06_pmc_traffic.json", "r06_pmc_traffic.json",
+                 "r05_pmc_traffic_fp16.json" if "1term" in kernel else "r05_pmc_traffic.json", "r05_pmc_traffic.json",
                  "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -393,10 +399,13 @@ def main():
         elapsed = float(t)
 
     # ---- one extra instrumented step: per-launch HIP events around every MFMA kernel and the fused SPADE kernel
+    from deepsee_amd import lib as _L
     ops.PROFILE = {}
     ops.PROFILE_BYTES.clear()
+    calls_before = _L.CALLS
     step()
     torch.cuda.synchronize()
+    capi_calls_per_step = _L.CALLS - calls_before
     prof, ops.PROFILE = ops.PROFILE, None
     kernels = {}
     for name, recs in prof.items():
@@ -458,13 +467,20 @@ def main():
                      "matrix cores: every fp32 operand is scaled by an exact power of two and split into two fp16 terms "
                      "(residual <= 2^-22, rms 2^-24), 3 MFMA products per multiply-add, fp32 accumulate; error vs float64 "
                      "equal to a CPU sgemm's (tests/test_gpu_conv.py::test_gemm_f16x2_is_fp32_accurate); --arith bf16x3 "
-                     "selects the exact 3-term bf16 split (6 products)",
+                     "selects the exact 3-term bf16 split (6 products).  The generated image deviates 2e-6 ... 5e-6 from the CPU "
+                     "oracle (bound 1e-4), and that deviation is the rounding of the fp32 F(4x4,3x3) transforms (the oracle's own "
+                     "distance to float64 is 8e-7), not of the split products; through the LeakyReLU / ReLU kinks it is what "
+                     "holds the model-level gradient comparison at a median of 1e-3 ... 2e-3 (DESIGN 4)",
             "bf16x3": "fp32 storage and accumulation; Winograd-domain GEMMs from exact 3-term bf16 operand splits (6 bf16 "
                       "MFMA products)",
             "f32": "fp32 (v_mfma_f32_32x32x2_f32)"}[kind]
         traffic, traffic_src = pmc_traffic(dom)
-        # a kernel below half of BOTH rooflines is bound by neither: say so instead of picking the larger fraction
-        bound = "neither (issue/latency)" if max(f_mfma, f_hbm) < 0.5 else ("mfma" if f_mfma >= f_hbm else "hbm")
+        # a kernel below half of BOTH datasheet rooflines is bound by neither of them.  Round 6 measured what it IS bound by: the
+        # socket power cap (profiles/r06_gemm_ablation.md) -- `power` below prices it against the MFMA rate that cap allows
+        split_products = round(F16_MFMA_PEAK_TFLOPS / peak) if peak > 200 else 0
+        power_peak = F16_MFMA_POWER_CAP_TFLOPS / split_products if split_products else None
+        bound = ("neither datasheet roofline: socket power cap" if (max(f_mfma, f_hbm) < 0.5 and power_peak) else
+                 ("neither (issue/latency)" if max(f_mfma, f_hbm) < 0.5 else ("mfma" if f_mfma >= f_hbm else "hbm")))
         roof = {"bound": bound, "closer_to": "mfma" if f_mfma >= f_hbm else "hbm", "kernel": dom,
                 "achieved": tf if f_mfma >= f_hbm else gbps, "peak": peak if f_mfma >= f_hbm else HBM_PEAK_GBPS,
                 "unit": "TFLOP/s" if f_mfma >= f_hbm else "GB/s", "frac": max(f_mfma, f_hbm),
@@ -474,6 +490,11 @@ def main():
                                       % (F16_MFMA_PEAK_TFLOPS, round(F16_MFMA_PEAK_TFLOPS / peak)) if peak > 200
                          else "v_mfma_f32 dense peak"},
                 "hbm": {"achieved_gbps_algorithmic": gbps, "peak": HBM_PEAK_GBPS, "frac": f_hbm},
+                "power": None if not power_peak else {
+                    "socket_cap_w": 1400, "mfma_only_tflops_under_cap_fp16_random_operands": F16_MFMA_POWER_CAP_TFLOPS,
+                    "peak_fp32_equiv_under_cap": power_peak, "frac_of_power_capped_peak": tf / power_peak,
+                    "source": "profiles/r06_mfma_power_cap.txt (MFMAs only, operands in registers, rocm-smi beside it), "
+                              "profiles/r06_gemm_ablation.md (this kernel back to back: 1 378-1 403 W, 1.54 GHz)"},
                 "launches_per_step": kd["launches"], "avg_launch_ms": kd["ms"] / kd["launches"],
                 "algorithmic_gb_per_launch": (kd["gb"] / kd["launches"]) or None,
                 "algorithmic_tflop_per_step": kd["tflop"],
@@ -511,6 +532,9 @@ def main():
                               "note": "N * F_iter / t_iter with SURVEY 8(d)'s F_iter; exceeds the fp32 MFMA peak because "
                                       "the wide layers run on the fp16 matrix cores in the Winograd domain"}
         out["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # of 288 GB (kept V / M tensors included)
+        out["launches_per_step"] = {"c_abi_entry_points": capi_calls_per_step,
+                                    "note": "dsee_* calls of one eager G + D step (an entry point is 1-3 kernel launches); the "
+                                            "rocprofv3 count of ALL kernels incl. ATen glue is in profiles/r06_kernel_stats_all.md"}
         out["host_enqueue_ms_per_step"] = host / args.steps * 1e3
         out["host_ms_per_step_incl_queue_backpressure"] = sum(host_steps) / args.steps * 1e3
         out["hip_graphs"] = {"enabled": bool(tm.use_graphs), "captured": sorted("/".join(map(str, k[:3])) for k in tm._graphs),
@@ -589,7 +613,13 @@ def main():
                 "generated_image_vs_fp32_path": {"bf16_operands_first_version": 7.9e-2, "scaled_fp16": 1.0e-2},
                 "generated_image_vs_cpu_oracle": {"bs1": 6.0e-3, "bs8": 8.6e-3, "bound": 3e-2},
                 "what_a_bf16_path_would_need": "a direct (non-Winograd) bf16 MFMA implicit GEMM: 2.25x the MFMA work of "
-                                               "F(4x4,3x3) at 0.24 % per layer; not built (DESIGN 6.2)"}
+                                               "F(4x4,3x3) at 0.24 % per layer",
+                "direct_bf16_measured_ceiling": {
+                    "mfma_only_bf16_random_operands_tflops": 1734.3, "mfma_only_bf16_zero_operands_tflops": 2459.9,
+                    "needed_to_beat_the_fp16_winograd_layer_tflops": 1270.0,
+                    "note": "512 -> 512 @256^2, N = 8 is 2.47 TFLOP direct: 1.42 ms at the MFMA rate the 1 400 W socket cap allows "
+                            "with NOTHING but MFMAs on random operands in registers; the loops that also move operands reach 0.50-0.67 "
+                            "of that ceiling (2.1-2.8 ms), the fp16 Winograd layer takes 1.95 ms -- profiles/r06_direct_bf16.txt"}}
         if dp:
             out["dp"] = dp
         if f32_only:

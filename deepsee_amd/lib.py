@@ -90,9 +90,14 @@ def _conv(v):
     return v
 
 
+CALLS = 0      # C-ABI entry points invoked by this process (bench.py reads the difference over one eager step)
+
+
 def call(name, *args):
     """Invoke ``dsee_<name>`` on the current stream (appended as the last argument).  Arguments are converted by the
     argtypes parsed from include/deepsee_hip.h: a wrong arity or a float where the header says int raises."""
+    global CALLS
+    CALLS += 1
     fn = getattr(lib(), "dsee_" + name)
     if len(args) + 1 != len(fn.argtypes):
         raise DseeError("dsee_%s takes %d arguments + stream (include/deepsee_hip.h), got %d"

@@ -22,8 +22,8 @@ def pk(k, i):      # the PK (packed one-term, 16-bit storage mode) template flag
     a = k.split("<")[1].split(">")[0].split(",")
     return len(a) > i and a[i].strip() == "true"
 
-groups = {"winograd_gemm_f16x2": lambda k: "gemm3a_kernel" in k and targ(k, 4) == "2" and not pk(k, 7),
-          "winograd_gemm_f16_1term_packed": lambda k: "gemm3a_kernel" in k and pk(k, 7),
+groups = {"winograd_gemm_f16x2": lambda k: ("gemm3a_kernel" in k and targ(k, 4) == "2" and not pk(k, 7)) or "gemm_w4_kernel<false" in k,
+          "winograd_gemm_f16_1term_packed": lambda k: ("gemm3a_kernel" in k and pk(k, 7)) or "gemm_w4_kernel<true" in k,
           "winograd_wgrad_f16_1term_packed": lambda k: "gemm3t_kernel" in k and pk(k, 8),
           "winograd_gemm_bf16x3": lambda k: "gemm3a_kernel" in k and targ(k, 4) == "3",
           "winograd_gemm_f16_1term": lambda k: "gemm3a_kernel" in k and targ(k, 4) == "1",
