@@ -70,19 +70,24 @@ __global__ __launch_bounds__(256) void chdot_partial_kernel(const float* __restr
   }
 }
 
+// part[parts][C] -> out[C]: block = 4 adjacent channels (one 16-byte load per row) x 256 part-lanes; lane l adds rows l, l + 256,
+// ... in order, the lanes then add pairwise in a fixed binary tree through LDS (bit-reproducible).  C % 4 == 0 (entry points).
 __global__ __launch_bounds__(256) void chdot_finalize_kernel(const float* __restrict__ part, int parts, int C,
                                                              float* __restrict__ out) {
-  __shared__ float sv[32][8];   // 8 channels x 32 part-lanes per block, lanes folded in order
-  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
-  float v = 0.f;
-  if (c < C)
-    for (int p = lane; p < parts; p += 32) v += part[(size_t)p * C + c];
-  sv[lane][cl] = v;
-  __syncthreads();
-  if (lane == 0 && c < C) {
-    for (int l = 1; l < 32; ++l) v += sv[l][cl];
-    out[c] = v;
+  __shared__ f32x4 sv[256];
+  const int lane = threadIdx.x, c0 = blockIdx.x * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int p = lane; p < parts; p += 256) v += *reinterpret_cast<const f32x4*>(part + (size_t)p * C + c0);
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (lane >= s && lane < 2 * s) sv[lane] = v;
+    __syncthreads();
+    if (lane < s) v += sv[lane + s];
+  }
+  if (lane == 0) {      // (scalar stores: `out` may be a slice of a flat gradient buffer at any 4-byte offset)
+    out[c0] = v[0];
+    out[c0 + 1] = v[1];
+    out[c0 + 2] = v[2];
+    out[c0 + 3] = v[3];
   }
 }
 
@@ -508,7 +513,7 @@ int dsee_channel_dot_rng(const float* a, float* out, long M, int C, float* works
   const int parts = (int)((M + cp - 1) / cp);
   chdot_rng_partial_kernel<<<parts, 256, 0, st>>>(a, workspace, M, C, (int)cp, seed, offset, dsee_rng_epoch());
   DSEE_LAUNCH_CHECK();
-  chdot_finalize_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, parts, C, out);
+  chdot_finalize_kernel<<<C / 4, 256, 0, st>>>(workspace, parts, C, out);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -552,7 +557,7 @@ int dsee_sumpool_dot_rng(const float* dy, float* dx, int N, int H, int W, int C,
   const int grid = egrid((long)N * (H >> ups) * (W >> ups) * C / 4);
   sumpool_dot_rng_kernel<<<grid, 256, 0, st>>>(dy, dx, N, H, W, C, ups, amax_dx, workspace, seed, offset, dsee_rng_epoch());
   DSEE_LAUNCH_CHECK();
-  chdot_finalize_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, grid, C, dnoise_w);
+  chdot_finalize_kernel<<<C / 4, 256, 0, st>>>(workspace, grid, C, dnoise_w);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
@@ -572,7 +577,7 @@ int dsee_channel_dot(const float* a, const float* b, float* out, long M, int C, 
   const int parts = (int)((M + cp - 1) / cp);
   chdot_partial_kernel<<<parts, 256, 0, st>>>(a, b, workspace, M, C, (int)cp);
   DSEE_LAUNCH_CHECK();
-  chdot_finalize_kernel<<<dsee_cdiv(C, 8), 256, 0, st>>>(workspace, parts, C, out);
+  chdot_finalize_kernel<<<C / 4, 256, 0, st>>>(workspace, parts, C, out);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

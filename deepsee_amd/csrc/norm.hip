@@ -131,47 +131,62 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   }
 }
 
-// Fold of the (count, mean, M2) rows a producer kernel wrote (DseeStatsAcc::flush): block = 4 channels x 64 row-lanes, lane l
-// merges rows l, l+64, ... then lane 0 merges the lanes in order (fixed order: bit-reproducible).
+// Fold of the (count, mean, M2) rows a producer kernel wrote (DseeStatsAcc::flush): block = 4 adjacent channels (one 16-byte
+// load per row and quantity) x 256 row-lanes; lane l merges rows l, l+256, ... in order, then the lanes merge pairwise in a
+// fixed binary tree through LDS (fixed order: bit-reproducible; 8 dependent merges instead of a 63-step serial fold).
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float qb) {
+  if (nb == 0.f) return;
+  const float d = mb - mean, nt = n + nb;
+  mean += d * nb / nt;
+  m2 += qb + d * d * n * nb / nt;
+  n = nt;
+}
+
 __global__ __launch_bounds__(256) void stats_finalize_parts_kernel(const float* __restrict__ part, int rows, int C,
                                                                    float* __restrict__ mean_out,
                                                                    float* __restrict__ invstd_out,
                                                                    float* __restrict__ run_mean, float* __restrict__ run_var,
                                                                    float eps, float momentum) {
-  __shared__ float sn[64][4], sm[64][4], s2[64][4];
-  const int cl = threadIdx.x & 3, lane = threadIdx.x >> 2;
-  const int c = blockIdx.x * 4 + cl;
-  const bool ok = c < C;
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (ok)
-    for (int k = lane; k < rows; k += 64) {
-      const float* r = part + (size_t)k * 3 * C + c;
-      const float nb = r[0];
-      if (nb == 0.f) continue;
-      const float d = r[C] - mean, nt = n + nb;
-      mean += d * nb / nt;
-      m2 += r[2 * C] + d * d * n * nb / nt;
-      n = nt;
-    }
-  sn[lane][cl] = n;
-  sm[lane][cl] = mean;
-  s2[lane][cl] = m2;
-  __syncthreads();
-  if (lane != 0 || !ok) return;
-  for (int l = 1; l < 64; ++l) {
-    const float nb = sn[l][cl];
-    if (nb == 0.f) continue;
-    const float d = sm[l][cl] - mean, nt = n + nb;
-    mean += d * nb / nt;
-    m2 += s2[l][cl] + d * d * n * nb / nt;
-    n = nt;
+  __shared__ float4 sn[256], sm[256], s2[256];
+  const int lane = threadIdx.x, c0 = blockIdx.x * 4;      // (C % 4 == 0: checked by the entry point)
+  float n[4] = {0.f, 0.f, 0.f, 0.f}, mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < rows; k += 256) {
+    const float* r = part + (size_t)k * 3 * C + c0;
+    const float4 nb = *reinterpret_cast<const float4*>(r);
+    const float4 mb = *reinterpret_cast<const float4*>(r + C);
+    const float4 qb = *reinterpret_cast<const float4*>(r + 2 * C);
+    chan_merge(n[0], mean[0], m2[0], nb.x, mb.x, qb.x);
+    chan_merge(n[1], mean[1], m2[1], nb.y, mb.y, qb.y);
+    chan_merge(n[2], mean[2], m2[2], nb.z, mb.z, qb.z);
+    chan_merge(n[3], mean[3], m2[3], nb.w, mb.w, qb.w);
   }
-  const float var = m2 / n;  // biased
-  mean_out[c] = mean;
-  invstd_out[c] = 1.0f / sqrtf(var + eps);
-  if (run_mean) {
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (lane >= s && lane < 2 * s) {
+      sn[lane] = make_float4(n[0], n[1], n[2], n[3]);
+      sm[lane] = make_float4(mean[0], mean[1], mean[2], mean[3]);
+      s2[lane] = make_float4(m2[0], m2[1], m2[2], m2[3]);
+    }
+    __syncthreads();
+    if (lane < s) {
+      const float4 nb = sn[lane + s], mb = sm[lane + s], qb = s2[lane + s];
+      chan_merge(n[0], mean[0], m2[0], nb.x, mb.x, qb.x);
+      chan_merge(n[1], mean[1], m2[1], nb.y, mb.y, qb.y);
+      chan_merge(n[2], mean[2], m2[2], nb.z, mb.z, qb.z);
+      chan_merge(n[3], mean[3], m2[3], nb.w, mb.w, qb.w);
+    }
+    __syncthreads();
+  }
+  if (lane != 0) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    const float var = m2[j] / n[j];  // biased
+    mean_out[c] = mean[j];
+    invstd_out[c] = 1.0f / sqrtf(var + eps);
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[j];
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n[j] / fmaxf(n[j] - 1.f, 1.f));
+    }
   }
 }
 

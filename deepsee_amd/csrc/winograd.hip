@@ -1276,6 +1276,77 @@ inline int wgrid(long n) { return (int)min(16384L, (n + 255) / 256); }
 // the transform kernels decompose a 32-bit item index (tile, channel quad)
 inline bool wino_items32(int N, int H, int W, int C) { return (long)N * ((H + 3) / 4) * ((W + 3) / 4) * ((C + 3) / 4) < (1L << 32); }
 
+// wino43_weight8_kernel with the weights staged through LDS.  There a lane gathers its 8 x 9 floats with 72 four-byte loads whose
+// addresses lie 288 B (forward) or Cin * 36 B (data gradient) apart across the wave: every load instruction touches 64 cache lines
+// and the kernel runs at a fifth of the HBM rate its 47 MB deserve.  Here a 128-thread block owns 16 rows x 64 k of one layer,
+// copies the weights it needs as contiguous runs (64 ci x 9 floats per co forward, 16 ci x 9 per co transposed) with 16-byte loads
+// into a padded LDS tile (row stride = 1 mod 64 banks / 145: conflict-free for the 8 x 9 gather), and every thread then forms the
+// same 8 transforms from LDS.  Same expressions, same stores: bit-identical U.  R % 16 == 0, K % 64 == 0, Cin % 4 == 0.
+template <bool T>
+__global__ __launch_bounds__(128) void wino43_weight8_tiled_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
+                                                                   int Cin, int rows, int Kpad, int transpose_flip, int split,
+                                                                   const float* __restrict__ amax, long w_stride, long u_stride) {
+  constexpr int RUN = T ? 16 * 9 : 64 * 9, NRUN = T ? 64 : 16, LD = RUN + 1;
+  __shared__ float tile[NRUN * LD];
+  w += (size_t)blockIdx.z * w_stride;
+  U += (size_t)blockIdx.z * u_stride;
+  if (amax) amax += (size_t)blockIdx.z * (DSEE_AMAX_LINES * DSEE_AMAX_STRIDE);
+  const int row0 = blockIdx.y * 16, kb = blockIdx.x * 64;       // rows: co forward, ci transposed; k: the other one
+  const size_t per = (size_t)rows * Kpad;
+  const float sc = split >= 2 ? dsee_pow2_scale(dsee_amax_read(amax)) : 1.f;
+  const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  const int tid = threadIdx.x, r = tid >> 3, k0 = kb + (tid & 7) * 8, row = row0 + r;
+  if (row0 < R && kb < K) {
+    for (int q = tid; q < NRUN * (RUN / 4); q += 128) {
+      const int run = q / (RUN / 4), e = (q - run * (RUN / 4)) * 4;
+      const int co = T ? kb + run : row0 + run, ci0 = T ? row0 : kb;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w + ((size_t)co * Cin + ci0) * 9 + e);
+      float* d = tile + run * LD + e;
+      d[0] = v[0];
+      d[1] = v[1];
+      d[2] = v[2];
+      d[3] = v[3];
+    }
+  }
+  __syncthreads();
+  float g[8][9];
+  const bool ok = row0 < R && kb < K;      // (a tile is all weights or all padding: R % 16 == 0, K % 64 == 0)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float* src = T ? tile + ((tid & 7) * 8 + j) * LD + r * 9 : tile + r * LD + ((tid & 7) * 8 + j) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int a = tap / 3, b = tap % 3;
+      const int kh = transpose_flip == 1 ? 2 - a : a, kw = transpose_flip == 1 ? 2 - b : b;
+      g[j][tap] = ok ? src[kh * 3 + kw] : 0.f;
+    }
+  }
+  ggt8(g, [&](int xi, const float (&v)[8]) { store_u8(U, split, (size_t)xi, per, rows, Kpad, row, k0, sc, v); });
+}
+
+inline bool weight8_tiled_ok(const float* w, int Cout, int Cin, int transpose_flip, int rows, int Kpad, long w_stride) {
+  const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
+  return R % 16 == 0 && K % 64 == 0 && Cin % 4 == 0 && rows % 16 == 0 && Kpad % 64 == 0 && ((uintptr_t)w & 15) == 0 &&
+         w_stride % 4 == 0 && rows / 16 < 65536;
+}
+
+inline void launch_weight8(const float* w, float* U, int layers, long w_stride, long u_stride, int Cout, int Cin, int rows,
+                           int Kpad, int transpose_flip, int split, const float* amax, hipStream_t st) {
+  if (weight8_tiled_ok(w, Cout, Cin, transpose_flip, rows, Kpad, w_stride)) {
+    const dim3 grid(Kpad / 64, rows / 16, layers);
+    if (transpose_flip)
+      wino43_weight8_tiled_kernel<true><<<grid, 128, 0, st>>>(w, U, Cout, Cin, rows, Kpad, transpose_flip, split, amax, w_stride,
+                                                               u_stride);
+    else
+      wino43_weight8_tiled_kernel<false><<<grid, 128, 0, st>>>(w, U, Cout, Cin, rows, Kpad, transpose_flip, split, amax, w_stride,
+                                                                u_stride);
+  } else {
+    wino43_weight8_kernel<<<dim3(wgrid((long)rows * Kpad / 8), layers), 256, 0, st>>>(w, U, Cout, Cin, rows, Kpad, transpose_flip,
+                                                                                      split, amax, w_stride, u_stride);
+  }
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -1585,8 +1656,7 @@ int dsee_wino43_weights(const float* w_oihw, float* U, int Cout, int Cin, int tr
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
   if (split != 1 && Kpad % 8 == 0)
-    wino43_weight8_kernel<<<wgrid((long)rows * Kpad / 8), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip, split,
-                                                                        amax_w, 0, 0);
+    launch_weight8(w_oihw, U, 1, 0, 0, Cout, Cin, rows, Kpad, transpose_flip, split, amax_w, st);
   else
     wino43_weight_kernel<<<wgrid((long)rows * Kpad), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad, transpose_flip,
                                                                    split, amax_w, 0, 0);
@@ -1602,9 +1672,7 @@ int dsee_wino43_weights_batch(const float* w_oihw, float* U, int layers, long w_
   const int R = transpose_flip ? Cin : Cout, K = transpose_flip ? Cout : Cin;
   const int rows = dsee_conv_wrows(R), Kpad = dsee_conv_kpad(1, 1, (K + 3) / 4 * 4);
   if (split != 1 && Kpad % 8 == 0)
-    wino43_weight8_kernel<<<dim3(wgrid((long)rows * Kpad / 8), layers), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad,
-                                                                                      transpose_flip, split, amax_w, w_stride,
-                                                                                      u_stride);
+    launch_weight8(w_oihw, U, layers, w_stride, u_stride, Cout, Cin, rows, Kpad, transpose_flip, split, amax_w, st);
   else
     wino43_weight_kernel<<<dim3(wgrid((long)rows * Kpad), layers), 256, 0, st>>>(w_oihw, U, Cout, Cin, rows, Kpad,
                                                                                  transpose_flip, split, amax_w, w_stride,

@@ -291,11 +291,15 @@ class SRModel(nn.Module):
         parts = [lambda: self.discriminate(d["labels"], fake, d["image_hr"], train_d=False)]
         if use_vgg:
             parts += [lambda: self.vgg(fake), vgg_real]
-        if use_vgg and not getattr(self, "_vgg_packed", False) and not torch.cuda.is_current_stream_capturing():
-            # the first forward builds the frozen VGG weights' packed / transformed images once (ops._frozen_cache) and both VGG
-            # passes read them: that one time they run in order, on one stream
+        packed = getattr(self, "_vgg_packed", None)
+        if packed is None:
+            packed = self._vgg_packed = set()
+        if use_vgg and self.plan not in packed:
+            # the first forward under a plan builds the frozen VGG weights' packed / transformed images once (ops._frozen_cache
+            # entries depend on the plan: precision, storage mode) and both VGG passes read them: that one time they run in
+            # order, on one stream -- also when that first forward is a capture (a plan swapped in after construction)
             pred, fx, fy = [f() for f in parts]
-            self._vgg_packed = True
+            packed.add(self.plan)
         else:
             pred, fx, fy = (ops.branches(*parts, inputs=[fake, d["image_hr"]]) + [None, None])[:3]
         n = fake.shape[0]

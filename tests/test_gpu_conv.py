@@ -871,6 +871,36 @@ def test_small_channel_keeps_its_precision_in_the_fused_spade_kernel():
     assert e5 < 1e-3 and e_all < 2e-6
 
 
+@pytest.mark.parametrize("co,ci", [(512, 512), (128, 256), (256, 64), (64, 192)])
+@pytest.mark.parametrize("flip", [0, 1, 2])
+@pytest.mark.parametrize("split", [0, 2, 3, 4])
+def test_wino43_weights_lds_staged_form_is_bit_identical(co, ci, flip, split):
+    """dsee_wino43_weights stages the weights through LDS when whole 16 x 64 tiles exist (coalesced 16-byte loads instead of a 72-load
+    gather per lane); a weight tensor at a 4-byte offset takes the gather kernel.  Same U, bit for bit, padding rows included --
+    forward (flip 0), data-gradient (1: transposed + rotated) and adjoint (2: transposed) forms, all operand formats."""
+    from deepsee_amd import lib as L
+    g = torch.Generator().manual_seed(co + ci + flip)
+    w = torch.randn(co, ci, 3, 3, generator=g)
+    r_s, k_s = (ci, co) if flip else (co, ci)
+    rows, kp = L.wrows(r_s), L.kpad(1, 1, k_s)
+    amax = torch.zeros(64 * 32, device="cuda")
+    amax[:] = float(w.abs().max())
+    aligned = w.cuda().contiguous()
+    buf = torch.zeros(w.numel() + 4, device="cuda")
+    shifted = buf[1:1 + w.numel()]
+    shifted.copy_(aligned.view(-1))
+    assert aligned.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+    outs = []
+    for src in (aligned, shifted):
+        u = torch.full((36 * rows * kp * 2,), 0x5a5a, dtype=torch.int16, device="cuda")
+        L.call("wino43_weights", src, u, co, ci, flip, split, amax)
+        torch.cuda.synchronize()
+        outs.append(u)
+    assert torch.equal(outs[0], outs[1])
+    used = 36 * rows * kp * {0: 2, 2: 2, 3: 1, 4: 1}[split]
+    assert bool((outs[0][:used] != 0x5a5a).any()) and bool((outs[0][used:] == 0x5a5a).all())
+
+
 # ------------------------------------------------------------------------------------ 16-bit storage mode (packed one-term)
 def _pack1_rows(x, scale):
     """fp32 [rows][K] -> packed one-term fp16 [K/32][rows][32] (int16 view) of scale * x: the image dsee_wino43_input_f16p /

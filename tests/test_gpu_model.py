@@ -3,6 +3,7 @@ weights, inputs, noise tensors and branch decisions.  Outputs/losses are held to
 practice ~1e-5; gradients to the reference's own noise floor (see tests/test_oracle_golden.py)."""
 import math
 import random
+import time
 
 import pytest
 import torch
@@ -256,7 +257,9 @@ def test_benchmark_path_matches_oracle(preset):
         ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9
     except (ValueError, OSError):
         ram_gb = 0.0
-    bs = 8 if ram_gb >= 90 else 4
+    # the headline configuration runs at the benchmark's own bs = 8; the guided preset at bs = 4 (same kernels and tile shapes from
+    # N = 4 on; the bs = 8 oracle pass is a minute of CPU time and the suite has to fit a slow driver box)
+    bs = 8 if (ram_gb >= 90 and preset == "independent_8x_256") else 4
     over = dict(PRESETS[preset], batchSize=bs)
     oopt = O.make_opt(**over)
     states = O.recipe_state(oopt, gain=1.0)
@@ -406,6 +409,13 @@ def smooth_loss_errors(over, seed=555, plain_f32=True):
     batch = O.synthetic_batch(oopt, n, seed=seed)
 
     def oracle_run(dtype, tape=None, pert=0.0):
+        t0 = time.time()
+        try:
+            return _oracle_run(dtype, tape, pert)
+        finally:
+            print("  [oracle pass %s%s: %.1f s of CPU]" % (str(dtype).replace("torch.", ""), " perturbed" if pert else "", time.time() - t0))
+
+    def _oracle_run(dtype, tape=None, pert=0.0):
         ctl = O.RecordingCtl() if tape is None else O.ReplayCtl(tape)
         orc = O.Oracle(oopt, states, ctl, dtype=dtype)
         random.seed(3)
