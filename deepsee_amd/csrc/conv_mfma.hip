@@ -52,6 +52,9 @@ struct ConvArgs {
   // weights in the 64-line layout of dsee_common.h; NULL = exact fp32 MFMA
   const float* amax_a;
   const float* amax_w;
+  // optional: receives max |out| (64-line layout, zeroed by the caller) from the plain epilogue -- the operand bound of the next
+  // direct layer, which then needs no dsee_absmax pass over this output
+  float* amax_out;
 };
 
 constexpr int BK = 32;
@@ -65,6 +68,7 @@ template <int MT, int NT, int BN, int EPI, typename RowOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int bn, int wn, int lane,
                                               RowOf row_of) {
   if constexpr (EPI == EPI_PLAIN) {
+    float vmax = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = bn * BN + wn * NT * 32 + j * 32 + (lane & 31);
@@ -82,10 +86,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             } else if (a.res) {
               v += a.res[(size_t)row * a.res_ld + col];
             }
-            a.out[(size_t)row * a.Cout + col] = dsee_act(v, a.act, a.slope);
+            v = dsee_act(v, a.act, a.slope);
+            a.out[(size_t)row * a.Cout + col] = v;
+            vmax = fmaxf(vmax, fabsf(v));
           }
         }
     }
+    if (a.amax_out) dsee_wave_atomic_absmax(a.amax_out, vmax);
   } else {
     static_assert(EPI != EPI_MODULATE || NT == 2, "modulate pairs gamma/beta tiles");
     // tile j=0 holds (scale-ish) gamma, j=1 holds beta of channel c for the same rows.
@@ -1287,7 +1294,16 @@ int dsee_pack_weight_dgrad(const float* w_oihw, const float* scale_num, const fl
 
 int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                     const float* residual, int residual_ld, float* out, int act, float slope, hipStream_t st) {
+  return dsee_conv2d_fwd_amax(g, in, w_packed, bias, residual, residual_ld, out, act, slope, nullptr, st);
+}
+
+/* dsee_conv2d_fwd that also writes max |out| into amax_out (optional; 64-line layout, zeroed by the caller): the operand bound
+ * the next direct layer's fp16x2 split needs, from this layer's epilogue instead of a dsee_absmax pass over the output. */
+int dsee_conv2d_fwd_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
+                         const float* residual, int residual_ld, float* out, int act, float slope, float* amax_out,
+                         hipStream_t st) {
   ConvArgs a = {};
+  a.amax_out = amax_out;
   int rc = fill_geom(a, g);
   if (rc) return rc;
   DSEE_CHECK_ARG(in && w_packed && out);
@@ -1308,7 +1324,14 @@ int dsee_conv2d_fwd(const dsee_conv_geom* g, const float* in, const float* w_pac
 int dsee_conv2d_fwd_f16x2(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                           const float* residual, int residual_ld, float* out, int act, float slope,
                           const float* amax_in, const float* amax_w, hipStream_t st) {
+  return dsee_conv2d_fwd_f16x2_amax(g, in, w_packed, bias, residual, residual_ld, out, act, slope, amax_in, amax_w, nullptr, st);
+}
+
+int dsee_conv2d_fwd_f16x2_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
+                               const float* residual, int residual_ld, float* out, int act, float slope,
+                               const float* amax_in, const float* amax_w, float* amax_out, hipStream_t st) {
   ConvArgs a = {};
+  a.amax_out = amax_out;
   int rc = fill_geom(a, g);
   if (rc) return rc;
   DSEE_CHECK_ARG(in && w_packed && out && amax_in && amax_w);

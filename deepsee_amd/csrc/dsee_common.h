@@ -86,6 +86,19 @@ __device__ __forceinline__ void dsee_block_atomic_absmax(float* amax, float v) {
   }
 }
 
+// per-wave form (no block barrier: callable from an epilogue whose waves finish at different times); all 64 lanes call it
+__device__ __forceinline__ void dsee_wave_atomic_absmax(float* amax, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned slot = (blockIdx.x + blockIdx.y * 7u) * 4u + (threadIdx.x >> 6);
+    unsigned* line = reinterpret_cast<unsigned*>(amax + (slot & (DSEE_AMAX_LINES - 1)) * DSEE_AMAX_STRIDE);
+    const unsigned bits = __builtin_bit_cast(unsigned, v);
+    const unsigned cur = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bits > cur) atomicMax(line, bits);
+  }
+}
+
 // BatchNorm statistics in a producer's epilogue (sync_batchnorm/batchnorm.py:65-68): a kernel whose threads keep
 // one channel quad for their whole grid-stride loop (gridDim.x * 256 a multiple of C/4) accumulates shifted sums of what it
 // stores, and the block writes ONE row (count, mean, M2) x C to part[blockIdx.x][3][C]; dsee_norm_stats_finalize_parts

@@ -267,8 +267,10 @@ __global__ void label_to_u8_kernel(const float* __restrict__ lab, uint8_t* __res
 
 // cat([one-hot(label), image]) in NHWC: channels [0,L) one-hot, [L,L+3) image, rest 0 (sr_model.py:655-668)
 __global__ void build_d_input_kernel(const uint8_t* __restrict__ lab, const float* __restrict__ img,
-                                     float* __restrict__ out, long pixels, int L, int Cs, int img_cs) {
+                                     float* __restrict__ out, long pixels, int L, int Cs, int img_cs,
+                                     float* __restrict__ amax) {
   const long total = pixels * Cs;
+  float vmax = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cs);
     const long p = i / Cs;
@@ -276,7 +278,9 @@ __global__ void build_d_input_kernel(const uint8_t* __restrict__ lab, const floa
     if (c < L) v = lab[p] == c ? 1.f : 0.f;
     else if (c < L + 3) v = img[p * img_cs + (c - L)];
     out[i] = v;
+    vmax = fmaxf(vmax, fabsf(v));
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);   // (block-uniform) max |out|: operand bound of the discriminator's first layer
 }
 
 // d(image) from d(D input): dimg[p][k] = din[p][L+k]
@@ -681,8 +685,14 @@ int dsee_label_u8_prepare(const uint8_t* lab, const uint8_t* flip, uint8_t* out,
 
 int dsee_build_d_input(const uint8_t* lab, const float* img, float* out, long pixels, int L, int Cs, int img_cs,
                        hipStream_t st) {
+  return dsee_build_d_input_amax(lab, img, out, pixels, L, Cs, img_cs, nullptr, st);
+}
+
+/* ... that also folds max |out| into amax_out (optional; 64-line layout, zeroed by the caller) */
+int dsee_build_d_input_amax(const uint8_t* lab, const float* img, float* out, long pixels, int L, int Cs, int img_cs,
+                            float* amax_out, hipStream_t st) {
   DSEE_CHECK_ARG(lab && img && out && Cs >= L + 3 && img_cs >= 3);
-  build_d_input_kernel<<<egrid(pixels * Cs), 256, 0, st>>>(lab, img, out, pixels, L, Cs, img_cs);
+  build_d_input_kernel<<<egrid(pixels * Cs), 256, 0, st>>>(lab, img, out, pixels, L, Cs, img_cs, amax_out);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

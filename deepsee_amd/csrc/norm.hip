@@ -265,7 +265,9 @@ __global__ void eval_stats_kernel(const float* __restrict__ run_mean, const floa
 // ---- y = act((x - mean[g][c]) * invstd[g][c])
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float* __restrict__ y,
-                                                           long total4, int C, long group_elems, int act, float slope) {
+                                                           long total4, int C, long group_elems, int act, float slope,
+                                                           float* __restrict__ amax = nullptr) {
+  float vmax = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 4;
     const unsigned px = (unsigned)i / ((unsigned)C >> 2);       // (32-bit divisions: dsee_common.h)
@@ -278,7 +280,9 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = dsee_act(r[k], act, slope);
     *reinterpret_cast<f32x4*>(y + e) = r;
+    vmax = fmaxf(vmax, dsee_absmax4(r));
   }
+  if (amax) dsee_block_atomic_absmax(amax, vmax);   // (block-uniform) max |y|: operand bound of the direct layer that reads y
 }
 
 // ---- backward, pass 1: per-(group,channel) sums.
@@ -789,18 +793,30 @@ int dsee_norm_eval_stats(const float* running_mean, const float* running_var, in
 
 int dsee_norm_act_fwd(const float* x, const float* mean, const float* invstd, float* y, int N, int HW, int C,
                       int groups, int act, float slope, hipStream_t st) {
+  return dsee_norm_act_fwd_amax(x, mean, invstd, y, N, HW, C, groups, act, slope, nullptr, st);
+}
+
+/* ... that also writes max |y| into amax_y (optional; 64-line layout, zeroed by the caller): the bound of the next direct layer */
+int dsee_norm_act_fwd_amax(const float* x, const float* mean, const float* invstd, float* y, int N, int HW, int C,
+                      int groups, int act, float slope, float* amax_y, hipStream_t st) {
   DSEE_CHECK_ARG(x && mean && invstd && y && C % 4 == 0 && N % groups == 0 && (long)N * HW * C / 4 < (1L << 32));
   const long total4 = (long)N * HW * C / 4;
   norm_act_fwd_kernel<<<grid_for(total4), 256, 0, st>>>(x, mean, invstd, y, total4, C, (long)(N / groups) * HW * C, act,
-                                                        slope);
+                                                        slope, amax_y);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }
 
-/* IN + act backward: dx from (dy, y, x). */
 int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                       float* dx, int N, int HW, int C, int groups, int act, float slope, float* workspace,
                       hipStream_t st) {
+  return dsee_norm_act_bwd_amax(dy, y, x, mean, invstd, dx, N, HW, C, groups, act, slope, workspace, nullptr, st);
+}
+
+/* IN + act backward: dx from (dy, y, x); amax_dx (optional, zeroed by the caller) receives max |dx|. */
+int dsee_norm_act_bwd_amax(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                      float* dx, int N, int HW, int C, int groups, int act, float slope, float* workspace,
+                      float* amax_dx, hipStream_t st) {
   DSEE_CHECK_ARG(dy && y && x && mean && invstd && dx && workspace);
   DSEE_CHECK_ARG(C % 4 == 0 && C <= 1024 && N % groups == 0);
   RedGeom g = make_geom(N, HW, C, groups);
@@ -814,7 +830,7 @@ int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const flo
   DSEE_CHECK_ARG(total4 < (1L << 32));
   norm_bwd_apply_kernel<0><<<grid_for(total4), 256, 0, st>>>(dy, y, x, nullptr, mean, invstd, sums, nullptr, dx, total4,
                                                              C, (long)(N / groups) * HW * C, g.groups,
-                                                             1.0f / (float)g.P, act, slope);
+                                                             1.0f / (float)g.P, act, slope, amax_dx);
   DSEE_LAUNCH_CHECK();
   return DSEE_OK;
 }

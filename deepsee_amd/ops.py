@@ -333,18 +333,31 @@ def _dgrad_stride2_parity(g, w, geom, ci, amax_cache=None, exact=False):
     gd = L.ConvGeom(n, geom.Ho, geom.Wo, geom.Cout, ha, wa, 4 * cin_s, 2, 2, 1, 1, -1, 0, 0, korder)
     z = conv_raw(g, _pack_dgrad(w4, geom.Cout, korder), gd, amax_cache=amax_cache, exact=exact)
     dx = z.view(n, ha, wa, 2, 2, cin_s).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * ha, 2 * wa, cin_s)
-    return dx[:, :h, :wd].contiguous() if (2 * ha != h or 2 * wa != wd) else dx.contiguous()
+    dx = dx[:, :h, :wd].contiguous() if (2 * ha != h or 2 * wa != wd) else dx.contiguous()
+    if carried_amax(z) is not None:
+        tag_amax(dx, z.dsee_amax)         # (a permutation / crop of z: the same bound)
+    return dx
+
+
+def _direct_split_on(exact=False):
+    """the direct implicit-GEMM layers run on split fp16 operands (and therefore need operand maxima)"""
+    return (not exact) and P().gemm_split and P().gemm_f16x2 and P().conv_f16x2_min_flop > 0
 
 
 def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE, res_ld=0, amax_cache=None, exact=False):
     out = new(geom.N, geom.Ho, geom.Wo, geom.Cout)
-    if not exact and P().gemm_split and P().gemm_f16x2 and P().conv_f16x2_min_flop > 0 and _flops(geom) >= P().conv_f16x2_min_flop:
+    # round 6: the epilogue writes max |out| -- the bound the NEXT direct layer's fp16x2 split needs (VGG conv -> conv, the data
+    # gradient chain through D / VGG) -- instead of a stand-alone absmax pass over the activation (55 such passes per step before)
+    ao = amax_slot() if (_direct_split_on(exact) and P().conv_amax_out) else None
+    if _direct_split_on(exact) and _flops(geom) >= P().conv_f16x2_min_flop:
         ax, aw = tensor_amax(x, amax_cache), tensor_amax(wp)
         with _timed(_variant(geom).replace("halo", "igemm") + "_f16x2", _flops(geom)):   # (the halo kernel is fp32-only)
-            L.call("conv2d_fwd_f16x2", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw)
-        return out
-    with _timed(_variant(geom), _flops(geom)):
-        L.call("conv2d_fwd", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope))
+            L.call("conv2d_fwd_f16x2_amax", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw, ao)
+    else:
+        with _timed(_variant(geom), _flops(geom)):
+            L.call("conv2d_fwd_amax", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ao)
+    if ao is not None:
+        tag_amax(out, ao)
     return out
 
 
@@ -907,6 +920,10 @@ class Conv2d(torch.autograd.Function):
             g = torch.empty_like(dy)
             tag_amax(g, amax_slot())      # (the A dY A^T transform below is written pre-split with this bound)
             L.call("act_bwd_amax", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE, g.dsee_amax)
+        elif ctx.act != L.ACT_NONE and not ctx.wino and _direct_split_on(ctx.exact) and P().conv_amax_out:
+            g = torch.empty_like(dy)
+            tag_amax(g, amax_slot())      # (the direct data / weight gradient kernels split g with this bound)
+            L.call("act_bwd_amax", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE, g.dsee_amax)
         elif ctx.act != L.ACT_NONE:
             g = torch.empty_like(dy)
             L.call("act_bwd", dy, out, g, C.c_long(dy.numel()), ctx.act, LRELU_SLOPE)
@@ -1240,8 +1257,11 @@ class InstNormAct(torch.autograd.Function):
         ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, n), "norm")
         L.call("norm_stats", x, n, h * w, c, n, BN_EPS, 0.0, mean, invstd, None, None, ws)
         y = torch.empty_like(x)
-        L.call("norm_act_fwd", x, mean, invstd, y, n, h * w, c, n, act, LRELU_SLOPE)
-        ctx.act = act
+        ao = amax_slot() if (_direct_split_on() and P().conv_amax_out) else None    # (max |y| for the direct layer that reads y)
+        L.call("norm_act_fwd_amax", x, mean, invstd, y, n, h * w, c, n, act, LRELU_SLOPE, ao)
+        if ao is not None:
+            tag_amax(y, ao)
+        ctx.act, ctx.emit_amax = act, ao is not None
         ctx.save_for_backward(x, y, mean, invstd)
         return y
 
@@ -1251,7 +1271,11 @@ class InstNormAct(torch.autograd.Function):
         n, h, w, c = x.shape
         dx = torch.empty_like(x)
         ws = scratch(L.lib().dsee_norm_workspace(n, h * w, c, n), "norm")
-        L.call("norm_act_bwd", dy.contiguous(), y, x, mean, invstd, dx, n, h * w, c, n, ctx.act, LRELU_SLOPE, ws)
+        ao = amax_slot() if ctx.emit_amax else None    # (max |dx|: dx is a direct layer's output gradient; decided in forward --
+        #                                                 the engine's thread has no plan of its own)
+        L.call("norm_act_bwd_amax", dy.contiguous(), y, x, mean, invstd, dx, n, h * w, c, n, ctx.act, LRELU_SLOPE, ws, ao)
+        if ao is not None:
+            tag_amax(dx, ao)
         return dx, None
 
 
@@ -1964,6 +1988,8 @@ class AvgPool3s2(torch.autograd.Function):
         y = new(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c)
         L.call("avgpool3s2_fwd", x, y, n, h, w, c)
         ctx.shape = x.shape
+        if carried_amax(x) is not None:
+            tag_amax(y, x.dsee_amax)       # (an average: max |y| <= max |x|)
         return y
 
     @staticmethod
@@ -1981,6 +2007,8 @@ class MaxPool2(torch.autograd.Function):
         y = new(n, h // 2, w // 2, c)
         L.call("maxpool2_fwd", x, y, n, h, w, c)
         ctx.save_for_backward(x)
+        if carried_amax(x) is not None:
+            tag_amax(y, x.dsee_amax)       # (max |maxpool(x)| <= max |x|: the producer's bound holds for the pooled tensor)
         return y
 
     @staticmethod
@@ -1988,7 +2016,10 @@ class MaxPool2(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         n, h, w, c = x.shape
         dx = torch.empty_like(x)
-        L.call("maxpool2_bwd", dy.contiguous(), x, dx, n, h, w, c)
+        dy = dy.contiguous()
+        L.call("maxpool2_bwd", dy, x, dx, n, h, w, c)
+        if carried_amax(dy) is not None:
+            tag_amax(dx, dy.dsee_amax)     # (dx routes every dy to one position: max |dx| <= max |dy|)
         return dx
 
 
@@ -2002,9 +2033,12 @@ class DInput(torch.autograd.Function):
         n, h, w, cs = imgs[0].shape
         ld = L.pad4(labels.nc + 3)
         out = new(n * len(imgs), h, w, ld)
+        ao = amax_slot() if (_direct_split_on() and P().conv_amax_out) else None
         for i, img in enumerate(imgs):
-            L.call("build_d_input", labels.t, img.contiguous(), out[i * n:(i + 1) * n], C.c_long(n * h * w), labels.nc,
-                   ld, cs)
+            L.call("build_d_input_amax", labels.t, img.contiguous(), out[i * n:(i + 1) * n], C.c_long(n * h * w), labels.nc,
+                   ld, cs, ao)
+        if ao is not None:
+            tag_amax(out, ao)
         ctx.nc, ctx.cs, ctx.k, ctx.n = labels.nc, cs, len(imgs), n
         return out
 

@@ -83,6 +83,16 @@ int dsee_conv2d_fwd_f16x2(const dsee_conv_geom* g, const float* in, const float*
                           const float* residual, int residual_ld, float* out, int act, float slope,
                           const float* amax_in, const float* amax_w, hipStream_t stream);
 
+/* round 6: both forms with the operand bound of the NEXT direct layer written by this layer's epilogue: amax_out (optional;
+ * 2048 floats, zeroed by the caller) receives max |out| -- no dsee_absmax pass over the activation between two direct layers
+ * (VGG conv -> conv / pool -> conv, `architecture.py:151-181`; the discriminator's first layer, `discriminator.py:78-96`). */
+int dsee_conv2d_fwd_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
+                         const float* residual, int residual_ld, float* out, int act, float slope, float* amax_out,
+                         hipStream_t stream);
+int dsee_conv2d_fwd_f16x2_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
+                               const float* residual, int residual_ld, float* out, int act, float slope,
+                               const float* amax_in, const float* amax_w, float* amax_out, hipStream_t stream);
+
 /* Winograd F(4x4,3x3) path for 3x3 / stride 1 / pad 1 convolutions (same call sites as dsee_conv2d_fwd):
  *   V = dsee_wino43_input(x)                                [36][T][Cin],  T = N*(H/4)*(W/4)
  *   M = dsee_conv2d_fwd_grouped(V viewed [36][T][1][Cin], U, group_stride = wrows*Kpad)   36 GEMMs, 2.25 MAC/px/ch pair
@@ -436,6 +446,14 @@ int dsee_norm_act_fwd(const float* x, const float* mean, const float* invstd, fl
 int dsee_norm_act_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                       float* dx, int N, int HW, int C, int groups, int act, float slope, float* workspace,
                       hipStream_t stream);
+/* round 6: the same two with the operand bound of their consumer written in the same pass: amax_y / amax_dx (optional; 2048
+ * floats, zeroed by the caller) receive max |y| / max |dx| -- the discriminator's and encoders' convolutions that read them
+ * (discriminator.py:78-96, encoder.py:83-99) then need no dsee_absmax pass */
+int dsee_norm_act_fwd_amax(const float* x, const float* mean, const float* invstd, float* y, int N, int HW, int C,
+                           int groups, int act, float slope, float* amax_y, hipStream_t stream);
+int dsee_norm_act_bwd_amax(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                           float* dx, int N, int HW, int C, int groups, int act, float slope, float* workspace,
+                           float* amax_dx, hipStream_t stream);
 /* backward of dsee_conv2d_modulate_fwd w.r.t. x and (gamma,beta): see SURVEY.md Appendix E.
  * dgb [M][dgb_ld] is written in the packed gamma/beta column order and is the `dout` for the wgrad/dgrad of the
  * gamma/beta convolution; col_sums [2][C] = (sum g*xhat, sum g) are its bias gradients; dx gets `add` added. */
@@ -552,6 +570,8 @@ int dsee_label_u8_prepare(const uint8_t* lab, const uint8_t* flip, uint8_t* out,
 /* cat([input_semantics, image], dim=1) of sr_model.py:655-668 in NHWC, and the image part of its gradient */
 int dsee_build_d_input(const uint8_t* lab, const float* img, float* out, long pixels, int L, int Cs, int img_cs,
                        hipStream_t stream);
+int dsee_build_d_input_amax(const uint8_t* lab, const float* img, float* out, long pixels, int L, int Cs, int img_cs,
+                            float* amax_out, hipStream_t stream);     /* + max |out| folded into amax_out (optional) */
 int dsee_extract_image_grad(const float* din, float* dimg, long pixels, int L, int Cs, int img_cs, hipStream_t stream);
 /* Philox4x32-10 fill: N(0,1) (normal != 0) or U[0,1) — replaces tensor.normal_() / torch.rand_like on device */
 int dsee_rng_fill(float* out, long n, uint64_t seed, uint64_t offset, int normal, hipStream_t stream);

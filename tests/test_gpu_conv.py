@@ -55,12 +55,17 @@ def test_conv_fwd_dgrad_wgrad(case, f16x2):
     n, cin, cout, h, k, stride, pad, ups, act, use_bias, use_res = case
 
     def fwd(geom_, x_, w_, b_, r_, out_, act_, slope_):
+        # through the *_amax forms (round 6): the epilogue's max |out| must be exactly the maximum of what it stored
+        ao = torch.zeros(2048, device="cuda")
         if not f16x2:
-            return L.call("conv2d_fwd", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_)
-        ax, aw = torch.zeros(2048, device="cuda"), torch.zeros(2048, device="cuda")
-        L.call("absmax", x_, x_.numel(), ax)
-        L.call("absmax", w_, w_.numel(), aw)
-        return L.call("conv2d_fwd_f16x2", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_, ax, aw)
+            L.call("conv2d_fwd_amax", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_, ao)
+        else:
+            ax, aw = torch.zeros(2048, device="cuda"), torch.zeros(2048, device="cuda")
+            L.call("absmax", x_, x_.numel(), ax)
+            L.call("absmax", w_, w_.numel(), aw)
+            L.call("conv2d_fwd_f16x2_amax", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_, ax, aw, ao)
+        torch.cuda.synchronize()
+        assert float(ao.max()) == float(out_.abs().max()), (float(ao.max()), float(out_.abs().max()))
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(n, cin, h, h, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5

@@ -174,9 +174,17 @@ def test_instnorm_act(act):
     y.backward(gy)
     xs = nhwc(x.detach()).requires_grad_()
     ys = ops.InstNormAct.apply(xs, act)
+    seen = []
+    xs.register_hook(seen.append)        # (the gradient tensor as the backward node hands it on, before AccumulateGrad copies it)
     ys.backward(nhwc(gy))
     assert rel(nchw(ys.detach(), 24), y.detach()) < TOL
     assert rel(nchw(xs.grad, 24), x.grad) < 5 * TOL
+    # round 6: the kernels write the operand bound of the direct layer that consumes their output in the same pass
+    assert ops.DEFAULT_PLAN.conv_amax_out and ops.carried_amax(ys) is not None
+    assert float(ys.dsee_amax.max()) == float(ys.detach().abs().max())
+    assert ops.carried_amax(seen[0]) is not None and float(seen[0].dsee_amax.max()) == float(xs.grad.abs().max())
+    yp = ops.AvgPool3s2.apply(ys)
+    assert ops.carried_amax(yp) is ys.dsee_amax and float(yp.detach().abs().max()) <= float(ys.dsee_amax.max())
 
 
 def test_upsample_noise_and_sumpool():
@@ -287,6 +295,7 @@ def test_preprocess_bicubic_labels_dinput():
     din = ops.DInput.apply(labels, fk, nhwc(img))
     assert rel(nchw(din.detach(), 22), want) == 0.0
     assert float(din[..., 22:].abs().max()) == 0.0
+    assert float(din.dsee_amax.max()) == float(din.detach().abs().max())       # (bound of D's first layer, written with the tensor)
     gd = torch.randn(4, 22, 64, 64, generator=g)
     din.backward(nhwc(gd))
     assert rel(nchw(fk.grad, 3), gd[:2, 19:22]) == 0.0
