@@ -530,7 +530,7 @@ def _presplit_ok(xc, t, t_g, r_s, k_s=0, keep=False):
     """dsee_gemm_f16x2_pre takes 256 x 256 tiles only; below 512 of them the 128 x 128 kernel fills the chip better.
     `keep`: the weight gradient will read the same V2 (dsee_gemm_f16x2_tn_qpre: 160 or a multiple of 128 columns)."""
     return (P().presplit_a and carried_amax(xc) is not None and t_g % 256 == 0 and r_s % 256 == 0
-            and (36 * t // 256) * (r_s // 256) >= 512 and (not keep or k_s == 160 or k_s % 128 == 0))
+            and (36 * t // 256) * (r_s // 256) >= P().presplit_min_tiles and (not keep or k_s == 160 or k_s % 128 == 0))
 
 
 def _gemm_pre(name, k_s, r_s):

@@ -53,6 +53,7 @@ class KernelPlan:
     # data gradient of the 4x4 / stride-2 convolutions by output parity: one dense 2x2 convolution with 4 Cin output columns + a
     # depth-to-space copy (False: the general strided-gather kernel, three quarters of whose MFMAs multiply zeros)
     dgrad_s2_parity: bool = True
+    presplit_min_tiles: int = 512      # fewest 256 x 256 tiles for which a layer takes the pre-split NT GEMM (below: 128 x 128 tiles, fp32 A)
     conv_amax_out: bool = True         # direct layers write max |out| in their epilogue (operand bound of the next direct layer)
     # A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
     presplit_dm: bool = True

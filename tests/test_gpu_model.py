@@ -261,6 +261,11 @@ def test_benchmark_path_matches_oracle(preset):
     # N = 4 on; the bs = 8 oracle pass is a minute of CPU time and the suite has to fit a slow driver box)
     bs = 8 if (ram_gb >= 90 and preset == "independent_8x_256") else 4
     over = dict(PRESETS[preset], batchSize=bs)
+    t_phase, phases = [time.time()], []
+
+    def lap(name):
+        t_phase.append(time.time())
+        phases.append("%s %.0f s" % (name, t_phase[-1] - t_phase[-2]))
     oopt = O.make_opt(**over)
     states = O.recipe_state(oopt, gain=1.0)
     batch = O.synthetic_batch(oopt, bs, seed=2468)
@@ -304,6 +309,7 @@ def test_benchmark_path_matches_oracle(preset):
         pytest.fail("no replayable G + D pair after 48 iterations: %r" % (tm.graph_stats,))
     torch.cuda.synchronize()
     warm_iters = it
+    lap("setup + %d warm iterations (eager, captures)" % it)
     snap = {net: {k: v.detach().cpu().clone() for k, v in getattr(m, "net" + net).state_dict().items()} for net in ("SR", "D", "E")}
     snap["VGG"] = states["VGG"]
     noise_before_g = m.noise.state_dict()          # (forward index, device epoch) the replayed G step starts from
@@ -321,7 +327,9 @@ def test_benchmark_path_matches_oracle(preset):
     ctl = O.ReplayCtl(tape)
     orc = O.Oracle(oopt, snap, ctl)
     orc.create_optimizers()
+    lap("replayed G + tape")
     gl, fake = orc.run_generator_one_step(feed())
+    lap("oracle G step")
     assert ctl.pos == len(ctl.tape)
     ggrads = {"%s.%s" % (net, k): p.grad.clone() for net in ("SR", "E") for k, p in orc.params(net) if p.grad is not None}
     for k, v in gl.items():
@@ -373,6 +381,7 @@ def test_benchmark_path_matches_oracle(preset):
         assert herrs[len(herrs) // 2] < HALF_GRAD_MEDIAN_BOUND and herrs[-1] < HALF_GRAD_MAX_BOUND, (herrs[len(herrs) // 2], herrs[-1])
         th.close()
         del th, mh
+        lap("16-bit manager: warm iterations + replay")
     # ---- the replayed D step from the oracle's post-G state (both sides identical weights / buffers again)
     load_oracle_state(tm, orc)
     kd2, replayed = half("D")
@@ -381,7 +390,9 @@ def test_benchmark_path_matches_oracle(preset):
     ctl.tape += m.noise.dump(logs[kd])
     hdl = {k: float(v) for k, v in tm.d_losses.items()}
     hd = {nm: tm.optimizer_D.grad_view(nm).detach().cpu().clone() for nm in tm.optimizer_D.names}
+    lap("replayed D")
     dl = orc.run_discriminator_one_step(feed())
+    lap("oracle D step")
     assert ctl.pos == len(ctl.tape)
     dgrads = {"D." + k: p.grad.clone() for k, p in orc.params("D") if p.grad is not None}
     for k, v in dl.items():
@@ -389,8 +400,8 @@ def test_benchmark_path_matches_oracle(preset):
     dmax = max(float(v.norm()) for v in dgrads.values())
     derrs = sorted(float((hd[k].double() - v.double()).norm()) / max(float(v.norm()), 1e-2 * dmax) for k, v in dgrads.items())
     assert derrs[-1] < 5e-3, derrs[-1]
-    print(report + " | D step replayed from the oracle's post-G state: D-grad max %.2e, losses %s"
-          % (derrs[-1], {k: round(v, 5) for k, v in hdl.items()}))
+    print(report + " | D step replayed from the oracle's post-G state: D-grad max %.2e, losses %s | wall time: %s"
+          % (derrs[-1], {k: round(v, 5) for k, v in hdl.items()}, ", ".join(phases)))
     tm.close()
 
 
