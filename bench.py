@@ -479,6 +479,10 @@ def main():
         # socket power cap (profiles/r06_gemm_ablation.md) -- `power` below prices it against the MFMA rate that cap allows
         split_products = round(F16_MFMA_PEAK_TFLOPS / peak) if peak > 200 else 0
         power_peak = F16_MFMA_POWER_CAP_TFLOPS / split_products if split_products else None
+        # (measured for the Winograd-domain GEMM families; a direct-convolution kernel that ends up dominant -- configs[4] at N = 1 in
+        # the 16-bit mode -- runs at 2.3-2.45 GHz and is latency / issue bound)
+        if not dom.startswith("winograd"):
+            power_peak = None
         bound = ("neither datasheet roofline: socket power cap" if (max(f_mfma, f_hbm) < 0.5 and power_peak) else
                  ("neither (issue/latency)" if max(f_mfma, f_hbm) < 0.5 else ("mfma" if f_mfma >= f_hbm else "hbm")))
         roof = {"bound": bound, "closer_to": "mfma" if f_mfma >= f_hbm else "hbm", "kernel": dom,
