@@ -643,6 +643,193 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_halo_kernel(ConvArgs a) {
   });
 }
 
+// The halo kernel on split fp16 operands (round 6): same 8 x 16 patch, same per-tap weight slabs, but the halo and the
+// weight slab are scaled by their tensors' power-of-two factors and written to LDS as two fp16 terms (the 32-channel row keeps its
+// 128 bytes: 64 B of leading terms, 64 B of residuals) ONCE per 32-channel chunk -- the implicit-GEMM kernel converts every input
+// element once per tap, nine times -- and the taps run as 3 x v_mfma_f32_32x32x16_f16 per fragment pair on fragments read at shifted
+// LDS addresses.  NT = 1: a 64-column tile for the 64-channel layers (VGG conv1_2, `architecture.py:151-181`), NT = 2: 128 columns.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_halo_f16_kernel(ConvArgs a) {
+  constexpr int WM = 2, MT = 2, BN = 2 * NT * 32, NTHR = 256, B_CH = BN * 8 / NTHR, RPP = NTHR / 8;
+  constexpr int PH = WM * 4, HALO_PX = HALO_W * (PH + 2), HALO_CH = (HALO_PX * 8 + NTHR - 1) / NTHR;
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ah = smem;                    // [180][LDK]: per pixel 32 channels as [hi x 32 | lo x 32] halves
+  float* Bs = smem + HALO_PX * LDK;    // [2][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bm, bn;
+  {
+    const int nbn = gridDim.y, total = gridDim.x * nbn;
+    const int b = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bn = l % nbn;
+    bm = l / nbn;
+  }
+  const int txn = a.Wo / 16, tyn = a.Ho / PH;
+  const int tx = bm % txn, ty = (bm / txn) % tyn, n_img = bm / (txn * tyn);
+  const int chunk = tid & 7, lrow = tid >> 3;
+  const int ntaps = 9, ncc = a.Cin / 32, nk = ncc * ntaps;
+
+  unsigned h_voff[HALO_CH];
+  int h_lds[HALO_CH];
+#pragma unroll
+  for (int j = 0; j < HALO_CH; ++j) {
+    const int e = tid + NTHR * j, hp = e >> 3, hc = e & 7;      // (hc == chunk: NTHR % 8 == 0)
+    const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+    const int y = ty * PH + hy - 1, x = tx * 16 + hx - 1;
+    const bool ok = e < HALO_PX * 8 && y >= 0 && y < a.Hi && x >= 0 && x < a.Wi;
+    h_voff[j] = ok ? (unsigned)((((size_t)(n_img * a.Hi + y) * a.Wi + x) * a.Cin + hc * 4) * 4) : 0xFFFFFFFFu;
+    h_lds[j] = e < HALO_PX * 8 ? hp * LDK : -1;
+  }
+  unsigned b_voff[B_CH];
+#pragma unroll
+  for (int j = 0; j < B_CH; ++j) b_voff[j] = (unsigned)(((size_t)(lrow + RPP * j) * a.wstride + chunk * 4) * 4);
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0xFFFFFFFE, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.w + (size_t)bn * BN * a.wstride), 0, 0xFFFFFFFE, 0x00020000);
+
+  const float sc_a = dsee_pow2_scale(dsee_amax_read(a.amax_a)), sc_w = dsee_pow2_scale(dsee_amax_read(a.amax_w));
+  // 4 consecutive channels of one row -> 4 halves of each term, at byte 8 * chunk of the row's term-0 / term-1 half
+  auto store_split = [&](float* row, const f32x4& v, float sc) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h0, h1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e] * sc;
+      h0[e] = (_Float16)x;
+      h1[e] = (_Float16)(x - (float)h0[e]);
+    }
+    unsigned char* q = reinterpret_cast<unsigned char*>(row) + chunk * 8;
+    *reinterpret_cast<h4*>(q) = h0;
+    *reinterpret_cast<h4*>(q + 64) = h1;
+  };
+
+  f32x4 hreg[HALO_CH], rb[B_CH];
+  auto load_halo = [&](int cc, bool live) {
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(cc * (BK * 4));
+#pragma unroll
+    for (int j = 0; j < HALO_CH; ++j)
+      hreg[j] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, live ? h_voff[j] : 0xFFFFFFFFu, so, 0));
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int j = 0; j < HALO_CH; ++j)
+      if (h_lds[j] >= 0) store_split(Ah + h_lds[j], hreg[j], sc_a);
+  };
+  auto load_b = [&](int kt) {
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(kt * (BK * 4));
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], so, 0));
+  };
+  auto store_b = [&](int buf) {
+    float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) store_split(Bb + (lrow + RPP * j) * LDK, rb[j], sc_w);
+  };
+
+  f32x16 acc[MT][NT], part[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = part[i][j][r] = 0.f;
+
+  // fragment of k-step s16 (16 channels), term p, of the row at float offset `row`: 16 bytes at p * 64 + s16 * 32 + (lane >> 5) * 16
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  int a_frag[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a_frag[i] = ((wm * 4 + i * 2 + (frow >> 4)) * HALO_W + (frow & 15)) * LDK + fk;
+  const int b_frag = (wn * NT * 32 + frow) * LDK + fk;
+  auto tap_off = [&](int tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    return ((1 + a.off + kh * a.kdir) * HALO_W + (1 + a.off + kw * a.kdir)) * LDK;
+  };
+  u32x4v af[2][MT][2], bf[2][NT][2];
+  auto read_frags = [&](int toff, int buf, int s16, int set) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) af[set][i][p] = *reinterpret_cast<const u32x4v*>(Ah + a_frag[i] + toff + s16 * 8 + p * 16);
+    const float* Bc = Bs + buf * BN * LDK + b_frag + s16 * 8;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) bf[set][j][p] = *reinterpret_cast<const u32x4v*>(Bc + j * 32 * LDK + p * 16);
+  };
+  auto mma_group = [&](int set) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)   // a1*b0, a0*b1, a0*b0 (smallest first)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, af[set][i][q == 0 ? 1 : 0]),
+                                                              __builtin_bit_cast(f16x8v, bf[set][j][q == 1 ? 1 : 0]),
+                                                              part[i][j], 0, 0, 0);
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] += part[i][j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+      }
+  };
+
+  load_halo(0, true);
+  load_b(0);
+  int cur = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+    __syncthreads();  // nobody reads the previous chunk's halo / weight slabs any more
+    store_halo();
+    store_b(cur);
+    __syncthreads();
+    load_halo(min(cc + 1, ncc - 1), cc + 1 < ncc);  // next chunk's halo: 9 taps of MFMAs cover it
+    load_b(min(cc * ntaps + 1, nk - 1));
+    read_frags(tap_off(0), cur, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kt = cc * ntaps + tap;
+      read_frags(tap_off(tap), cur, 1, 1);
+      mma_group(0);
+      if (tap < 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(cur ^ 1);     // tap + 1's weights (loaded a whole tap ago) into the buffer every wave left before the last barrier
+        __syncthreads();
+        read_frags(tap_off(tap + 1), cur ^ 1, 0, 0);
+        load_b(min(kt + 2, nk - 1));
+        mma_group(1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+      } else {
+        mma_group(1);
+      }
+      if ((kt & (FLUSH - 1)) == FLUSH - 1) flush();
+    }
+  }
+  flush();
+  const float oscale = 1.f / (sc_a * sc_w);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] *= oscale;
+
+  conv_epilogue<MT, NT, BN, EPI_PLAIN>(a, acc, bn, wn, lane, [&](int i, int r) {
+    const int local = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    return (long)(n_img * a.Ho + ty * PH + (local >> 4)) * a.Wo + tx * 16 + (local & 15);
+  });
+}
+
 // ---------------------------------------------------------------- weight gradient (split-K)
 struct WgradArgs {
   const float* dout;  // [M][Cout]
@@ -1220,6 +1407,22 @@ static bool halo_ok(const ConvArgs& a) {
          (long)a.N * a.Hi * a.Wi * a.Cin * 4 + 65536 < 0xFFFFFFFEL;
 }
 
+template <int NT>
+int launch_conv_halo_f16(const ConvArgs& a, hipStream_t st) {
+  constexpr int BN = 2 * NT * 32;
+  const size_t lds = (size_t)(HALO_W * 10 + 2 * BN) * LDK * sizeof(float);
+  dim3 grid(a.M / 128, dsee_cdiv(a.Cout, BN));
+  conv_halo_f16_kernel<NT><<<grid, 256, lds, st>>>(a);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
+// split-operand halo kernel: 3 x 3 / stride 1 / pad 1 layers with whole 8 x 16 patches, 32-channel chunks and > 32 output columns
+static bool halo_f16_ok(const ConvArgs& a) {
+  return halo_ok(a) && a.amax_a && a.amax_w && a.Cin % 32 == 0 && a.Cout > 32 && !a.wt && a.wgroup_stride == 0 &&
+         a.dshift == 0 && a.ups == 0 && a.M % 128 == 0;
+}
+
 template <int MT, int NT, int WM, int WN, int EPI>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (MT == 2 && NT == 2 && WM == 2 && WN == 2 && halo_ok(a) && !a.amax_a) return launch_conv_halo<EPI, 2>(a, st);
@@ -1324,12 +1527,12 @@ int dsee_conv2d_fwd_amax(const dsee_conv_geom* g, const float* in, const float* 
 int dsee_conv2d_fwd_f16x2(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                           const float* residual, int residual_ld, float* out, int act, float slope,
                           const float* amax_in, const float* amax_w, hipStream_t st) {
-  return dsee_conv2d_fwd_f16x2_amax(g, in, w_packed, bias, residual, residual_ld, out, act, slope, amax_in, amax_w, nullptr, st);
+  return dsee_conv2d_fwd_f16x2_amax(g, in, w_packed, bias, residual, residual_ld, out, act, slope, amax_in, amax_w, nullptr, 0, st);
 }
 
 int dsee_conv2d_fwd_f16x2_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                                const float* residual, int residual_ld, float* out, int act, float slope,
-                               const float* amax_in, const float* amax_w, float* amax_out, hipStream_t st) {
+                               const float* amax_in, const float* amax_w, float* amax_out, int flags, hipStream_t st) {
   ConvArgs a = {};
   a.amax_out = amax_out;
   int rc = fill_geom(a, g);
@@ -1339,6 +1542,10 @@ int dsee_conv2d_fwd_f16x2_amax(const dsee_conv_geom* g, const float* in, const f
   a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out; a.act = act; a.slope = slope;
   a.res_ld = residual_ld > 0 ? residual_ld : a.Cout;
   a.amax_a = amax_in; a.amax_w = amax_w;
+  // (64-column tiles only: the 128-column instantiation needs 256 accumulator + fragment registers and spills at two blocks per
+  // CU; a wider layer runs two column blocks per patch, which converts the patch twice -- still 4.5x less than once per tap)
+  if (!(flags & DSEE_CONV_NO_HALO) && halo_f16_ok(a) && (long)(a.M / 128) * dsee_cdiv(a.Cout, 64) >= 256)
+    return launch_conv_halo_f16<1>(a, st);
   // round 6: a 128 x 128 grid that would leave most of the 256 CUs idle (the discriminator's 17^2 / 33^2 layers: 19-70 workgroups)
   // runs on 64 x 64 tiles instead
   if (a.Cout > 64 && small_grid(a)) return launch_conv<1, 1, 2, 2, EPI_PLAIN>(a, st);

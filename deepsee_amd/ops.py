@@ -352,7 +352,8 @@ def conv_raw(x, wp, geom, bias=None, res=None, act=L.ACT_NONE, slope=LRELU_SLOPE
     if _direct_split_on(exact) and _flops(geom) >= P().conv_f16x2_min_flop:
         ax, aw = tensor_amax(x, amax_cache), tensor_amax(wp)
         with _timed(_variant(geom).replace("halo", "igemm") + "_f16x2", _flops(geom)):   # (the halo kernel is fp32-only)
-            L.call("conv2d_fwd_f16x2_amax", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw, ao)
+            L.call("conv2d_fwd_f16x2_amax", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ax, aw, ao,
+                   0 if P().conv_halo_f16 else 1)       # (1 = DSEE_CONV_NO_HALO)
     else:
         with _timed(_variant(geom), _flops(geom)):
             L.call("conv2d_fwd_amax", C.byref(geom), x, wp, bias, res, res_ld, out, act, float(slope), ao)

@@ -89,9 +89,12 @@ int dsee_conv2d_fwd_f16x2(const dsee_conv_geom* g, const float* in, const float*
 int dsee_conv2d_fwd_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                          const float* residual, int residual_ld, float* out, int act, float slope, float* amax_out,
                          hipStream_t stream);
+/* flags: DSEE_CONV_NO_HALO keeps a 3 x 3 / stride 1 layer off the halo kernel (which stages an 8 x 16 patch and converts it to split
+ * fp16 once per 32-channel chunk instead of once per tap) -- for A/B measurements; results agree to fp32 rounding, not bit for bit. */
+#define DSEE_CONV_NO_HALO 1
 int dsee_conv2d_fwd_f16x2_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                                const float* residual, int residual_ld, float* out, int act, float slope,
-                               const float* amax_in, const float* amax_w, float* amax_out, hipStream_t stream);
+                               const float* amax_in, const float* amax_w, float* amax_out, int flags, hipStream_t stream);
 
 /* Winograd F(4x4,3x3) path for 3x3 / stride 1 / pad 1 convolutions (same call sites as dsee_conv2d_fwd):
  *   V = dsee_wino43_input(x)                                [36][T][Cin],  T = N*(H/4)*(W/4)

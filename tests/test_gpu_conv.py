@@ -42,6 +42,9 @@ CASES = [
     (3, 128, 128, 32, 3, 1, 1, 0, 0, True, True),
     (6, 128, 128, 64, 3, 1, 1, 0, 0, False, False),   # regression: 24 pixel splits; the dummy prefetch past the last
                                                       # slab once read beyond the end of `in` (fault at x_end + 16 KB)
+                                                      # (f16x2, round 6: the split-operand halo kernel, two column blocks, 4 chunks)
+    (32, 64, 64, 32, 3, 1, 1, 0, 2, True, False),     # VGG conv1_2's shape class: split-operand halo kernel (>= 256 workgroups)
+    (8, 64, 128, 64, 3, 1, 1, 0, 1, True, True),      # ... two column blocks with bias, residual and LeakyReLU
 ]
 
 
@@ -63,7 +66,7 @@ def test_conv_fwd_dgrad_wgrad(case, f16x2):
             ax, aw = torch.zeros(2048, device="cuda"), torch.zeros(2048, device="cuda")
             L.call("absmax", x_, x_.numel(), ax)
             L.call("absmax", w_, w_.numel(), aw)
-            L.call("conv2d_fwd_f16x2_amax", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_, ax, aw, ao)
+            L.call("conv2d_fwd_f16x2_amax", C.byref(geom_), x_, w_, b_, r_, 0, out_, act_, slope_, ax, aw, ao, 0)
         torch.cuda.synchronize()
         assert float(ao.max()) == float(out_.abs().max()), (float(ao.max()), float(out_.abs().max()))
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
