@@ -435,7 +435,7 @@ int dsee_spade_resblock_train_fwd(const dsee_norm_layer* norm_0, const float* w_
 namespace {
 struct BwdScratch {
   uint16_t *dm2c, *utc, *dm2n, *ute;
-  float *wsw, *dv, *dh, *dmid, *sums, *wsmod, *wst, *dve, *dactv, *wse, *amax, *dbias, *chws;
+  float *wsw, *dv, *dh, *dmid, *sums, *wsmod, *wst, *dve, *dactv, *wse, *amax, *dbias, *chws, *g1, *oh;
   size_t wsw_bytes, wst_bytes, wse_bytes;
 };
 BwdScratch bwd_scratch(Arena& a, int N, int H, int W, int C, int nc, int has_t, int lab_h, int lab_w, int shift) {
@@ -458,9 +458,13 @@ BwdScratch bwd_scratch(Arena& a, int N, int H, int W, int C, int nc, int has_t, 
   b.dve = a.take<float>(36 * T * kHidden);
   b.dactv = a.take<float>(px * kHidden);
   dsee_conv_geom g = {N, H, W, ld, H, W, kHidden, 3, 3, 1, -1, 1, 0, 0, 1};
-  const size_t w1 = has_t ? dsee_conv2d_wgrad_workspace(&g) : dsee_onehot_conv3x3_wgrad_workspace(N, lab_h, lab_w, shift, nc);
+  // (SPADE-only norms: mlp_shared's weight gradient runs on the MFMA kernel over 32 materialised one-hot channels, ops.py round 6)
+  dsee_conv_geom g32 = {N, H, W, 32, H, W, kHidden, 3, 3, 1, -1, 1, 0, 0, 1};
+  const size_t w1 = dsee_conv2d_wgrad_workspace(has_t ? &g : &g32);
   b.wse_bytes = w1;
   b.wse = a.take<float>(w1 / sizeof(float) + 64);
+  b.g1 = has_t ? nullptr : a.take<float>(px * kHidden);
+  b.oh = has_t ? nullptr : a.take<float>(px * 32);
   b.amax = a.take<float>(8 * kAmaxFloats);
   b.dbias = a.take<float>(3 * C + 64);
   const size_t c1 = dsee_channel_dot_workspace((long)px, kHidden), c2 = dsee_wino43_dout_f16x2_workspace();
@@ -574,9 +578,24 @@ int dsee_spade_resblock_bwd(const dsee_norm_layer* norm_0, const float* w_conv_0
       if (ngr[i]->db_shared) DSEE_TRY(dsee_channel_dot(B.dactv, nullptr, ngr[i]->db_shared, (long)px, kHidden, B.chws, stream));
     } else {
       DSEE_TRY(dsee_wino43_input_adjoint_amax(B.dve, B.dactv, N, H, W, kHidden, amax_da, stream));
-      if (ngr[i]->dw_shared && ngr[i]->db_shared)
-        DSEE_TRY(dsee_onehot_conv3x3_wgrad(labels, B.dactv, kHidden, ns.cat, ld, N, lab_h, lab_w, shift, label_nc, ngr[i]->dw_shared,
-                                           ngr[i]->db_shared, B.wse, stream));
+      if (ngr[i]->dw_shared && ngr[i]->db_shared) {
+        // ReLU backward of the embedding (+ max |g|), the one-hot label channels materialised, then the generic weight gradient
+        // (fp16x2 operands above 1 GFLOP like ops.py::wgrad_raw) and the bias gradient as a channel sum
+        float *amax_g1 = B.amax + 4 * kAmaxFloats, *amax_oh = B.amax + 5 * kAmaxFloats;
+        DSEE_TRY(zero(amax_g1, 2 * kAmaxFloats, stream, who));
+        DSEE_TRY(dsee_act_bwd_amax(B.dactv, ns.cat, B.g1, (long)(px * kHidden), DSEE_ACT_RELU, slope, amax_g1, stream));
+        DSEE_TRY(dsee_label_onehot(labels, B.oh, N, lab_h, lab_w, shift, 32, 0, stream));
+        dsee_conv_geom gs = {N, H, W, 32, H, W, kHidden, 3, 3, 1, -1, 1, 0, 0, 1};
+        const double flops = 2.0 * (double)px * kHidden * 9.0 * 32.0;
+        if (flops >= 1e9) {
+          DSEE_TRY(dsee_absmax(B.oh, (long)(px * 32), amax_oh, stream));
+          DSEE_TRY(dsee_conv2d_wgrad_f16x2(&gs, B.oh, B.g1, B.wse, B.wse_bytes, ngr[i]->dw_shared, kHidden, 0, label_nc, amax_oh, amax_g1,
+                                           stream));
+        } else {
+          DSEE_TRY(dsee_conv2d_wgrad(&gs, B.oh, B.g1, B.wse, B.wse_bytes, ngr[i]->dw_shared, kHidden, 0, label_nc, stream));
+        }
+        DSEE_TRY(dsee_channel_dot(B.g1, nullptr, ngr[i]->db_shared, (long)px, kHidden, B.chws, stream));
+      }
     }
     if (ngr[i]->dgamma_beta_sums &&
         hipMemcpyAsync(ngr[i]->dgamma_beta_sums, B.sums + 2 * C, 2 * C * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {

@@ -1936,8 +1936,20 @@ class SeanNormTable(torch.autograd.Function):
                     dlow = torch.empty_like(actv_low)
                     L.call("sumpool", dactv, dlow, n, h, w, NHIDDEN, ctx.cat_ups)
                     dactv, act_lo, ld_lo = dlow, actv_low, NHIDDEN
-                L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, act_lo, ld_lo, n, lab.h, lab.w, shift, lab.nc,
-                       dw_sh, db_sh, wso)
+                if P().onehot_wgrad_mfma and ld_lo == NHIDDEN and _direct_split_on():
+                    # round 6: the compare-select kernel is VALU bound (128 channels x 9 taps x 20 labels per pixel: 0.29 ms at 64^2,
+                    # N = 8); the MFMA weight gradient over 32 materialised one-hot channels takes 0.07 (profiles/r06_onehot_wgrad.txt)
+                    rh, rw_ = dactv.shape[1], dactv.shape[2]
+                    g1 = torch.empty_like(dactv)
+                    tag_amax(g1, amax_slot())
+                    L.call("act_bwd_amax", dactv.contiguous(), act_lo, g1, C.c_long(g1.numel()), L.ACT_RELU, LRELU_SLOPE, g1.dsee_amax)
+                    oh = new(n, rh, rw_, 32)
+                    L.call("label_onehot", lab.t, oh, n, lab.h, lab.w, shift, 32, 0)
+                    dw_sh = wgrad_raw(oh, g1, L.geom_fwd(n, rh, rw_, 32, NHIDDEN, 3, 1, 1, 0), NHIDDEN, lab.nc, 3, 3)
+                    db_sh = channel_dot(g1, None, NHIDDEN).clone()
+                else:
+                    L.call("onehot_conv3x3_wgrad", lab.t, dactv, NHIDDEN, act_lo, ld_lo, n, lab.h, lab.w, shift, lab.nc,
+                           dw_sh, db_sh, wso)
         if wino_w and not fused_d:
             dw2a, dtable = wino_wgrad()
         if wino_w:

@@ -55,6 +55,7 @@ class KernelPlan:
     dgrad_s2_parity: bool = True
     presplit_min_tiles: int = 512      # fewest 256 x 256 tiles for which a layer takes the pre-split NT GEMM (below: 128 x 128 tiles, fp32 A)
     conv_halo_f16: bool = True         # 3 x 3 / stride 1 direct layers on the split-operand halo kernel (patch converted once per chunk, not per tap)
+    onehot_wgrad_mfma: bool = True     # SPADE-only norms: mlp_shared's weight gradient on the MFMA kernel over materialised one-hot channels
     conv_amax_out: bool = True         # direct layers write max |out| in their epilogue (operand bound of the next direct layer)
     # A dY A^T of a convolution written pre-split for its weight gradient and adjoint data gradient (False: fp32 dM)
     presplit_dm: bool = True

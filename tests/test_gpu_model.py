@@ -1117,7 +1117,7 @@ SWITCHES = [("keep_v", False), ("adjoint_dgrad", False), ("fuse_dm", False), ("f
             ("fused_norm", False), ("thin_gemm", False), ("gemm_f16x2", False), ("gemm_split", False),
             ("winograd_wgrad", False), ("winograd_mod", False), ("conv_f16x2_min_flop", 0.0), ("dout_sums", False),
             ("share_stats", False), ("producer_stats", False), ("presplit_a", False), ("presplit_dm", False),
-            ("presplit_gb", False), ("sign_mask", False), ("defer_act", False), ("gemm_w4", False), ("dgrad_s2_parity", False), ("conv_amax_out", False), ("conv_halo_f16", False), ("fused_w4", True), ("branch_streams", None)]      # None: the other side of a bool
+            ("presplit_gb", False), ("sign_mask", False), ("defer_act", False), ("gemm_w4", False), ("dgrad_s2_parity", False), ("conv_amax_out", False), ("conv_halo_f16", False), ("onehot_wgrad_mfma", False), ("fused_w4", True), ("branch_streams", None)]      # None: the other side of a bool
 
 
 def test_kernel_path_switches():
