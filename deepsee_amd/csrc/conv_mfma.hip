@@ -830,6 +830,80 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f16_kernel(ConvArgs a) {
   });
 }
 
+// 3 x 3 / stride 1 / pad 1 over a 4-channel (RGB0) input with 64 output channels (VGG conv1_1, `architecture.py:151-181`): K = 36.  The
+// implicit-GEMM kernel spends a 32-k LDS slab, two barriers and a gather per tap on it (15 TFLOP/s: 0.165 ms for a layer whose
+// only real cost is writing 134 MB).  Here nothing goes through LDS: a lane builds its A fragments straight from global memory -- the
+// 8 k of a 32x32x16 fragment are two taps x 4 channels = two 16-byte loads --, the 64 x 48 weights live in registers as split
+// fragments for the whole kernel, a wave owns 64 consecutive pixels x 64 channels (36 MFMAs) and the plain epilogue stores them.
+__global__ __launch_bounds__(256) void conv3x3_c4_f16_kernel(ConvArgs a) {
+  typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, kg = lane >> 5;
+  const float sc_a = dsee_pow2_scale(dsee_amax_read(a.amax_a)), sc_w = dsee_pow2_scale(dsee_amax_read(a.amax_w));
+  auto split8 = [&](const f32x4& u, const f32x4& v, float sc, f16x8v& hi, f16x8v& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (e < 4 ? u[e] : v[e - 4]) * sc;
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+  };
+  f16x8v bh[2][3], bl[2][3];     // weights: column block j, k-slab s (k = s * 16 + kg * 8 ..+7 of row j * 32 + l31)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float* wr = a.w + (size_t)(j * 32 + l31) * a.wstride + s * 16 + kg * 8;
+      split8(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 4), sc_w, bh[j][s], bl[j][s]);
+    }
+  const float oscale = 1.f / (sc_a * sc_w);
+  const long ntile = ((long)a.M + 63) / 64;
+  for (long t = (long)blockIdx.x * 4 + wave; t < ntile; t += (long)gridDim.x * 4) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long p = t * 64 + i * 32 + l31;
+      const unsigned pu = (unsigned)(p < a.M ? p : 0), r_ = pu / (unsigned)a.Wi, n_ = r_ / (unsigned)a.Hi;
+      const int x = (int)(pu - r_ * (unsigned)a.Wi), y = (int)(r_ - n_ * (unsigned)a.Hi);
+      const float* img = a.in + (size_t)n_ * a.Hi * a.Wi * 4;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        f32x4 v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int tap = s * 4 + kg * 2 + q, ky = tap / 3, kx = tap - ky * 3;
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          const bool ok = p < a.M && tap < 9 && yy >= 0 && yy < a.Hi && xx >= 0 && xx < a.Wi;
+          v[q] = ok ? *reinterpret_cast<const f32x4*>(img + ((size_t)yy * a.Wi + xx) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        f16x8v ah, al;
+        split8(v[0], v[1], sc_a, ah, al);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // a1*b0, a0*b1, a0*b0 (smallest first)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j][s], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j][s], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j][s], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= oscale;
+    conv_epilogue<2, 2, 64, EPI_PLAIN>(a, acc, 0, 0, lane, [&](int i, int r) {
+      const long row = t * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      return row < a.M ? row : -1L;
+    });
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient (split-K)
 struct WgradArgs {
   const float* dout;  // [M][Cout]
@@ -1407,6 +1481,19 @@ static bool halo_ok(const ConvArgs& a) {
          (long)a.N * a.Hi * a.Wi * a.Cin * 4 + 65536 < 0xFFFFFFFEL;
 }
 
+static bool c4_f16_ok(const ConvArgs& a) {
+  return a.Cin == 4 && a.Cout == 64 && a.KH == 3 && a.KW == 3 && a.mul == 1 && a.off == -1 && a.kdir == 1 && a.dshift == 0 &&
+         a.ups == 0 && a.korder == 0 && a.Hi == a.Ho && a.Wi == a.Wo && a.amax_a && a.amax_w && !a.wt && a.wgroup_stride == 0 &&
+         a.Kpad >= 48 && a.M >= 16384;
+}
+
+int launch_conv3x3_c4_f16(const ConvArgs& a, hipStream_t st) {
+  const long ntile = ((long)a.M + 63) / 64;
+  conv3x3_c4_f16_kernel<<<(unsigned)min(2048L, (ntile + 3) / 4), 256, 0, st>>>(a);
+  DSEE_LAUNCH_CHECK();
+  return DSEE_OK;
+}
+
 template <int NT>
 int launch_conv_halo_f16(const ConvArgs& a, hipStream_t st) {
   constexpr int BN = 2 * NT * 32;
@@ -1544,6 +1631,7 @@ int dsee_conv2d_fwd_f16x2_amax(const dsee_conv_geom* g, const float* in, const f
   a.amax_a = amax_in; a.amax_w = amax_w;
   // (64-column tiles only: the 128-column instantiation needs 256 accumulator + fragment registers and spills at two blocks per
   // CU; a wider layer runs two column blocks per patch, which converts the patch twice -- still 4.5x less than once per tap)
+  if (!(flags & DSEE_CONV_NO_HALO) && c4_f16_ok(a)) return launch_conv3x3_c4_f16(a, st);
   if (!(flags & DSEE_CONV_NO_HALO) && halo_f16_ok(a) && (long)(a.M / 128) * dsee_cdiv(a.Cout, 64) >= 256)
     return launch_conv_halo_f16<1>(a, st);
   // round 6: a 128 x 128 grid that would leave most of the 256 CUs idle (the discriminator's 17^2 / 33^2 layers: 19-70 workgroups)

@@ -45,6 +45,7 @@ CASES = [
                                                       # (f16x2, round 6: the split-operand halo kernel, two column blocks, 4 chunks)
     (32, 64, 64, 32, 3, 1, 1, 0, 2, True, False),     # VGG conv1_2's shape class: split-operand halo kernel (>= 256 workgroups)
     (8, 64, 128, 64, 3, 1, 1, 0, 1, True, True),      # ... two column blocks with bias, residual and LeakyReLU
+    (8, 3, 64, 50, 3, 1, 1, 0, 2, True, False),       # VGG conv1_1's shape class (f16x2: the LDS-free K = 36 kernel, ragged last tile)
 ]
 
 

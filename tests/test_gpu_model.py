@@ -1056,6 +1056,12 @@ def test_half_mode_tracks_fp32():
             # terms live on a scale of 0..2: held to half of it and to 4x the fp32 rounding drift, whichever is larger; the
             # feature-matching and VGG terms (what the generator is mostly trained on) keep the 30 % bound in every window.
             tol = max(1.0, 4.0 * abs(my - mb))
+        elif lo >= 10 and k in ("GAN", "D_Fake", "D_Real"):
+            # (round 6) the drift can set in before iteration 30: after mlp_shared's weight gradient moved to another kernel (one
+            # rounding per element) the fp32 run's D_Fake mean over 10-30 read 0.43 while BOTH the 16-bit run (0.86) and the
+            # yardstick run (0.88) stayed together.  The 16-bit run may be as far from the fp32 run as twice what the two fp32-class
+            # runs are apart, capped at half the hinge scale
+            tol = max(tol, min(1.0, 2.0 * abs(my - mb)))
         assert abs(ma - mb) <= tol, (lo, hi, k, ma, mb, my)
 
 

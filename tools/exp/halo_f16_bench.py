@@ -9,7 +9,7 @@ def timeit(fn, it=20):
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / it
-for (n, r, ci, co) in [(8, 256, 64, 64), (8, 128, 64, 128), (8, 128, 128, 64), (8, 64, 128, 256), (16, 64, 64, 64)]:
+for (n, r, ci, co) in [(8, 256, 4, 64), (8, 256, 64, 64), (8, 128, 64, 128), (8, 128, 128, 64), (8, 64, 128, 256), (16, 64, 64, 64)]:
     x = torch.randn(n, r, r, ci, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
     geom = L.geom_fwd(n, r, r, ci, co, 3, 1, 1)
     wp = torch.empty(L.wrows(co), L.kpad(3, 3, ci), device="cuda")
