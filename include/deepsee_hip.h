@@ -90,7 +90,8 @@ int dsee_conv2d_fwd_amax(const dsee_conv_geom* g, const float* in, const float* 
                          const float* residual, int residual_ld, float* out, int act, float slope, float* amax_out,
                          hipStream_t stream);
 /* flags: DSEE_CONV_NO_HALO keeps a 3 x 3 / stride 1 layer off the halo kernel (which stages an 8 x 16 patch and converts it to split
- * fp16 once per 32-channel chunk instead of once per tap) -- for A/B measurements; results agree to fp32 rounding, not bit for bit. */
+ * fp16 once per 32-channel chunk instead of once per tap) and a 4-channel input off the LDS-free K = 36 kernel -- for A/B
+ * measurements; both issue the same MFMA sequence on the same fragments as the implicit-GEMM kernel: bit-identical results. */
 #define DSEE_CONV_NO_HALO 1
 int dsee_conv2d_fwd_f16x2_amax(const dsee_conv_geom* g, const float* in, const float* w_packed, const float* bias,
                                const float* residual, int residual_ld, float* out, int act, float slope,
