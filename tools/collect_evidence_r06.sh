@@ -32,6 +32,7 @@ run $O/bench_ab_gemm_w8.json python bench.py --steps 20 --warmup 5 --no-f32-run 
 run $O/bench_ab_dgrad_gather.json python bench.py --steps 20 --warmup 5 --no-f32-run --no-cpu-baseline --plan dgrad_s2_parity=False
 run $O/bench_ab_absmax_passes.json python bench.py --steps 20 --warmup 5 --no-f32-run --no-cpu-baseline --plan conv_amax_out=False
 run $O/bench_ab_conv_igemm_no_halo.json python bench.py --steps 20 --warmup 5 --no-f32-run --no-cpu-baseline --plan conv_halo_f16=False
+run $O/bench_ab_onehot_wgrad_valu.json python bench.py --steps 20 --warmup 5 --no-f32-run --no-cpu-baseline --plan onehot_wgrad_mfma=False
 run $O/bench_ab_fused_w4.json python bench.py --steps 20 --warmup 5 --no-f32-run --no-cpu-baseline --plan fused_w4=True
 run $O/step_shapes.txt python tools/step_shapes.py
 run $O/step_functions.txt python tools/step_functions.py 60
