@@ -27,7 +27,18 @@ for r in (256, 128, 64, 32):
     ws = ops.scratch(L.lib().dsee_onehot_conv3x3_wgrad_workspace(n, 256, 256, shift, nc), "ohw")
     def onehot():
         L.call("onehot_conv3x3_wgrad", lab, dactv, NH, cat, ld, n, 256, 256, shift, nc, dw2, db2, ws)
+    oh = ops.new(n, r, r, 32)
+    g32 = L.geom_fwd(n, r, r, 32, NH, 3, 1, 1, 0)
+    def compact():
+        L.call("label_onehot", lab, oh, n, 256, 256, shift, 32, 0)
+        dw = ops.wgrad_raw(oh, dactv, g32, NH, nc, 3, 3)
+        db = ops.channel_dot(dactv, None, NH)
+        return dw, db
+    t3 = timeit(compact)
+    dw3, _ = compact()
+    print("%3d^2: MFMA wgrad over a compact 32-channel one-hot tensor (+ label_onehot + channel_dot) %.3f ms" % (r, t3))
     t1, t2 = timeit(mfma), timeit(onehot)
+    assert float((dw3 - mfma()[0]).abs().max()) < 1e-3 * float(dw3.abs().max())
     dw, db = mfma(); onehot(); torch.cuda.synchronize()
     print("%3d^2: MFMA wgrad + channel_dot %.3f ms | one-hot kernel %.3f ms | dw rel diff %.1e, db rel diff %.1e"
           % (r, t1, t2, float((dw - dw2).norm() / dw2.norm()), float((db - db2).norm() / db2.norm())))
